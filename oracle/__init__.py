@@ -1,0 +1,257 @@
+"""ctypes/numpy front-end of the CPU oracle (``oracle/liboracle.so``).
+
+TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` - as the checker, never as the product.  ``artist_amd``
+must not import this package (tests/test_boundary.py enforces it).
+
+All functions take/return numpy arrays; float32 inputs run the ``_f32`` restatement (the
+reference's arithmetic), float64 inputs the ``_f64`` yardstick.
+"""
+from __future__ import annotations
+
+import ctypes
+import pathlib
+import subprocess
+
+import numpy as np
+
+_DIR = pathlib.Path(__file__).resolve().parent
+_LIB = None
+
+
+def build(force: bool = False) -> pathlib.Path:
+    so = _DIR / "liboracle.so"
+    srcs = [_DIR / "artist_oracle.c", _DIR / "oracle_impl.inc"]
+    if force or not so.exists() or any(s.exists() and s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.check_call(["make", "-C", str(_DIR), "-s", "-B", "liboracle.so"])
+    return so
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(str(build()))
+        _LIB.orc_sampler_indices.restype = ctypes.c_int64
+    return _LIB
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def _sfx(dtype) -> str:
+    return {np.dtype(np.float32): "_f32", np.dtype(np.float64): "_f64"}[np.dtype(dtype)]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+_i64 = ctypes.c_int64
+_dbl = ctypes.c_double
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def reflect(incident, normals):
+    dt = normals.dtype
+    inc, nrm = _c(incident, dt), _c(normals, dt)
+    H, P = nrm.shape[0], nrm.shape[1]
+    out = np.empty_like(nrm)
+    _check(getattr(lib(), "orc_reflect" + _sfx(dt))(_p(inc), _p(nrm), _i64(H), _i64(P), _p(out)), "reflect")
+    return out
+
+
+def _dist_args(dist_u, dist_e):
+    """Element strides of the [H,R,P] distortion views (they may be stride-2 views of one
+    interleaved buffer, artist/scene/sun.py:227-234)."""
+    assert dist_u.shape == dist_e.shape and dist_u.strides == dist_e.strides
+    it = dist_u.itemsize
+    assert all(s % it == 0 for s in dist_u.strides)
+    return [_i64(s // it) for s in dist_u.strides]
+
+
+def trace_fwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
+              resolution, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, debug=False):
+    """Returns (flux [H,Hh,W], factors [3,H]) and, with debug=True, a dict of per-stage arrays."""
+    dt = origins.dtype
+    o, n, inc = _c(origins, dt), _c(normals, dt), _c(incident, dt)
+    du = np.asarray(dist_u, dtype=dt)
+    de = np.asarray(dist_e, dtype=dt)
+    H, P = o.shape[0], o.shape[1]
+    R = du.shape[1]
+    assert du.shape == (H, R, P), (du.shape, (H, R, P))
+    tix = _c(target_idx, np.int32)
+    c, m, d = _c(centers, dt), _c(plane_normals, dt), _c(dims, dt)
+    T = c.shape[0]
+    W, Hh = int(resolution[0]), int(resolution[1])
+    flux = np.empty((H, Hh, W), dtype=dt)
+    factors = np.empty((3, H), dtype=dt)
+    dbg = {}
+    if debug:
+        dbg = dict(reflected=np.empty((H, P, 4), dt), scattered=np.empty((H, R, P, 4), dt),
+                   e_px=np.empty((H, R, P), dt), u_px=np.empty((H, R, P), dt),
+                   distances=np.empty((H, R, P), dt), intensities=np.empty((H, R, P), dt))
+    rc = getattr(lib(), "orc_trace_fwd" + _sfx(dt))(
+        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d),
+        _dbl(ray_magnitude), _dbl(extinction), _dbl(reflectivity),
+        _i64(H), _i64(R), _i64(P), _i64(T), _i64(W), _i64(Hh), _p(flux), _p(factors), ctypes.c_int(nthreads),
+        _p(dbg.get("reflected")), _p(dbg.get("scattered")), _p(dbg.get("e_px")), _p(dbg.get("u_px")),
+        _p(dbg.get("distances")), _p(dbg.get("intensities")))
+    _check(rc, "trace_fwd")
+    return (flux, factors, dbg) if debug else (flux, factors)
+
+
+def trace_bwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
+              resolution, grad_flux, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0):
+    dt = origins.dtype
+    o, n, inc = _c(origins, dt), _c(normals, dt), _c(incident, dt)
+    du = np.asarray(dist_u, dtype=dt)
+    de = np.asarray(dist_e, dtype=dt)
+    H, P = o.shape[0], o.shape[1]
+    R = du.shape[1]
+    tix = _c(target_idx, np.int32)
+    c, m, d = _c(centers, dt), _c(plane_normals, dt), _c(dims, dt)
+    T = c.shape[0]
+    W, Hh = int(resolution[0]), int(resolution[1])
+    g = _c(grad_flux, dt)
+    assert g.shape == (H, Hh, W)
+    go, gn = np.empty_like(o), np.empty_like(n)
+    rc = getattr(lib(), "orc_trace_bwd" + _sfx(dt))(
+        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d),
+        _dbl(ray_magnitude), _dbl(extinction), _dbl(reflectivity),
+        _i64(H), _i64(R), _i64(P), _i64(T), _i64(W), _i64(Hh), _p(g), _p(go), _p(gn), ctypes.c_int(nthreads))
+    _check(rc, "trace_bwd")
+    return go, gn
+
+
+def per_target(bitmaps, target_idx, n_targets):
+    dt = bitmaps.dtype
+    b = _c(bitmaps, dt)
+    H = b.shape[0]
+    npix = int(np.prod(b.shape[1:]))
+    out = np.empty((n_targets,) + b.shape[1:], dtype=dt)
+    _check(getattr(lib(), "orc_per_target" + _sfx(dt))(_p(b), _p(_c(target_idx, np.int32)), _i64(H), _i64(n_targets),
+                                                      _i64(npix), _p(out)), "per_target")
+    return out
+
+
+def uniform_knots(n_ctrl, degree, dtype=np.float32):
+    """artist/nurbs/surfaces.py:128-147 - clamped uniform knot vector (torch.linspace values)."""
+    import torch
+
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[np.dtype(dtype)]
+    k = torch.zeros(n_ctrl + degree + 1, dtype=tdt)
+    k[degree:-degree] = torch.linspace(0, 1, n_ctrl - degree + 1, dtype=tdt)
+    k[-degree:] = 1
+    return k.numpy()
+
+
+def _nurbs_common(cp, uv, degrees, knots_u, knots_v, dt):
+    cp, uv = _c(cp, dt), _c(uv, dt)
+    H, F, nu, nv, _ = cp.shape
+    M = uv.shape[2]
+    p, q = int(degrees[0]), int(degrees[1])
+    if knots_u is None:
+        knots_u = uniform_knots(nu, p, dt)
+    if knots_v is None:
+        knots_v = uniform_knots(nv, q, dt)
+    ku = _c(np.broadcast_to(np.asarray(knots_u, dtype=dt), (H, F, nu + p + 1)), dt)
+    kv = _c(np.broadcast_to(np.asarray(knots_v, dtype=dt), (H, F, nv + q + 1)), dt)
+    nuq_u = np.unique(ku.reshape(-1, ku.shape[-1]), axis=1).shape[1]
+    nuq_v = np.unique(kv.reshape(-1, kv.shape[-1]), axis=1).shape[1]
+    return cp, uv, ku, kv, H, F, M, nu, nv, p, q, nuq_u, nuq_v
+
+
+def nurbs_fwd(cp, uv, degrees, canting=None, translations=None, knots_u=None, knots_v=None, uniform=True):
+    dt = cp.dtype
+    cp, uv, ku, kv, H, F, M, nu, nv, p, q, nuq_u, nuq_v = _nurbs_common(cp, uv, degrees, knots_u, knots_v, dt)
+    cant, tr = _c(canting, dt), _c(translations, dt)
+    pts = np.empty((H, F, M, 4), dtype=dt)
+    nrm = np.empty((H, F, M, 4), dtype=dt)
+    rc = getattr(lib(), "orc_nurbs_fwd" + _sfx(dt))(
+        _p(cp), _p(uv), _p(ku), _p(kv), _p(cant), _p(tr), ctypes.c_int(p), ctypes.c_int(q), ctypes.c_int(int(uniform)),
+        _i64(nuq_u), _i64(nuq_v), _i64(H), _i64(F), _i64(M), _i64(nu), _i64(nv), _p(pts), _p(nrm))
+    _check(rc, "nurbs_fwd")
+    return pts, nrm
+
+
+def nurbs_bwd(cp, uv, degrees, g_points, g_normals, canting=None, knots_u=None, knots_v=None, uniform=True):
+    dt = cp.dtype
+    cp, uv, ku, kv, H, F, M, nu, nv, p, q, nuq_u, nuq_v = _nurbs_common(cp, uv, degrees, knots_u, knots_v, dt)
+    cant = _c(canting, dt)
+    gp, gn = _c(g_points, dt), _c(g_normals, dt)
+    g_cp = np.empty_like(cp)
+    rc = getattr(lib(), "orc_nurbs_bwd" + _sfx(dt))(
+        _p(cp), _p(uv), _p(ku), _p(kv), _p(cant), ctypes.c_int(p), ctypes.c_int(q), ctypes.c_int(int(uniform)),
+        _i64(nuq_u), _i64(nuq_v), _i64(H), _i64(F), _i64(M), _i64(nu), _i64(nv), _p(gp), _p(gn), _p(g_cp))
+    _check(rc, "nurbs_bwd")
+    return g_cp
+
+
+def find_spans(x, knots, n_ctrl, degree, uniform=True):
+    """Span search alone (artist/nurbs/surfaces.py:157-245) via a degenerate 1-facet evaluation is
+    overkill; restated here in numpy on top of the same formulae for the known-answer test."""
+    x = np.asarray(x)
+    knots = np.asarray(knots)
+    if uniform:
+        n_unique = len(np.unique(knots))
+        return (np.floor(x * x.dtype.type(n_unique - 1)).astype(np.int64) + degree)
+    out = np.full(x.shape, degree, dtype=np.int64)
+    for i, xv in enumerate(x.flat):
+        for k in range(degree, n_ctrl):
+            if xv >= knots[k] and xv < knots[k + 1]:
+                out.flat[i] = k
+                break
+        if abs(xv - knots[n_ctrl]) <= 1e-5 + 1e-5 * abs(knots[n_ctrl]):
+            out.flat[i] = n_ctrl - 1
+    return out
+
+
+def sampler_indices(n_samples, n_active_heliostats, world_size, rank):
+    buf = np.empty(max(int(n_samples), 1), dtype=np.int64)
+    n = lib().orc_sampler_indices(_i64(n_samples), _i64(n_active_heliostats), _i64(world_size), _i64(rank),
+                                  _p(buf), _i64(buf.size))
+    if n < 0:
+        raise RuntimeError("sampler buffer too small")
+    return buf[:n].copy()
+
+
+# ---- stage entry points (known-answer tests) ------------------------------------------------
+def scatter(e, u, dirs):
+    """rotate_distortions(e, u) @ d for N independent triples (broadcast by the caller)."""
+    dt = dirs.dtype
+    e, u, dirs = _c(e, dt).reshape(-1), _c(u, dt).reshape(-1), _c(dirs, dt).reshape(-1, 4)
+    assert e.shape == u.shape and e.shape[0] == dirs.shape[0]
+    out = np.empty_like(dirs)
+    _check(getattr(lib(), "orc_scatter" + _sfx(dt))(_p(e), _p(u), _p(dirs), _i64(e.shape[0]), _p(out)), "scatter")
+    return out
+
+
+def line_plane(dirs, mags, origins, centers, plane_normals, dims, target, resolution=(256, 256)):
+    dt = dirs.dtype
+    dirs, mags, origins = _c(dirs, dt).reshape(-1, 4), _c(mags, dt).reshape(-1), _c(origins, dt).reshape(-1, 4)
+    N = dirs.shape[0]
+    outs = [np.empty(N, dtype=dt) for _ in range(4)]
+    rc = getattr(lib(), "orc_line_plane" + _sfx(dt))(
+        _p(dirs), _p(mags), _p(origins), _i64(N), _p(_c(centers, dt)), _p(_c(plane_normals, dt)), _p(_c(dims, dt)),
+        _i64(target), _i64(int(resolution[0])), _i64(int(resolution[1])), *[_p(o) for o in outs])
+    _check(rc, "line_plane")
+    return outs
+
+
+def splat(e_px, u_px, inten, resolution):
+    dt = e_px.dtype
+    e, u, i = _c(e_px, dt).reshape(-1), _c(u_px, dt).reshape(-1), _c(inten, dt).reshape(-1)
+    W, Hh = int(resolution[0]), int(resolution[1])
+    out = np.empty((Hh, W), dtype=dt)
+    _check(getattr(lib(), "orc_splat" + _sfx(dt))(_p(e), _p(u), _p(i), _i64(e.shape[0]), _i64(W), _i64(Hh), _p(out)),
+           "splat")
+    return out

@@ -1,0 +1,54 @@
+"""pytest configuration: `gpu` marker + shared helpers.
+
+Mirrors the reference's test strategy: inline known-answer vectors for
+every stage, integration fixtures generated from the imported reference, determinism by seed.
+"""
+import pathlib
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(GOLDEN / f"{name}.npz"))
+        return cache[name]
+
+    return load
+
+
+STAGE_CASES = ["small_deg3", "small_deg2_tilted", "small_offtarget", "mid_256"]
+
+
+def sun_distortions(n_heliostats, n_rays, n_points, covariance=4.3681e-06, mean=0.0, seed=7):
+    """The reference's distortion recipe (artist/scene/sun.py:96-119, 224-234): seeded CPU
+    MultivariateNormal sample of shape [H,R,P,2], returned as the two stride-2 views (u, e)."""
+    import torch
+
+    torch.manual_seed(seed)
+    mvn = torch.distributions.MultivariateNormal(
+        torch.tensor([mean, mean], dtype=torch.float),
+        torch.tensor([[covariance, 0], [0, covariance]], dtype=torch.float))
+    du, de = mvn.sample((n_heliostats, n_rays, n_points)).permute(3, 0, 1, 2)
+    return du, de

@@ -1,0 +1,489 @@
+#!/usr/bin/env python3
+"""Golden-vector generator for the ARTIST hot path (runs ONLY in the build container).
+
+TEST INFRASTRUCTURE - not part of the product.  This script imports the *reference*
+(ARTIST v2.0.0, read-only at /root/reference), drives it through its public constructors
+on small synthetic scenarios, and writes the inputs + outputs of every stage of the hot
+path as ``.npz`` fixtures next to this file.  The fixtures (pure data) travel to the GPU
+box; the reference does not.
+
+Import recipe: four packages that the reference imports at module
+scope but that are absent from this image (colorlog, h5py, torchvision, paint) are
+replaced by empty module objects - they are only used for logging colours, file IO and
+type annotations, none of which the hot path touches.  ``artist.field`` must be imported
+first (circular import otherwise) and the CWD must be a scratch dir because importing
+``artist.util`` creates ./runtime_log.txt.
+
+Usage:  python tests/golden/generate_golden.py            (writes tests/golden/*.npz)
+
+Stages captured per scenario (reference file:line each array comes from):
+  nurbs points/normals     artist/nurbs/surfaces.py:475-689
+  orientation [H,4,4]      artist/field/kinematics_rigid_body.py:540-634
+  aligned points/normals   artist/field/heliostat_group_rigid_body.py:217-222
+  reflected                artist/raytracing/geometry.py:11-41
+  scattered directions     artist/raytracing/heliostat_ray_tracer.py:510-561
+  e_px,u_px,t,intensity    artist/raytracing/geometry.py:44-204
+  bitmaps                  artist/raytracing/heliostat_ray_tracer.py:610-778
+  flux + 3 factors         artist/raytracing/heliostat_ray_tracer.py:220-508
+  per-target sums          artist/raytracing/heliostat_ray_tracer.py:563-608
+  autograd gradients       torch.autograd through all of the above
+"""
+from __future__ import annotations
+
+import os
+import pathlib
+import sys
+import tempfile
+import types
+
+OUT_DIR = pathlib.Path(__file__).resolve().parent
+REFERENCE = "/root/reference"
+
+
+def _import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Fmt:  # colorlog.ColoredFormatter stand-in (logging colours only)
+        def __init__(self, *a, **k):
+            pass
+
+    stub("colorlog", ColoredFormatter=_Fmt)
+    stub("h5py", File=object, Group=object)
+    stub("torchvision")
+    stub("torchvision.transforms")
+    stub("paint")
+    stub("paint.util")
+    pm = stub("paint.util.paint_mappings")
+    pm.__getattr__ = lambda n: n
+    sys.path.insert(0, REFERENCE)
+    os.chdir(tempfile.mkdtemp(prefix="artist_ref_cwd_"))
+    import artist.field  # noqa: F401  (must come first)
+
+
+_import_reference()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from artist.field import (  # noqa: E402
+    HeliostatField,
+    HeliostatGroupRigidBody,
+    SolarTower,
+    TowerTargetAreasCylindrical,
+    TowerTargetAreasPlanar,
+)
+from artist.geometry import transforms  # noqa: E402
+from artist.nurbs import NURBSSurfaces  # noqa: E402
+from artist.nurbs.utils import (  # noqa: E402
+    create_nurbs_evaluation_grid,
+    create_planar_nurbs_control_points,
+)
+from artist.raytracing import geometry  # noqa: E402
+from artist.raytracing.heliostat_ray_tracer import HeliostatRayTracer  # noqa: E402
+from artist.raytracing.sampling import RestrictedDistributedSampler  # noqa: E402
+from artist.scenario.scenario import Scenario  # noqa: E402
+from artist.scene import LightSourceArray, Rays, Sun  # noqa: E402
+
+CPU = torch.device("cpu")
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic scenario through the reference's public constructors.
+# --------------------------------------------------------------------------------------
+CANTING = [[0.8025, 0.0, 0.0, 0.0], [0.0, 0.6375, 0.0, 0.0]]
+FACET_TRANSLATIONS = [
+    [-0.8075, 0.6425, 0.0, 0.0],
+    [0.8075, 0.6425, 0.0, 0.0],
+    [-0.8075, -0.6425, 0.0, 0.0],
+    [0.8075, -0.6425, 0.0, 0.0],
+]
+
+
+def fan_positions(n, dtype):
+    """Deterministic fan: e in [-60,60] m, n in [30,150] m, u = 0."""
+    i = torch.arange(n, dtype=dtype)
+    if n == 1:
+        e = torch.zeros(1, dtype=dtype)
+        nn = torch.full((1,), 60.0, dtype=dtype)
+    else:
+        e = -60.0 + 120.0 * ((i * 0.61803398875) % 1.0)
+        nn = 30.0 + 120.0 * i / (n - 1)
+    return torch.stack([e, nn, torch.zeros_like(e), torch.ones_like(e)], dim=1)
+
+
+def build(case, dtype=torch.float32):
+    """Build reference objects for a case description dict; return everything needed."""
+    torch.set_default_dtype(dtype)
+    n_hel = case["n_heliostats"]
+    F = 4
+    nu, nv = case["n_cp"]
+    p, q = case["degrees"]
+    npts = case["n_eval"]
+    canting = torch.tensor(CANTING, dtype=dtype).unsqueeze(0).repeat(F, 1, 1)
+    translations = torch.tensor(FACET_TRANSLATIONS, dtype=dtype)
+
+    cp = create_planar_nurbs_control_points(
+        torch.tensor([nu, nv]), canting, device=CPU
+    )  # [F,nu,nv,3]
+    cp = cp.unsqueeze(0).repeat(n_hel, 1, 1, 1, 1).clone()
+    torch.manual_seed(7)
+    cp[..., 2] += case.get("z_noise", 1e-3) * torch.randn(cp[..., 2].shape, dtype=torch.float32).to(dtype)
+    if case.get("curvature", 0.0):
+        # mild paraboloid so that normals vary smoothly (focusing mirror)
+        cp[..., 2] += case["curvature"] * (cp[..., 0] ** 2 + cp[..., 1] ** 2)
+
+    uv = create_nurbs_evaluation_grid(torch.tensor([npts, npts]), device=CPU)  # [M,2]
+    uv_full = uv[None, None].expand(n_hel, F, -1, -1).contiguous()
+    canting_h = canting.unsqueeze(0).repeat(n_hel, 1, 1, 1)
+    transl_h = translations.unsqueeze(0).repeat(n_hel, 1, 1)
+    degrees = torch.tensor([p, q])
+
+    nurbs = NURBSSurfaces(degrees=degrees, control_points=cp, device=CPU)
+    pts, nrm = nurbs.calculate_surface_points_and_normals(
+        evaluation_points=uv_full, canting=canting_h, facet_translations=transl_h, device=CPU
+    )
+    P = F * uv.shape[0]
+    surface_points = pts.reshape(n_hel, P, 4).detach()
+    surface_normals = nrm.reshape(n_hel, P, 4).detach()
+
+    positions = fan_positions(n_hel, dtype)
+    if "positions" in case:
+        positions = torch.tensor(case["positions"], dtype=dtype)
+    group = HeliostatGroupRigidBody(
+        names=[f"h{i}" for i in range(n_hel)],
+        positions=positions,
+        surface_points=surface_points,
+        surface_normals=surface_normals,
+        canting=canting_h,
+        facet_translations=transl_h,
+        initial_orientations=torch.tensor([[0.0, -1.0, 0.0, 0.0]], dtype=dtype).repeat(n_hel, 1),
+        nurbs_control_points=cp,
+        nurbs_degrees=degrees,
+        kinematics_translation_deviation_parameters=torch.zeros(n_hel, 9, dtype=dtype),
+        kinematics_rotation_deviation_parameters=torch.zeros(n_hel, 4, dtype=dtype),
+        actuator_parameters_non_optimizable=torch.tensor(
+            [[1.0, 1.0], [0.0, 0.0], [-10.0, -10.0], [10.0, 10.0]], dtype=dtype
+        ).unsqueeze(0).repeat(n_hel, 1, 1),
+        device=CPU,
+    )
+    planar = TowerTargetAreasPlanar(
+        names=[f"t{i}" for i in range(len(case["target_centers"]))],
+        centers=torch.tensor(case["target_centers"], dtype=dtype),
+        normals=torch.tensor(case["target_normals"], dtype=dtype),
+        dimensions=torch.tensor(case["target_dims"], dtype=dtype),
+    )
+    cyl = TowerTargetAreasCylindrical(
+        names=[],
+        centers=torch.zeros(0, 4, dtype=dtype),
+        normals=torch.zeros(0, 4, dtype=dtype),
+        axes=torch.zeros(0, 4, dtype=dtype),
+        radii=torch.zeros(0, dtype=dtype),
+        heights=torch.zeros(0, dtype=dtype),
+        opening_angles=torch.zeros(0, dtype=dtype),
+    )
+    tower = SolarTower([planar, cyl], device=CPU)
+    sun = Sun(
+        number_of_rays=case["n_rays"],
+        distribution_parameters=dict(
+            distribution_type="normal", mean=0.0, covariance=case.get("covariance", 4.3681e-06)
+        ),
+        device=CPU,
+    )
+    scenario = Scenario(
+        power_plant_position=torch.tensor([50.91, 6.39, 87.0], dtype=dtype),
+        solar_tower=tower,
+        light_sources=LightSourceArray([sun]),
+        heliostat_field=HeliostatField([group], device=CPU),
+    )
+    return dict(
+        scenario=scenario, group=group, nurbs_inputs=(degrees, cp, uv_full, canting_h, transl_h),
+        planar=planar, sun=sun, P=P,
+    )
+
+
+def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, distortions_f32=None):
+    """Run the reference on one case; return dict of arrays."""
+    b = build(case, dtype)
+    scenario, group = b["scenario"], b["group"]
+    degrees, cp, uv_full, canting_h, transl_h = b["nurbs_inputs"]
+    out = {}
+    mask = torch.tensor(case.get("active_mask", [1] * case["n_heliostats"]), dtype=torch.int32)
+    H = int(mask.sum())
+    target_idx = torch.tensor(case.get("target_idx", [0] * H), dtype=torch.int64)
+    incident = torch.tensor(case.get("incident", [[0.0, 1.0, 0.0, 0.0]] * H), dtype=dtype)
+    incident = torch.nn.functional.normalize(incident, dim=1)
+    res = torch.tensor(case.get("resolution", [256, 256]))
+
+    group.activate_heliostats(active_heliostats_mask=mask, device=CPU)
+    # --- K1 in graph (surface_reconstructor.py:510-543 pattern) ---
+    cp_active = group.active_nurbs_control_points.detach().clone().requires_grad_(with_grads)
+    nurbs = NURBSSurfaces(degrees=degrees, control_points=cp_active, device=CPU)
+    uv_a = uv_full.repeat_interleave(mask, dim=0)
+    cant_a = group.active_canting
+    tr_a = group.active_facet_translations
+    pts, nrm = nurbs.calculate_surface_points_and_normals(
+        evaluation_points=uv_a, canting=cant_a, facet_translations=tr_a, device=CPU
+    )
+    out.update(
+        degrees=npy(degrees), control_points=npy(cp_active), eval_points=npy(uv_a),
+        canting=npy(cant_a), facet_translations=npy(tr_a),
+        nurbs_points=npy(pts), nurbs_normals=npy(nrm),
+        knots_u=npy(nurbs.knot_vectors_u[0, 0]), knots_v=npy(nurbs.knot_vectors_v[0, 0]),
+    )
+    P = b["P"]
+    sp = pts.reshape(H, P, 4)
+    sn = nrm.reshape(H, P, 4)
+    if with_grads:
+        sp.retain_grad()
+        sn.retain_grad()
+
+    # --- K2 alignment: same ops as heliostat_group_rigid_body.py:210-222, kept explicit so that
+    #     the orientation matrices can be captured and differentiated ---
+    aim = scenario.solar_tower.get_centers_of_target_areas(target_area_indices=target_idx, device=CPU)
+    if "aim_offset" in case:
+        aim = aim + torch.tensor(case["aim_offset"], dtype=dtype)
+    with torch.no_grad():
+        orientation = group.kinematics.incident_ray_directions_to_orientations(
+            incident_ray_directions=incident, aim_points=aim, device=CPU
+        )
+    orientation = orientation.detach().clone().requires_grad_(with_grads)
+    apts = sp @ orientation.transpose(1, 2)
+    anrm = sn @ orientation.transpose(1, 2)
+    if with_grads:
+        apts.retain_grad()
+        anrm.retain_grad()
+    group.active_surface_points = apts
+    group.active_surface_normals = anrm
+    out.update(orientation=npy(orientation), aim_points=npy(aim), incident=npy(incident),
+               aligned_points=npy(apts), aligned_normals=npy(anrm),
+               active_mask=npy(mask), target_idx=npy(target_idx))
+
+    rt = HeliostatRayTracer(
+        scenario=scenario, heliostat_group=group, blocking_active=False,
+        batch_size=case.get("batch_size", 100), random_seed=case.get("seed", 7),
+        bitmap_resolution=res, dni=case.get("dni", None),
+    )
+    du32, de32 = rt.distortions_dataset.distortions_u, rt.distortions_dataset.distortions_e
+    if distortions_f32 is not None:
+        du32, de32 = distortions_f32
+    if dtype != torch.float32:
+        rt.distortions_dataset.distortions_u = du32.to(dtype)
+        rt.distortions_dataset.distortions_e = de32.to(dtype)
+    du, de = rt.distortions_dataset.distortions_u, rt.distortions_dataset.distortions_e
+    ext = case.get("extinction", 0.0)
+    refl = case.get("reflectivity", 0.935)
+    out.update(
+        ray_magnitude=np.float64(float(rt.ray_magnitude)), extinction=np.float64(ext), reflectivity=np.float64(refl),
+        resolution=npy(res), target_centers=npy(b["planar"].centers), target_normals=npy(b["planar"].normals),
+        target_dims=npy(b["planar"].dimensions), n_rays=np.int64(case["n_rays"]), seed=np.int64(case.get("seed", 7)),
+        covariance=np.float64(case.get("covariance", 4.3681e-06)),
+    )
+    if store_rays:
+        out.update(distortions_u=npy(du), distortions_e=npy(de))
+
+    # --- stage-by-stage (same calls trace_rays makes, heliostat_ray_tracer.py:285-494) ---
+    if store_rays:
+        with torch.no_grad():
+            refl_dirs = geometry.reflect(incident.unsqueeze(1), anrm)
+            rays = rt.scatter_rays(distortion_u=du.contiguous(), distortion_e=de.contiguous(),
+                                   original_ray_direction=refl_dirs, device=CPU)
+            e_px, u_px, t, inten = geometry.line_plane_intersections(
+                rays=rays, points_at_ray_origins=apts, target_areas=b["planar"],
+                target_area_indices=target_idx, bitmap_resolution=res, device=CPU)
+            inten_abs = inten * (1 - 0.0) * (1 - ext) * refl
+            bitmaps = rt.bilinear_splatting(e_px, u_px, inten_abs, device=CPU)
+        out.update(reflected=npy(refl_dirs), scattered=npy(rays.ray_directions), e_px=npy(e_px), u_px=npy(u_px),
+                   distances=npy(t), intensities=npy(inten), stage_bitmaps=npy(bitmaps))
+
+    flux, intercept, on_target, blocking = rt.trace_rays(
+        incident_ray_directions=incident, active_heliostats_mask=mask, target_area_indices=target_idx,
+        ray_extinction_factor=ext, mirror_reflectivity=refl, device=CPU,
+    )
+    per_target = rt.get_bitmaps_per_target(flux, target_idx, device=CPU)
+    out.update(flux=npy(flux), intercept=npy(intercept), on_target=npy(on_target), blocking=npy(blocking),
+               per_target=npy(per_target), sampler_indices=npy(rt.get_sampler_indices()))
+
+    if with_grads:
+        g = torch.Generator().manual_seed(1234)
+        weights = torch.rand(flux.shape, generator=g, dtype=torch.float32).to(dtype)
+        loss = (flux * weights).sum()
+        loss.backward()
+        out.update(loss_weights=npy(weights), loss=npy(loss),
+                   grad_aligned_points=npy(apts.grad), grad_aligned_normals=npy(anrm.grad),
+                   grad_nurbs_points=npy(sp.grad), grad_nurbs_normals=npy(sn.grad),
+                   grad_orientation=npy(orientation.grad), grad_control_points=npy(cp_active.grad))
+    torch.set_default_dtype(torch.float32)
+    return out, (du32, de32)
+
+
+def save(name, arrays):
+    path = OUT_DIR / f"{name}.npz"
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path.name}: {path.stat().st_size/1024:.1f} KiB, keys={len(arrays)}")
+
+
+# --------------------------------------------------------------------------------------
+# Cases
+# --------------------------------------------------------------------------------------
+RECEIVER = dict(target_centers=[[0.0, 0.0, 55.0, 1.0]], target_normals=[[0.0, 1.0, 0.0, 0.0]], target_dims=[[8.0, 8.0]])
+
+CASES = {
+    # H=4 active (each heliostat twice - the reference's sampler needs a uniform replica count,
+    # sampling.py:133-135), degree 3, 10x10 cps, 64x64 bitmap; every stage stored.
+    "small_deg3": dict(n_heliostats=2, active_mask=[2, 2], n_cp=(10, 10), degrees=(3, 3), n_eval=8, n_rays=4,
+                       resolution=[64, 64], **RECEIVER),
+    # degree 2, 7x7 cps, two tilted target planes, non-square bitmap, non-default scalars, dni.
+    "small_deg2_tilted": dict(
+        n_heliostats=2, n_cp=(7, 7), degrees=(2, 2), n_eval=6, n_rays=5, resolution=[96, 48],
+        target_centers=[[0.0, 0.0, 55.0, 1.0], [3.0, -2.0, 40.0, 1.0]],
+        target_normals=[[0.0, 1.0, 0.0, 0.0], [0.2182, 0.7071, 0.7071, 0.0]],
+        target_dims=[[8.0, 8.0], [6.0, 5.0]], target_idx=[1, 0],
+        incident=[[0.1, 0.9, -0.3, 0.0], [-0.2, 0.8, -0.5, 0.0]],
+        extinction=0.1, reflectivity=0.9, dni=800.0, curvature=2e-3),
+    # tiny target: most rays fall off the 1 m x 1 m receiver; one heliostat aims 30 m off -> all rays miss.
+    "small_offtarget": dict(n_heliostats=2, n_cp=(6, 6), degrees=(3, 3), n_eval=6, n_rays=3, resolution=[32, 32],
+                            target_centers=[[0.0, 0.0, 55.0, 1.0], [30.0, 0.0, 55.0, 1.0]],
+                            target_normals=[[0.0, 1.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]],
+                            target_dims=[[1.0, 1.0], [1.0, 1.0]], target_idx=[0, 0],
+                            aim_offset=[[0.0, 0.0, 0.0, 0.0], [30.0, 0.0, 0.0, 0.0]]),
+    # mid-size: 2 heliostats, 20x20 points per facet, 8 rays, full 256x256 bitmap.
+    "mid_256": dict(n_heliostats=2, n_cp=(6, 6), degrees=(3, 3), n_eval=20, n_rays=8, resolution=[256, 256],
+                    curvature=1e-3, **RECEIVER),
+}
+
+# Config 1 of BASELINE.json: 1 heliostat, 4 planar facets, point sun, 10k rays.
+CONFIG1 = dict(n_heliostats=1, n_cp=(10, 10), degrees=(3, 3), n_eval=50, n_rays=1, z_noise=0.0, covariance=1e-12,
+               resolution=[256, 256], **RECEIVER)
+# Config 2: 1 NURBS heliostat, Gaussian sun, 1M rays.
+CONFIG2 = dict(n_heliostats=1, n_cp=(10, 10), degrees=(3, 3), n_eval=50, n_rays=100, resolution=[256, 256], **RECEIVER)
+
+
+def summarize_large(arrs, keep):
+    return {k: v for k, v in arrs.items() if k in keep}
+
+
+def known_answers():
+    """Inputs/expected values of the reference's own inline known-answer tests, read from the
+    pytest parametrisation of the test modules (data only), plus the values the reference
+    computes for them here."""
+    sys.path.insert(0, REFERENCE)
+    import importlib
+    out = {}
+    tg = importlib.import_module("tests.raytracing.test_geometry")
+    # reflect: tests/raytracing/test_geometry.py:13-51
+    for i, (inc, nrm, exp) in enumerate(tg.test_reflect_function.pytestmark[0].args[1]):
+        out[f"reflect{i}_incident"] = npy(inc)
+        out[f"reflect{i}_normals"] = npy(nrm)
+        out[f"reflect{i}_expected"] = npy(exp)
+        out[f"reflect{i}_reference"] = npy(geometry.reflect(inc, nrm))
+    # line-plane: tests/raytracing/test_geometry.py:195-259 (targets from fixtures :110-166)
+    targets = {
+        "target_area_1_planar": ([[0.0, 0.0, 0.0, 1.0]], [[0.0, 1.0, 0.0, 0.0]], [[2.0, 2.0]]),
+        "target_area_2_planar": ([[0.0, 0.0, 0.0, 1.0]], [[0.2182, 0.7071, 0.7071, 0.0]], [[3.0, 3.0]]),
+    }
+    for i, (rays, tname, origins, ee, eu, ed, ei) in enumerate(tg.test_line_plane_intersection.pytestmark[0].args[1]):
+        c, n, d = (torch.tensor(x) for x in targets[tname])
+        ta = TowerTargetAreasPlanar(names=["p"], centers=c, normals=n, dimensions=d)
+        r = Rays(ray_directions=rays[0], ray_magnitudes=rays[1])
+        e_px, u_px, t, inten = geometry.line_plane_intersections(r, origins, ta, torch.tensor([0]), device=CPU)
+        out.update({
+            f"plane{i}_dirs": npy(rays[0]), f"plane{i}_mags": npy(rays[1]), f"plane{i}_origins": npy(origins),
+            f"plane{i}_center": npy(c), f"plane{i}_normal": npy(n), f"plane{i}_dims": npy(d),
+            f"plane{i}_expected_e": npy(ee), f"plane{i}_expected_u": npy(eu), f"plane{i}_expected_t": npy(ed),
+            f"plane{i}_expected_i": npy(ei), f"plane{i}_reference_e": npy(e_px), f"plane{i}_reference_u": npy(u_px),
+            f"plane{i}_reference_t": npy(t), f"plane{i}_reference_i": npy(inten)})
+    # rotate_distortions: tests/geometry/test_transforms.py (test_distortion_rotations)
+    tt = importlib.import_module("tests.geometry.test_transforms")
+    k = 0
+    for (e, u, rays, exp) in tt.test_distortion_rotations.pytestmark[0].args[1]:
+        if exp is None:
+            continue
+        got = (transforms.rotate_distortions(e=e, u=u, device=CPU) @ rays.unsqueeze(-1)).squeeze(-1)
+        out.update({f"rot{k}_e": npy(e), f"rot{k}_u": npy(u), f"rot{k}_rays": npy(rays),
+                    f"rot{k}_expected": npy(exp), f"rot{k}_reference": npy(got)})
+        k += 1
+    out["rot_count"] = np.int64(k)
+    # sampler partition table: tests/raytracing/test_sampling.py:8-15
+    ts = importlib.import_module("tests.raytracing.test_sampling")
+    rows = []
+    for (ns, nh, ws, per_rank) in ts.test_distributed_sampler.pytestmark[0].args[1]:
+        for rank in range(ws):
+            got = list(RestrictedDistributedSampler(ns, nh, ws, rank))
+            assert got == per_rank[rank]
+            rows.append([ns, nh, ws, rank] + got + [-1] * (16 - len(got)))
+    out["sampler_table"] = np.asarray(rows, dtype=np.int64)
+    # NURBS forward known answer: tests/nurbs/test_surfaces.py:202-300
+    canting = torch.tensor([[[[8.0249e-01, -0.0, -4.7736e-03, 0.0], [1.7949e-05, 6.3749e-01, 3.0172e-03, 0.0]]]])
+    transl = torch.tensor([[[1.0, 0.0, 0.0, 0.0]]])
+    uv = torch.cartesian_prod(torch.linspace(1e-5, 1 - 1e-5, 2), torch.linspace(1e-5, 1 - 1e-5, 2))[None, None]
+    cp = create_planar_nurbs_control_points(torch.tensor([4, 4]), canting[0], device=CPU)[None]
+    nurbs = NURBSSurfaces(degrees=torch.tensor([2, 2]), control_points=cp, device=CPU)
+    pts, nrm = nurbs(uv, canting, transl, CPU)
+    exp_p = torch.tensor([[[[1.975133419037e-01, -6.374730467796e-01, 1.756353536621e-03, 1.0],
+                            [1.975492835045e-01, 6.374730467796e-01, 7.790592499077e-03, 1.0],
+                            [1.802450656891e00, -6.374730467796e-01, -7.790592499077e-03, 1.0],
+                            [1.802486538887e00, 6.374729871750e-01, -1.756352838129e-03, 1.0]]]])
+    exp_n = torch.tensor([[[[0.005948313046, -0.004732967820, 0.999971091747, 0.0]] * 4]])
+    torch.testing.assert_close(pts, exp_p)
+    torch.testing.assert_close(nrm, exp_n)
+    out.update(nurbsfwd_canting=npy(canting), nurbsfwd_transl=npy(transl), nurbsfwd_uv=npy(uv), nurbsfwd_cp=npy(cp),
+               nurbsfwd_degrees=np.asarray([2, 2]), nurbsfwd_expected_points=npy(exp_p),
+               nurbsfwd_expected_normals=npy(exp_n), nurbsfwd_reference_points=npy(pts),
+               nurbsfwd_reference_normals=npy(nrm))
+    # span search: tests/nurbs/test_surfaces.py:150-199
+    from artist.geometry import coordinates
+    ev = coordinates.normalize_points(create_nurbs_evaluation_grid(torch.tensor([4, 5]), device=CPU))
+    x, y = torch.meshgrid(torch.linspace(1e-2, 1 - 1e-2, 6), torch.linspace(1e-2, 1 - 1e-2, 6), indexing="ij")
+    knots = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.1, 0.7, 1.0, 1.0, 1.0, 1.0])
+    ns = NURBSSurfaces(degrees=torch.tensor([3, 3]), control_points=torch.stack([x, y], -1)[None, None], device=CPU)
+    span = ns.find_spans(direction=0, evaluation_points=ev[None, None], knot_vectors=knots[None, None], device=CPU)
+    exp_span = [3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5]
+    assert span.flatten().tolist() == exp_span
+    ns2 = NURBSSurfaces(degrees=torch.tensor([3, 3]), control_points=torch.stack([x, y], -1)[None, None],
+                        uniform=False, device=CPU)
+    span_nu = ns2.find_spans(direction=0, evaluation_points=ev[None, None], knot_vectors=knots[None, None], device=CPU)
+    out.update(span_eval=npy(ev), span_knots=npy(knots), span_expected=np.asarray(exp_span),
+               span_nonuniform_reference=npy(span_nu.flatten()))
+    # sun distortions layout: tests/scene/test_sun.py:10-57 semantics (seeded MVN sample, permute)
+    sun = Sun(number_of_rays=3, device=CPU)
+    du, de = sun.get_distortions(number_of_points=5, number_of_active_heliostats=2, random_seed=7)
+    out.update(sun_u=npy(du), sun_e=npy(de), sun_strides=np.asarray(du.stride()))
+    return out
+
+
+def main():
+    save("known_answers", known_answers())
+    for name, case in CASES.items():
+        arrs32, dist = run_case(name, case, dtype=torch.float32)
+        save(name, arrs32)
+        arrs64, _ = run_case(name, case, dtype=torch.float64, distortions_f32=dist)
+        drop = {"reflected", "scattered", "distances", "stage_bitmaps", "aligned_points", "aligned_normals",
+                "grad_nurbs_points", "grad_nurbs_normals", "knots_u", "knots_v"}
+        save(name + "_f64", {k: v for k, v in arrs64.items() if k not in drop})
+    # config 1 / config 2: inputs regenerate from the recipe (seeded torch CPU RNG); store outputs only.
+    keep = {"flux", "intercept", "on_target", "blocking", "per_target", "control_points", "orientation",
+            "aligned_points", "aligned_normals", "incident", "target_idx", "target_centers", "target_normals",
+            "target_dims", "resolution", "ray_magnitude", "extinction", "reflectivity", "n_rays", "seed", "covariance",
+            "degrees", "eval_points_grid", "canting", "facet_translations", "nurbs_points", "nurbs_normals"}
+    for name, case in (("config1", CONFIG1), ("config2", CONFIG2)):
+        arrs32, dist = run_case(name, case, with_grads=False, store_rays=False, dtype=torch.float32)
+        a = summarize_large(arrs32, keep)
+        a["eval_points_grid"] = arrs32["eval_points"][0, 0]
+        arrs64, _ = run_case(name, case, with_grads=False, store_rays=False, dtype=torch.float64, distortions_f32=dist)
+        a["flux_f64"] = arrs64["flux"]
+        # aligned points are 160 KB each - keep (they are the op's inputs); drop the per-facet duplicates
+        a.pop("nurbs_points"), a.pop("nurbs_normals")
+        save(name, a)
+
+
+if __name__ == "__main__":
+    main()
