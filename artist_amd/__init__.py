@@ -1,0 +1,19 @@
+"""artist_amd - MI355X-native (gfx950) implementation of ARTIST's heliostat ray-tracing hot path.
+
+Scope: NURBS surface points + normals, ray-mirror reflection, sun-shape
+scattering, receiver-plane intersection and the bilinear scatter-add flux bitmap, forward and
+backward, behind ARTIST's own call surface:
+
+    artist_amd.HeliostatRayTracer   <-> artist.raytracing.heliostat_ray_tracer.HeliostatRayTracer
+    artist_amd.NURBSSurfaces        <-> artist.nurbs.NURBSSurfaces
+
+All arithmetic runs in hand-written HIP kernels (``artist_amd/csrc``) reached through the C ABI in
+``include/artist_hip.h``; there is no CPU fallback.
+"""
+from ._lib import ArtistHipError, build, lib  # noqa: F401
+from .nurbs import NURBSSurfaces, create_nurbs_evaluation_grid, create_planar_nurbs_control_points  # noqa: F401
+from .ops import nurbs_surface_points_and_normals, per_target_sum, trace_rays  # noqa: F401
+from .raytracing import HeliostatRayTracer  # noqa: F401
+from .sampling import DistortionsDataset, RestrictedDistributedSampler  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,218 @@
+"""``torch.autograd.Function`` wrappers around the C ABI of ``libartist_hip.so``.
+
+PyTorch is plumbing here (device memory, streams, autograd tape); every number is produced by
+the hand-written gfx950 kernels in ``artist_amd/csrc``.  No CPU path exists: non-CUDA inputs
+raise.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+
+__all__ = ["trace_rays", "nurbs_surface_points_and_normals", "per_target_sum", "TraceRays", "NurbsEval"]
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(*tensors: torch.Tensor) -> torch.device:
+    dev = tensors[0].device
+    if dev.type != "cuda":
+        raise _lib.ArtistHipError(
+            f"artist_amd ops run on the GPU only (got a tensor on {dev}); there is no CPU fallback")
+    for t in tensors:
+        if t is not None and t.device != dev:
+            raise ValueError(f"all tensors must be on {dev}, found one on {t.device}")
+    return dev
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """float32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _dist_views(dist_u: torch.Tensor, dist_e: torch.Tensor, shape):
+    """Validate the two [H,R,P] distortion views and return (u, e, element strides).
+
+    ``Sun.get_distortions`` (artist/scene/sun.py:227-234) returns stride-(2RP,2P,2) views of one
+    interleaved buffer; they are passed through as-is (the kernel does one 8-byte load per ray)."""
+    if dist_u.shape != dist_e.shape:
+        # same condition / message as transforms.rotate_distortions (artist/geometry/transforms.py:47-50)
+        raise ValueError("The two tensors containing angles for the east and up rotation must have the same shape.")
+    if tuple(dist_u.shape) != tuple(shape):
+        raise ValueError(f"distortions must have shape {tuple(shape)}, got {tuple(dist_u.shape)}")
+    if dist_u.dtype != torch.float32 or dist_e.dtype != torch.float32:
+        dist_u, dist_e = dist_u.float(), dist_e.float()
+    if dist_u.stride() != dist_e.stride():
+        dist_u, dist_e = dist_u.contiguous(), dist_e.contiguous()
+    return dist_u, dist_e, dist_u.stride()
+
+
+class TraceRays(torch.autograd.Function):
+    """reflect -> scatter -> plane intersection -> bilinear splat (+ factors), fused.
+
+    Replaces the body of ``HeliostatRayTracer.trace_rays``
+    (artist/raytracing/heliostat_ray_tracer.py:285-506) for ``blocking_active=False`` and planar
+    target areas.  Differentiable w.r.t. ``origins`` and ``normals`` exactly like the eager chain
+    (indices and masks are constants).
+    """
+
+    @staticmethod
+    def forward(ctx, origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
+                ray_magnitude, extinction, reflectivity, width, height, per_target):
+        dev = _require_cuda(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims)
+        origins, normals, incident = _f32c(origins), _f32c(normals), _f32c(incident)
+        H, P = origins.shape[0], origins.shape[1]
+        if origins.shape != (H, P, 4) or normals.shape != (H, P, 4) or incident.shape != (H, 4):
+            raise ValueError("origins/normals must be [H,P,4] and incident [H,4]")
+        R = dist_u.shape[1] if dist_u.dim() == 3 else -1
+        dist_u, dist_e, (sh, sr, sp) = _dist_views(dist_u, dist_e, (H, R, P))
+        target_idx = target_idx.to(torch.int32).contiguous()
+        centers, plane_normals, dims = _f32c(centers), _f32c(plane_normals), _f32c(dims)
+        T = centers.shape[0]
+        n_maps = T if per_target else H
+        flux = torch.empty((n_maps, height, width), dtype=torch.float32, device=dev)
+        factors = torch.empty((3, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_trace_fwd(
+                origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
+                sh, sr, sp, target_idx.data_ptr(), centers.data_ptr(), plane_normals.data_ptr(), dims.data_ptr(),
+                float(ray_magnitude), float(extinction), float(reflectivity), H, R, P, T, width, height,
+                1 if per_target else 0, flux.data_ptr(), factors.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_trace_fwd")
+        ctx.save_for_backward(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims)
+        ctx.scalars = (float(ray_magnitude), float(extinction), float(reflectivity), width, height, bool(per_target))
+        ctx.mark_non_differentiable(factors)
+        return flux, factors
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_flux, _grad_factors):
+        origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims = ctx.saved_tensors
+        mag, ext, refl, width, height, per_target = ctx.scalars
+        dev = origins.device
+        H, P = origins.shape[0], origins.shape[1]
+        R = dist_u.shape[1]
+        sh, sr, sp = dist_u.stride()
+        grad_flux = _f32c(grad_flux)
+        g_o = torch.empty_like(origins)
+        g_n = torch.empty_like(normals)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_trace_bwd(
+                origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
+                sh, sr, sp, target_idx.data_ptr(), centers.data_ptr(), plane_normals.data_ptr(), dims.data_ptr(),
+                mag, ext, refl, H, R, P, centers.shape[0], width, height, 1 if per_target else 0,
+                grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_trace_bwd")
+        return (g_o, g_n) + (None,) * 13
+
+
+def trace_rays(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
+               ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, resolution=(256, 256), per_target=False):
+    """Functional form.  Returns ``(flux, factors)`` with ``flux`` ``[H,Hh,W]`` (or ``[T,Hh,W]`` when
+    ``per_target``) and ``factors`` ``[3,H]`` = intercept, on-target, blocking fractions."""
+    return TraceRays.apply(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
+                           ray_magnitude, extinction, reflectivity, int(resolution[0]), int(resolution[1]),
+                           bool(per_target))
+
+
+def per_target_sum(bitmaps: torch.Tensor, target_idx: torch.Tensor, n_targets: int) -> torch.Tensor:
+    """``get_bitmaps_per_target`` (heliostat_ray_tracer.py:563-608) as one kernel; differentiable
+    through a gather in torch (the backward of a masked sum is an index_select)."""
+    _require_cuda(bitmaps, target_idx)
+    return _PerTargetSum.apply(bitmaps, target_idx.to(torch.int32).contiguous(), int(n_targets))
+
+
+class _PerTargetSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bitmaps, target_idx, n_targets):
+        dev = bitmaps.device
+        b = _f32c(bitmaps)
+        H = b.shape[0]
+        npix = int(math.prod(b.shape[1:]))
+        out = torch.empty((n_targets,) + tuple(b.shape[1:]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_per_target_sum(b.data_ptr(), target_idx.data_ptr(), H, n_targets, npix,
+                                               out.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_per_target_sum")
+        ctx.save_for_backward(target_idx)
+        ctx.n_targets = n_targets
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (target_idx,) = ctx.saved_tensors
+        idx = target_idx.long()
+        ok = (idx >= 0) & (idx < ctx.n_targets)
+        g = grad_out.index_select(0, idx.clamp(0, ctx.n_targets - 1))
+        return g * ok.view(-1, *([1] * (g.dim() - 1))), None, None
+
+
+class NurbsEval(torch.autograd.Function):
+    """``NURBSSurfaces.calculate_surface_points_and_normals`` (artist/nurbs/surfaces.py:475-689),
+    differentiable w.r.t. the control points."""
+
+    @staticmethod
+    def forward(ctx, control_points, eval_points, knots_u, knots_v, canting, translations, p, q, uniform,
+                n_unique_u, n_unique_v):
+        dev = _require_cuda(control_points, eval_points, knots_u, knots_v)
+        cp = _f32c(control_points)
+        H, F, nu, nv, three = cp.shape
+        if three != 3:
+            raise ValueError("control_points must be [H,F,nu,nv,3]")
+        uv = eval_points if eval_points.dtype == torch.float32 else eval_points.float()
+        if uv.dim() != 4 or uv.shape[0] != H or uv.shape[1] != F or uv.shape[3] != 2:
+            raise ValueError("evaluation_points must be [H,F,M,2]")
+        M = uv.shape[2]
+        if uv.stride(3) != 1 or uv.stride(2) != 2 or (uv.data_ptr() % 8) != 0:
+            uv = uv.contiguous()   # expanded (stride-0) heliostat/facet dims are passed through
+        ku = _f32c(knots_u.expand(H, F, nu + p + 1))
+        kv = _f32c(knots_v.expand(H, F, nv + q + 1))
+        cant = None if canting is None else _f32c(canting)
+        tr = None if canting is None else _f32c(translations.reshape(H, F, 4))
+        points = torch.empty((H, F, M, 4), dtype=torch.float32, device=dev)
+        normals = torch.empty((H, F, M, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_nurbs_fwd(
+                cp.data_ptr(), uv.data_ptr(), uv.stride(0), uv.stride(1), ku.data_ptr(), kv.data_ptr(),
+                None if cant is None else cant.data_ptr(), None if tr is None else tr.data_ptr(),
+                p, q, 1 if uniform else 0, n_unique_u, n_unique_v, H, F, M, nu, nv,
+                points.data_ptr(), normals.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_nurbs_fwd")
+        ctx.save_for_backward(cp, uv, ku, kv, cant if cant is not None else cp.new_empty(0))
+        ctx.meta = (p, q, bool(uniform), n_unique_u, n_unique_v, cant is not None)
+        return points, normals
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_points, g_normals):
+        cp, uv, ku, kv, cant = ctx.saved_tensors
+        p, q, uniform, nuq_u, nuq_v, has_cant = ctx.meta
+        dev = cp.device
+        H, F, nu, nv, _ = cp.shape
+        M = uv.shape[2]
+        g_points, g_normals = _f32c(g_points), _f32c(g_normals)
+        g_cp = torch.empty_like(cp)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_nurbs_bwd(
+                cp.data_ptr(), uv.data_ptr(), uv.stride(0), uv.stride(1), ku.data_ptr(), kv.data_ptr(),
+                cant.data_ptr() if has_cant else None, p, q, 1 if uniform else 0, nuq_u, nuq_v, H, F, M, nu, nv,
+                g_points.data_ptr(), g_normals.data_ptr(), g_cp.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_nurbs_bwd")
+        return (g_cp,) + (None,) * 10
+
+
+def nurbs_surface_points_and_normals(control_points, eval_points, knots_u, knots_v, degrees, canting=None,
+                                     translations=None, uniform=True, n_unique=None):
+    p, q = int(degrees[0]), int(degrees[1])
+    nu, nv = control_points.shape[2], control_points.shape[3]
+    if n_unique is None:
+        n_unique = (nu - p + 1, nv - q + 1)
+    return NurbsEval.apply(control_points, eval_points, knots_u, knots_v, canting, translations, p, q,
+                           bool(uniform), int(n_unique[0]), int(n_unique[1]))

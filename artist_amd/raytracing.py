@@ -1,0 +1,178 @@
+"""Drop-in for ``artist.raytracing.heliostat_ray_tracer.HeliostatRayTracer`` on MI355X.
+
+Same constructor arguments, method names, return values and error behaviour as
+``artist/raytracing/heliostat_ray_tracer.py:19-778``; the per-batch Python loop of eager ATen
+ops inside ``trace_rays`` (:316-506) is ONE fused HIP kernel launch (``art_trace_fwd``), and its
+autograd is ``art_trace_bwd``.  ``scenario`` / ``heliostat_group`` are duck-typed: ARTIST's own
+``Scenario`` / ``HeliostatGroup`` objects work unchanged, and so do the light stand-ins in
+``artist_amd.scene`` used by the tests and the benchmark.
+
+Multi-rank contract (the reference's is broken for world_size > 1): a rank
+returns rows for the heliostat samples it OWNS only, in ``get_sampler_indices()`` order, so that
+``get_bitmaps_per_target(flux_local, target_area_indices[sampler_indices])`` is well defined and
+the sum over ranks equals the single-rank result.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .sampling import DistortionsDataset, RestrictedDistributedSampler
+
+_DEFAULT_RESOLUTION = torch.tensor([256, 256])   # artist/util/indices.py:307
+
+
+def reflect(incident_ray_directions: torch.Tensor, reflection_surface_normals: torch.Tensor) -> torch.Tensor:
+    """``i - 2 (i.n) n`` (artist/raytracing/geometry.py:11-41); only used to publish
+    ``heliostat_group.preferred_reflection_directions`` - the kernel reflects in registers."""
+    return (incident_ray_directions
+            - 2 * torch.sum(incident_ray_directions * reflection_surface_normals, dim=-1, keepdim=True)
+            * reflection_surface_normals)
+
+
+class HeliostatRayTracer:
+    """See ``artist/raytracing/heliostat_ray_tracer.py:19-69`` for the attribute documentation."""
+
+    #: publish ``heliostat_group.preferred_reflection_directions`` like the reference does (:285-290)
+    publish_reflection_directions = True
+
+    def __init__(self, scenario, heliostat_group, blocking_active: bool = True, world_size: int = 1, rank: int = 0,
+                 batch_size: int = 100, random_seed: int = 7, bitmap_resolution: torch.Tensor = _DEFAULT_RESOLUTION,
+                 dni: float | None = None) -> None:
+        self.scenario = scenario
+        self.heliostat_group = heliostat_group
+        self.blocking_active = blocking_active
+        if blocking_active:
+            raise NotImplementedError(
+                "blocking_active=True (artist/raytracing/blocking.py) is not implemented in the MI355X path yet; "
+                "construct the ray tracer with blocking_active=False")
+        self.world_size = world_size
+        self.rank = rank
+        self.batch_size = batch_size   # accepted for API parity; the fused kernel has no per-ray intermediates
+
+        self.light_source = scenario.light_sources.light_source_list[0]
+        self.distortions_dataset = DistortionsDataset(
+            light_source=self.light_source,
+            number_of_points_per_heliostat=self.heliostat_group.active_surface_points.shape[1],
+            number_of_active_heliostats=self.heliostat_group.number_of_active_heliostats,
+            random_seed=random_seed,
+        )
+        self.distortions_sampler = RestrictedDistributedSampler(
+            number_of_samples=len(self.distortions_dataset),
+            number_of_active_heliostats=int((self.heliostat_group.active_heliostats_mask > 0).sum()),
+            world_size=self.world_size,
+            rank=self.rank,
+        )
+        self.bitmap_resolution = bitmap_resolution
+        self._resolution_host = (int(bitmap_resolution[0]), int(bitmap_resolution[1]))
+
+        if dni is not None:
+            # heliostat_ray_tracer.py:185-201
+            canting_norm = (torch.norm(self.heliostat_group.canting[0], dim=1)[0])[:2]
+            dimensions = (canting_norm * 4) + 0.02
+            heliostat_surface_area = dimensions[0] * dimensions[1]
+            power_single_heliostat = dni * heliostat_surface_area
+            rays_per_heliostat = self.heliostat_group.surface_points.shape[1] * self.light_source.number_of_rays
+            self.ray_magnitude = power_single_heliostat / rays_per_heliostat
+        else:
+            self.ray_magnitude = 1.0
+        self._local_cache = None
+
+    # ------------------------------------------------------------------------------------------
+    def get_sampler_indices(self) -> torch.Tensor:
+        """Indices of the distortions dataset assigned to this rank (:205-218)."""
+        return torch.tensor(self.distortions_sampler.rank_indices, device=self.distortions_dataset.distortions_u.device)
+
+    def _local_rows(self, device):
+        """(index tensor or None, dist_u, dist_e) for the rows this rank owns."""
+        if self._local_cache is not None and self._local_cache[0] == device:
+            return self._local_cache[1:]
+        du, de = self.distortions_dataset.distortions_u, self.distortions_dataset.distortions_e
+        idx_list = self.distortions_sampler.rank_indices
+        if len(idx_list) == du.shape[0] and idx_list == list(range(du.shape[0])):
+            idx = None
+            if du.device != device:
+                both = torch.stack((du, de), dim=-1).to(device)      # keep the interleaved layout
+                du, de = both[..., 0], both[..., 1]
+        else:
+            idx = torch.tensor(idx_list, dtype=torch.long, device=du.device)
+            both = torch.stack((du.index_select(0, idx), de.index_select(0, idx)), dim=-1).to(device)
+            du, de = both[..., 0], both[..., 1]
+            idx = idx.to(device)
+        self._local_cache = (device, idx, du, de)
+        return idx, du, de
+
+    def trace_rays(self, incident_ray_directions: torch.Tensor, active_heliostats_mask: torch.Tensor,
+                   target_area_indices: torch.Tensor, ray_extinction_factor: float = 0.0,
+                   mirror_reflectivity: float = 0.935, device: torch.device | None = None
+                   ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Heliostat ray tracing (:220-508).  Returns ``(flux [H,res_u,res_e], intercept_factor [H],
+        on_target_factor [H], blocking_factor [H])`` for the heliostat samples owned by this rank."""
+        group = self.heliostat_group
+        assert torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
+            "Some heliostats were not aligned and cannot be raytraced."
+
+        points, normals = group.active_surface_points, group.active_surface_normals
+        device = points.device if device is None else torch.device(device)
+        if self.publish_reflection_directions:
+            with torch.no_grad():
+                group.preferred_reflection_directions = reflect(incident_ray_directions.unsqueeze(1), normals)
+
+        tower = self.scenario.solar_tower
+        n_planar = int(tower.number_of_target_areas_per_type[0])
+        planar = tower.target_areas[0]
+        idx, dist_u, dist_e = self._local_rows(device)
+        if idx is not None:
+            points, normals = points.index_select(0, idx), normals.index_select(0, idx)
+            incident_ray_directions = incident_ray_directions.index_select(0, idx)
+            target_area_indices = target_area_indices.index_select(0, idx)
+        if target_area_indices.numel() > 0:
+            lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
+            if lo < 0 or hi >= int(tower.number_of_target_areas_per_type.sum()):
+                raise IndexError("target_area_indices out of range")
+            if hi >= n_planar:
+                raise NotImplementedError(
+                    "cylindrical target areas (geometry.line_cylinder_intersections) are not implemented in the "
+                    "MI355X path yet")
+
+        ray_magnitude = float(self.ray_magnitude)
+        width, height = self._resolution_host
+        flux, factors = ops.TraceRays.apply(
+            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, planar.centers,
+            planar.normals, planar.dimensions, ray_magnitude, float(ray_extinction_factor), float(mirror_reflectivity),
+            width, height, False)
+        return flux, factors[0], factors[1], factors[2]
+
+    def trace_rays_per_target(self, incident_ray_directions, active_heliostats_mask, target_area_indices,
+                              ray_extinction_factor: float = 0.0, mirror_reflectivity: float = 0.935,
+                              device: torch.device | None = None):
+        """``trace_rays`` + ``get_bitmaps_per_target`` without materialising ``[H,res,res]``: every
+        heliostat's rays are splatted straight into its target's bitmap (``[T,res_u,res_e]``).
+        Extension of the reference API for field-scale flux prediction (configs 3 and 5)."""
+        group = self.heliostat_group
+        assert torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
+            "Some heliostats were not aligned and cannot be raytraced."
+        points, normals = group.active_surface_points, group.active_surface_normals
+        device = points.device if device is None else torch.device(device)
+        tower = self.scenario.solar_tower
+        planar = tower.target_areas[0]
+        idx, dist_u, dist_e = self._local_rows(device)
+        if idx is not None:
+            points, normals = points.index_select(0, idx), normals.index_select(0, idx)
+            incident_ray_directions = incident_ray_directions.index_select(0, idx)
+            target_area_indices = target_area_indices.index_select(0, idx)
+        width, height = self._resolution_host
+        flux, factors = ops.TraceRays.apply(
+            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, planar.centers,
+            planar.normals, planar.dimensions, float(self.ray_magnitude), float(ray_extinction_factor),
+            float(mirror_reflectivity), width, height, True)
+        n_total = int(tower.number_of_target_areas_per_type.sum())
+        if n_total > flux.shape[0]:   # cylindrical slots stay zero, like get_bitmaps_per_target's zeros init
+            flux = torch.cat([flux, flux.new_zeros((n_total - flux.shape[0],) + tuple(flux.shape[1:]))])
+        return flux, factors[0], factors[1], factors[2]
+
+    def get_bitmaps_per_target(self, bitmaps_per_heliostat: torch.Tensor, target_area_indices: torch.Tensor,
+                               device: torch.device | None = None) -> torch.Tensor:
+        """Bitmaps per heliostat -> bitmaps per target area ``[T,res_u,res_e]`` (:563-608)."""
+        n_targets = int(self.scenario.solar_tower.number_of_target_areas_per_type.sum())
+        return ops.per_target_sum(bitmaps_per_heliostat, target_area_indices, n_targets)

@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json's headline metric on MI355X.
+
+metric   : traced rays/s fwd+bwd, 1000-heliostat NURBS field (rays = H*R*P per step)
+workload : the metric config of BASELINE.md section 4 - H=1000 heliostats x R=100 rays/point x
+           P=10^4 points (4 facets x 50x50), 10x10 degree-3 NURBS control nets, one 8 m x 8 m planar
+           receiver, 256x256 bitmap, Gaussian sun; synthetic data, random (seeded) surface noise.
+step     : one surface-reconstruction epoch over the whole field:
+           NURBS points+normals (HIP) -> alignment bmm -> trace_rays (HIP) -> per-target sum ->
+           [N>1: RCCL all_reduce of the [T,256,256] flux] -> MSE loss vs fixed target bitmaps ->
+           backward (trace_bwd HIP, alignment, nurbs_bwd HIP) -> [N>1: RCCL all_reduce of the
+           control-point gradients, like surface_reconstructor.py:767-777].
+           Inputs (control points, orientations, distortions) are resident in HBM before timing.
+N GPUs   : heliostats are sharded over ranks exactly like RestrictedDistributedSampler
+           (heliostat i -> rank i mod N); total work is fixed  => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--heliostats", type=int, default=1000, help="total heliostats in the field (all ranks)")
+    ap.add_argument("--rays", type=int, default=100, help="rays per surface point (Sun.number_of_rays)")
+    ap.add_argument("--n-eval", type=int, default=50, help="evaluation points per facet per direction")
+    ap.add_argument("--n-cp", type=int, default=10, help="NURBS control points per facet per direction")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, cp_host, canting, transl, uv, orientation, incident, planar, seconds):
+    """Oracle (C restatement of the reference, kind='port') on the host cores: fwd+bwd of the same
+    workload on a bounded sample of heliostats.  Checker code used as a yardstick only."""
+    import numpy as np
+
+    import oracle
+    threads = oracle.max_threads()
+    H1 = cp_host.shape[0]
+    R, P = args.rays, 4 * args.n_eval * args.n_eval
+    rng = np.random.default_rng(7)
+
+    def run(h_count):
+        sel = np.arange(h_count) % H1
+        cp = cp_host[sel]
+        pts, nrm = oracle.nurbs_fwd(cp, np.broadcast_to(uv, (h_count,) + uv.shape[1:]), [3, 3], canting[sel], transl[sel])
+        ori = orientation[sel]
+        ap = (pts.reshape(h_count, P, 4) @ ori.transpose(0, 2, 1)).astype(np.float32)
+        an = (nrm.reshape(h_count, P, 4) @ ori.transpose(0, 2, 1)).astype(np.float32)
+        both = (rng.standard_normal((h_count, R, P, 2), dtype=np.float32) * np.float32(np.sqrt(4.3681e-06)))
+        du, de = both[..., 0], both[..., 1]
+        tix = np.zeros(h_count, dtype=np.int32)
+        t0 = time.perf_counter()
+        pts, nrm = oracle.nurbs_fwd(cp, np.broadcast_to(uv, (h_count,) + uv.shape[1:]), [3, 3], canting[sel], transl[sel])
+        flux, _ = oracle.trace_fwd(ap, an, incident[sel], du, de, tix, *planar, (256, 256), nthreads=threads)
+        g = 2.0 * (flux - flux.mean()) / flux.size
+        go, gn = oracle.trace_bwd(ap, an, incident[sel], du, de, tix, *planar, (256, 256), g.astype(np.float32),
+                                  nthreads=threads)
+        oracle.nurbs_bwd(cp, np.broadcast_to(uv, (h_count,) + uv.shape[1:]), [3, 3],
+                         (go @ ori).reshape(pts.shape), (gn @ ori).reshape(nrm.shape), canting[sel])
+        return time.perf_counter() - t0
+
+    probe = max(threads, 1)
+    t_probe = run(probe)
+    scale = max(1, min(int(seconds / max(t_probe, 1e-3)), 16))
+    h_count = probe * scale
+    t = run(h_count) if scale > 1 else t_probe
+    return {"value": h_count * R * P / t, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"C oracle (OpenMP over heliostats), fwd+bwd of {h_count} heliostats x {R} rays x {P} points "
+                      f"({h_count * R * P:.2e} rays) in {t:.2f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from artist_amd import HeliostatRayTracer, NURBSSurfaces
+    from artist_amd.distributed import all_reduce_sum, owned_heliostats
+    from artist_amd.scene import build_synthetic_scenario
+
+    H_total, R, n_eval = args.heliostats, args.rays, args.n_eval
+    P = 4 * n_eval * n_eval
+    own = owned_heliostats(H_total, world, rank)            # heliostat i -> rank i mod N
+    H = len(own)
+
+    # ---- synthetic field; this rank keeps only its own rows (positions from the global fan) ----------
+    from artist_amd import scene
+    scenario, uv = build_synthetic_scenario(H_total, n_rays=R, n_cp=(args.n_cp, args.n_cp), n_eval=n_eval, device=dev)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    mask = torch.ones(H_total, dtype=torch.int32, device=dev)
+    group.activate_heliostats(mask)
+    tix_all = torch.zeros(H_total, dtype=torch.long, device=dev)
+    inc_all = torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=dev).repeat(H_total, 1)
+    aim = scenario.solar_tower.get_centers_of_target_areas(tix_all)
+    orientation_all = scene.ideal_orientations(group.active_positions, aim, inc_all)
+    own_t = torch.tensor(own, dtype=torch.long, device=dev)
+    orientation = orientation_all[own_t].contiguous()
+    inc, tix = inc_all[own_t].contiguous(), tix_all[own_t].contiguous()
+    cp_all = group.active_nurbs_control_points
+    cp = cp_all[own_t].clone().requires_grad_(True)
+    canting, transl = group.active_canting[own_t].contiguous(), group.active_facet_translations[own_t].contiguous()
+    uv_local = uv[:1].expand(H, -1, -1, -1)
+    degrees = group.nurbs_degrees
+    planar = scenario.solar_tower.target_areas[0]
+    T = planar.centers.shape[0]
+    # distortions for the owned rows only: ONE interleaved [H,R,P,2] buffer, (u,e) = stride-2 views
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    both = torch.randn((H, R, P, 2), generator=g, device=dev, dtype=torch.float32) * (4.3681e-06 ** 0.5)
+    dist_u, dist_e = both[..., 0], both[..., 1]
+
+    from artist_amd import ops
+    target = None
+
+    def forward():
+        pts, nrm = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl)
+        ap = pts.reshape(H, P, 4) @ orientation.transpose(1, 2)
+        an = nrm.reshape(H, P, 4) @ orientation.transpose(1, 2)
+        flux, factors = ops.trace_rays(ap, an, inc, dist_u, dist_e, tix, planar.centers, planar.normals,
+                                       planar.dimensions, 1.0, 0.0, 0.935, (256, 256))
+        return flux, factors
+
+    def step(backward=True):
+        if cp.grad is not None:
+            cp.grad = None
+        with torch.set_grad_enabled(backward):
+            flux, _ = forward()
+            per_target = ops.per_target_sum(flux.detach(), tix, T)
+            all_reduce_sum(per_target)                           # RCCL reduce of the receiver flux bitmap
+            if backward:
+                loss = torch.nn.functional.mse_loss(flux, target)
+                loss.backward()
+                full = torch.zeros_like(cp_all)
+                full[own_t] = cp.grad
+                all_reduce_sum(full)                             # surface_reconstructor.py:767-777
+        return per_target
+
+    with torch.no_grad():
+        f0, _ = forward()
+        target = (f0 * 1.05).detach()
+        del f0
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, k):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step(True)
+    dt = timed(lambda: step(True), args.steps)
+    dt_fwd = timed(lambda: step(False), args.steps)
+
+    # ---- dominant-kernel timing with HIP events on the launch stream (current torch stream) ----------
+    def kernel_ms(fn, k=5):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / k
+
+    with torch.no_grad():
+        pts, nrm = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl)
+        ap = (pts.reshape(H, P, 4) @ orientation.transpose(1, 2)).contiguous()
+        an = (nrm.reshape(H, P, 4) @ orientation.transpose(1, 2)).contiguous()
+    ms_fwd = kernel_ms(lambda: ops.trace_rays(ap, an, inc, dist_u, dist_e, tix, planar.centers, planar.normals,
+                                              planar.dimensions, 1.0, 0.0, 0.935, (256, 256)))
+    apg, ang = ap.clone().requires_grad_(True), an.clone().requires_grad_(True)
+    flux, _ = ops.trace_rays(apg, ang, inc, dist_u, dist_e, tix, planar.centers, planar.normals, planar.dimensions,
+                             1.0, 0.0, 0.935, (256, 256))
+    gflux = torch.ones_like(flux)
+    ms_bwd = kernel_ms(lambda: torch.autograd.grad(flux, (apg, ang), gflux, retain_graph=True))
+    del flux, gflux, apg, ang
+
+    rays_local = H * R * P
+    # algorithmic bytes per launch: distortions 8 B/ray + origin/normal 32 B/point
+    # + one bitmap write (fwd) / one grad-bitmap read + 32 B/point grad write (bwd)
+    bytes_fwd = rays_local * 8 + H * P * 32 + H * 256 * 256 * 4
+    bytes_bwd = rays_local * 8 + H * P * 32 + H * P * 32 + H * 256 * 256 * 4
+    if ms_bwd >= ms_fwd:
+        dom = dict(kernel="trace_bwd_kernel", ms=ms_bwd, bytes=bytes_bwd)
+    else:
+        dom = dict(kernel="trace_fwd_kernel", ms=ms_fwd, bytes=bytes_fwd)
+    achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+
+    if rank == 0:
+        total_rays = H_total * R * P
+        out = {
+            "metric": "traced rays/s fwd+bwd, 1000-heliostat NURBS field",
+            "value": total_rays * args.steps / dt,
+            "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"metric config: {H_total} heliostats x {R} rays/point x {P} points "
+                                   f"({total_rays:.3g} rays/step), {args.n_cp}x{args.n_cp} degree-3 NURBS, 256x256 bitmap, "
+                                   "surface-reconstruction epoch fwd+bwd",
+                       "heliostats": H_total, "rays_per_point": R, "points_per_heliostat": P,
+                       "parallelism": f"heliostat-sharded dp{world}", "heliostats_per_rank": H},
+            "fwd_only": {"value": total_rays * args.steps / dt_fwd, "unit": "rays/s",
+                         "ms_per_step": dt_fwd / args.steps * 1e3},
+            "kernels": {"trace_fwd_ms": ms_fwd, "trace_bwd_ms": ms_bwd,
+                        "trace_fwd_rays_per_s": rays_local / (ms_fwd * 1e-3),
+                        "trace_bwd_rays_per_s": rays_local / (ms_bwd * 1e-3)},
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import numpy as np
+            k = min(H, 64)
+            npf = lambda x: x.detach().cpu().numpy()  # noqa: E731
+            out["cpu_baseline"] = cpu_baseline(
+                args, npf(cp[:k]), npf(canting[:k]), npf(transl[:k]), npf(uv[:1].contiguous()),
+                npf(orientation[:k]), npf(inc[:k]), (npf(planar.centers), npf(planar.normals), npf(planar.dimensions)),
+                args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

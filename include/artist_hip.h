@@ -1,0 +1,125 @@
+/*
+ * artist_hip.h - C ABI of libartist_hip.so: the MI355X (gfx950) implementation of ARTIST's
+ * heliostat ray-tracing hot path.
+ *
+ * ARTIST (v2.0.0) is pure Python/PyTorch and has no FFI of its own; the boundary its callers
+ * see is the Python method surface quoted below.  Each entry point here replaces the chain of
+ * ATen ops behind one of those methods, and is what a binding inside ARTIST would call
+ * (INTEGRATION.md shows the ctypes stub).  Reference paths are relative to the ARTIST repo.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all tensors fp32, row-major, contiguous unless
+ *     an explicit element stride is passed; all pointers are DEVICE pointers;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream
+ *     and allocates nothing that outlives it; no global state -> re-entrant;
+ *   - return 0 on success, a negative ART_E* code otherwise (never throws across the ABI);
+ *     art_strerror() maps a code to text;
+ *   - outputs are fully written by the callee (zero-filled first where they are accumulators).
+ */
+#ifndef ARTIST_HIP_H
+#define ARTIST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ART_OK 0
+#define ART_EINVAL -1      /* bad size / null pointer / unsupported degree */
+#define ART_ETARGET -2     /* reserved: target index out of range (checked on host copies only) */
+#define ART_ELAUNCH -3     /* HIP launch or runtime error (see art_last_hip_error) */
+#define ART_EUNSUPPORTED -4
+
+/* Library / ABI version (bumped when a signature changes). */
+int art_abi_version(void);
+const char *art_strerror(int code);
+/* hipError_t of the last failing HIP call made by this library on the calling thread (0 = none). */
+int art_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_trace_fwd - HeliostatRayTracer.trace_rays with blocking off and planar targets:
+ *   artist/raytracing/heliostat_ray_tracer.py:220-508 =
+ *     geometry.reflect                (artist/raytracing/geometry.py:11-41)
+ *   + scatter_rays/rotate_distortions (heliostat_ray_tracer.py:510-561, artist/geometry/transforms.py:7-83)
+ *   + line_plane_intersections        (artist/raytracing/geometry.py:44-204)
+ *   + intensity product               (heliostat_ray_tracer.py:482-487)
+ *   + bilinear_splatting              (heliostat_ray_tracer.py:610-778)
+ *   + the three diagnostic factors    (heliostat_ray_tracer.py:498-506)
+ *   + (mode 1) get_bitmaps_per_target (heliostat_ray_tracer.py:563-608) fused into the splat.
+ *
+ *   origins, normals  [H,P,4]  heliostat_group.active_surface_points / _normals (aligned)
+ *   incident          [H,4]    incident_ray_directions
+ *   dist_u, dist_e    distortion angles; element (h,r,p) at base[h*dist_sh + r*dist_sr + p*dist_sp]
+ *                     (element strides: Sun.get_distortions returns stride-2 views of one
+ *                     interleaved [H,R,P,2] buffer, artist/scene/sun.py:227-234)
+ *   target_idx        [H] int32, each in [0,T)
+ *   plane_centers / plane_normals [T,4], plane_dims [T,2]  TowerTargetAreasPlanar tensors
+ *   ray_magnitude     Rays.ray_magnitudes fill value (heliostat_ray_tracer.py:185-203)
+ *   extinction, reflectivity  trace_rays(ray_extinction_factor, mirror_reflectivity)
+ *   W, Hh             bitmap_resolution[0] (east), bitmap_resolution[1] (up)
+ *   mode              0: flux is [H,Hh,W] (one bitmap per active heliostat)
+ *                     1: flux is [T,Hh,W] (summed per target area)
+ *   flux              output, zero-filled then accumulated; rows already up-down flipped
+ *   factors           output [3,H]: intercept, on_target, blocking fractions
+ * ------------------------------------------------------------------------------------------- */
+int art_trace_fwd(const float *origins, const float *normals, const float *incident,
+                  const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
+                  const int32_t *target_idx, const float *plane_centers, const float *plane_normals,
+                  const float *plane_dims, double ray_magnitude, double extinction, double reflectivity,
+                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t W, int64_t Hh, int mode,
+                  float *flux, float *factors, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_trace_bwd - what torch.autograd derives for the op chain of art_trace_fwd (mode 0 or 1):
+ * indices and masks are constants, gradients flow through the bilinear weights, the Lambert
+ * intensity and the hit point (heliostat_ray_tracer.py:285-290, 328-335, 390-409, 482-494,
+ * 610-778).  Same inputs as the forward plus
+ *   grad_flux     [H,Hh,W] (mode 0) or [T,Hh,W] (mode 1)
+ *   grad_origins, grad_normals   outputs [H,P,4] (w components 0 / as autograd gives them)
+ * ------------------------------------------------------------------------------------------- */
+int art_trace_bwd(const float *origins, const float *normals, const float *incident,
+                  const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
+                  const int32_t *target_idx, const float *plane_centers, const float *plane_normals,
+                  const float *plane_dims, double ray_magnitude, double extinction, double reflectivity,
+                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t W, int64_t Hh, int mode,
+                  const float *grad_flux, float *grad_origins, float *grad_normals, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_per_target_sum - HeliostatRayTracer.get_bitmaps_per_target
+ * (heliostat_ray_tracer.py:563-608): out[t] = sum of bitmaps[h] with target_idx[h] == t.
+ *   bitmaps [H,npix], target_idx [H], out [T,npix] (fully written).
+ * ------------------------------------------------------------------------------------------- */
+int art_per_target_sum(const float *bitmaps, const int32_t *target_idx, int64_t H, int64_t T, int64_t npix,
+                       float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_nurbs_fwd - NURBSSurfaces.calculate_surface_points_and_normals
+ * (artist/nurbs/surfaces.py:475-689: find_spans :157-245, basis_functions_and_derivatives
+ * :247-417, A3.6 accumulation :578-613, normals :615-672, canting + translation :674-687 via
+ * artist/geometry/transforms.py:276-347).
+ *   control_points [H,F,nu,nv,3]; eval_points element (h,f,m,c) at
+ *   base[h*uv_sh + f*uv_sf + m*2 + c] (strides 0 broadcast one [M,2] grid to every facet);
+ *   knots_u [H,F,nu+p+1], knots_v [H,F,nv+q+1];
+ *   uniform != 0: span = floor(x*(n_unique-1)) + degree (surfaces.py:198-207), else the
+ *   linear search of :209-243;  canting [H,F,2,4] or NULL; translations [H,F,4] (used only
+ *   with canting);  outputs points, normals [H,F,M,4].   Degrees 1..7.
+ * ------------------------------------------------------------------------------------------- */
+int art_nurbs_fwd(const float *control_points, const float *eval_points, int64_t uv_sh, int64_t uv_sf,
+                  const float *knots_u, const float *knots_v, const float *canting, const float *translations,
+                  int p, int q, int uniform, int64_t n_unique_u, int64_t n_unique_v,
+                  int64_t H, int64_t F, int64_t M, int64_t nu, int64_t nv,
+                  float *points, float *normals, void *stream);
+
+/* art_nurbs_bwd - autograd of art_nurbs_fwd w.r.t. the control points.
+ *   grad_points, grad_normals [H,F,M,4] -> grad_control_points [H,F,nu,nv,3] (fully written). */
+int art_nurbs_bwd(const float *control_points, const float *eval_points, int64_t uv_sh, int64_t uv_sf,
+                  const float *knots_u, const float *knots_v, const float *canting,
+                  int p, int q, int uniform, int64_t n_unique_u, int64_t n_unique_v,
+                  int64_t H, int64_t F, int64_t M, int64_t nu, int64_t nv,
+                  const float *grad_points, const float *grad_normals, float *grad_control_points, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTIST_HIP_H */

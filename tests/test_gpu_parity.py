@@ -1,0 +1,273 @@
+"""GPU parity suite (``-m gpu``): the HIP path, called through the C ABI, against
+  (1) the CPU oracle on the same seeded inputs,
+  (2) the golden fixtures generated from the imported reference, and
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances are fp32 tolerances and are written next to each assertion.  Nothing here reads
+/root/reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import STAGE_CASES, rel_l2, sun_distortions
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+
+
+def t(x, dtype=None):
+    out = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return out if dtype is None else out.to(dtype)
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def interleave(du, de):
+    """Return (u, e) as stride-2 views of ONE device buffer, like Sun.get_distortions."""
+    both = torch.stack((t(du), t(de)), dim=-1).contiguous()
+    return both[..., 0], both[..., 1]
+
+
+def trace_inputs(d, interleaved=True):
+    du, de = (interleave(d["distortions_u"], d["distortions_e"]) if interleaved
+              else (t(d["distortions_u"]).contiguous(), t(d["distortions_e"]).contiguous()))
+    return dict(origins=t(d["aligned_points"]), normals=t(d["aligned_normals"]), incident=t(d["incident"]),
+                dist_u=du, dist_e=de, target_idx=t(d["target_idx"]), centers=t(d["target_centers"]),
+                plane_normals=t(d["target_normals"]), dims=t(d["target_dims"]),
+                ray_magnitude=float(d["ray_magnitude"]), extinction=float(d["extinction"]),
+                reflectivity=float(d["reflectivity"]), resolution=tuple(int(v) for v in d["resolution"]))
+
+
+def oracle_fwd(d, **kw):
+    return oracle.trace_fwd(d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"],
+                            d["distortions_e"], d["target_idx"], d["target_centers"], d["target_normals"],
+                            d["target_dims"], d["resolution"], float(d["ray_magnitude"]), float(d["extinction"]),
+                            float(d["reflectivity"]), **kw)
+
+
+def test_library_is_the_hip_one():
+    from artist_amd import _lib
+    assert _lib.lib().art_abi_version() == 1
+    assert len(_lib.loaded_hip_runtimes()) == 1, _lib.loaded_hip_runtimes()
+
+
+@pytest.mark.parametrize("name", STAGE_CASES)
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_trace_forward(golden, name, interleaved):
+    from artist_amd import trace_rays
+    d = golden(name)
+    flux, fac = trace_rays(**trace_inputs(d, interleaved))
+    o_flux, o_fac = oracle_fwd(d)
+    # vs oracle: same op order; only sinf/cosf (<=1 ULP) and the atomic summation order differ.
+    # Tiny cases have O(1) rays per pixel so per-ray 1e-4 px noise is not averaged: 2e-4 relative L2.
+    assert rel_l2(n(flux), o_flux) < 2e-4, rel_l2(n(flux), o_flux)
+    assert rel_l2(n(flux), d["flux"]) < 2e-4, rel_l2(n(flux), d["flux"])
+    np.testing.assert_array_equal(n(fac), o_fac)          # ray counts are integers: exact
+    np.testing.assert_array_equal(n(fac[0]), d["intercept"])
+    np.testing.assert_array_equal(n(fac[1]), d["on_target"])
+    np.testing.assert_array_equal(n(fac[2]), d["blocking"])
+
+
+@pytest.mark.parametrize("name", STAGE_CASES)
+def test_trace_per_target_mode(golden, name):
+    from artist_amd import per_target_sum, trace_rays
+    d = golden(name)
+    T = d["target_centers"].shape[0]
+    inp = trace_inputs(d)
+    flux_h, _ = trace_rays(**inp)
+    flux_t, fac = trace_rays(**inp, per_target=True)
+    summed = per_target_sum(flux_h, inp["target_idx"], T)
+    assert flux_t.shape == (T, int(d["resolution"][1]), int(d["resolution"][0]))
+    scale = float(np.abs(d["per_target"]).max()) + 1e-30
+    np.testing.assert_allclose(n(flux_t), n(summed), rtol=0, atol=2e-6 * scale)    # summation order only
+    assert rel_l2(n(summed), d["per_target"]) < 2e-4
+    np.testing.assert_allclose(n(summed), oracle.per_target(n(flux_h), d["target_idx"], T), rtol=1e-6, atol=1e-6 * scale)
+
+
+@pytest.mark.parametrize("name", STAGE_CASES)
+def test_trace_backward(golden, name):
+    from artist_amd import trace_rays
+    d, d64 = golden(name), golden(name + "_f64")
+    inp = trace_inputs(d)
+    inp["origins"].requires_grad_(True)
+    inp["normals"].requires_grad_(True)
+    flux, _ = trace_rays(**inp)
+    (flux * t(d["loss_weights"])).sum().backward()
+    go, gn = oracle.trace_bwd(d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"],
+                              d["distortions_e"], d["target_idx"], d["target_centers"], d["target_normals"],
+                              d["target_dims"], d["resolution"], d["loss_weights"], float(d["ray_magnitude"]),
+                              float(d["extinction"]), float(d["reflectivity"]))
+    for got, orc, key in ((inp["origins"].grad, go, "grad_aligned_points"), (inp["normals"].grad, gn, "grad_aligned_normals")):
+        ref = d[key]
+        if np.linalg.norm(ref) == 0:
+            assert float(got.abs().sum()) == 0
+            continue
+        # yardstick: the reference's own fp32-vs-fp64 gradient error (cell flips at pixel borders)
+        ref_err = rel_l2(ref, d64[key])
+        assert rel_l2(n(got), orc) < max(ref_err, 2e-4), (key, rel_l2(n(got), orc))
+        assert rel_l2(n(got), ref) < max(3 * ref_err, 2e-4), (key, rel_l2(n(got), ref), ref_err)
+        assert float(got[..., 3].abs().max()) == 0 or key == "grad_aligned_normals"
+
+
+@pytest.mark.parametrize("name", STAGE_CASES + ["known"])
+def test_nurbs_forward_backward(golden, name):
+    from artist_amd import NURBSSurfaces
+    if name == "known":   # tests/nurbs/test_surfaces.py:202-300 known answer, through the mirror class
+        ka = golden("known_answers")
+        surf = NURBSSurfaces(torch.tensor([2, 2]), t(ka["nurbsfwd_cp"]), device=DEV)
+        pts, nrm = surf(t(ka["nurbsfwd_uv"]), t(ka["nurbsfwd_canting"]), t(ka["nurbsfwd_transl"]), DEV)
+        torch.testing.assert_close(pts.cpu(), torch.from_numpy(ka["nurbsfwd_expected_points"]))
+        torch.testing.assert_close(nrm.cpu(), torch.from_numpy(ka["nurbsfwd_expected_normals"]))
+        return
+    d = golden(name)
+    cp = t(d["control_points"]).requires_grad_(True)
+    surf = NURBSSurfaces(torch.from_numpy(d["degrees"]), cp, device=DEV)
+    assert np.array_equal(n(surf.knot_vectors_u[0, 0]), d["knots_u"])
+    pts, nrm = surf.calculate_surface_points_and_normals(t(d["eval_points"]), t(d["canting"]), t(d["facet_translations"]))
+    o_pts, o_nrm = oracle.nurbs_fwd(d["control_points"], d["eval_points"], d["degrees"], d["canting"], d["facet_translations"])
+    np.testing.assert_array_equal(n(pts), o_pts)                              # same op order: bit-exact
+    np.testing.assert_array_equal(n(pts), d["nurbs_points"])                  # ... and equal to the reference
+    np.testing.assert_allclose(n(nrm), d["nurbs_normals"], rtol=0, atol=1.2e-7)   # 1 ULP (sqrt / vector_norm)
+    gp, gn = d["grad_nurbs_points"].reshape(d["nurbs_points"].shape), d["grad_nurbs_normals"].reshape(d["nurbs_normals"].shape)
+    torch.autograd.backward([pts, nrm], [t(gp), t(gn)])
+    o_g = oracle.nurbs_bwd(d["control_points"], d["eval_points"], d["degrees"], gp, gn, d["canting"])
+    if np.linalg.norm(o_g) > 0:
+        assert rel_l2(n(cp.grad), o_g) < 1e-5, rel_l2(n(cp.grad), o_g)               # LDS-atomic summation order
+        assert rel_l2(n(cp.grad), d["grad_control_points"]) < 2e-5
+
+
+def test_nurbs_broadcast_grid_and_no_canting(golden):
+    """Expanded (stride-0) evaluation grid, canting=None branch (surfaces.py:689), mixed degrees (generic kernel)."""
+    from artist_amd import NURBSSurfaces
+    g = torch.Generator().manual_seed(3)
+    cp = torch.rand(2, 3, 6, 5, 3, generator=g)
+    uv = torch.rand(37, 2, generator=g) * 0.98 + 0.01
+    for deg in ([3, 3], [2, 3], [5, 2], [1, 1]):
+        surf = NURBSSurfaces(torch.tensor(deg), cp.to(DEV), device=DEV)
+        uvx = uv.to(DEV)[None, None].expand(2, 3, -1, -1)
+        pts, nrm = surf(uvx, None, None)
+        o_pts, o_nrm = oracle.nurbs_fwd(cp.numpy(), uvx.cpu().contiguous().numpy(), deg)
+        np.testing.assert_allclose(n(pts), o_pts, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(n(nrm), o_nrm, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", STAGE_CASES)
+def test_end_to_end_autograd_to_control_points(golden, name):
+    """control points -> NURBS (HIP) -> alignment (torch bmm) -> trace (HIP) -> loss; d loss / d control points and
+    d loss / d orientation vs torch.autograd of the reference (north_star: grads w.r.t. NURBS control points and
+    kinematic parameters - the kinematic chain enters through the orientation matrices)."""
+    from artist_amd import NURBSSurfaces, trace_rays
+    d, d64 = golden(name), golden(name + "_f64")
+    cp = t(d["control_points"]).requires_grad_(True)
+    ori = t(d["orientation"]).requires_grad_(True)
+    H = ori.shape[0]
+    pts, nrm = NURBSSurfaces(torch.from_numpy(d["degrees"]), cp, device=DEV)(
+        t(d["eval_points"]), t(d["canting"]), t(d["facet_translations"]))
+    ap = pts.reshape(H, -1, 4) @ ori.transpose(1, 2)
+    an = nrm.reshape(H, -1, 4) @ ori.transpose(1, 2)
+    inp = trace_inputs(d)
+    inp.update(origins=ap, normals=an)
+    flux, _ = trace_rays(**inp)
+    (flux * t(d["loss_weights"])).sum().backward()
+    for got, key in ((cp.grad, "grad_control_points"), (ori.grad, "grad_orientation")):
+        ref = d[key]
+        if np.linalg.norm(ref) == 0:
+            assert float(got.abs().sum()) == 0
+            continue
+        ref_err = rel_l2(ref, d64[key])
+        assert rel_l2(n(got), ref) < max(3 * ref_err, 5e-4), (key, rel_l2(n(got), ref), ref_err)
+
+
+@pytest.mark.parametrize("name,tol", [("config1", 1e-6), ("config2", 1e-5)])
+def test_baseline_configs_flux_l2(golden, name, tol):
+    """BASELINE.json configs 1 and 2 on the GPU vs the reference PyTorch-CPU flux (north_star: < 1e-5)."""
+    from artist_amd import trace_rays
+    d = golden(name)
+    H, P = d["aligned_points"].shape[:2]
+    du, de = sun_distortions(H, int(d["n_rays"]), P, float(d["covariance"]), seed=int(d["seed"]))
+    dd = dict(d, distortions_u=du.numpy(), distortions_e=de.numpy())
+    flux, fac = trace_rays(**trace_inputs(dd))
+    err = rel_l2(n(flux), d["flux"])
+    print(f"{name}: flux rel L2 vs reference = {err:.3e}; reference fp32-vs-fp64 = {rel_l2(d['flux'], d['flux_f64']):.3e}")
+    assert err < tol, err
+    np.testing.assert_array_equal(n(fac[0]), d["intercept"])
+    np.testing.assert_array_equal(n(fac[1]), d["on_target"])
+
+
+# ---- properties at full size (H=8 heliostats x 10^6 rays each; same kernel paths as H=1000) ----------------
+@pytest.fixture(scope="module")
+def field():
+    from artist_amd.scene import build_synthetic_scenario
+    H = 8
+    scenario, uv = build_synthetic_scenario(H, n_rays=100, device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    group.activate_heliostats(mask)
+    tix = torch.zeros(H, dtype=torch.long, device=DEV)
+    inc = torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=DEV).repeat(H, 1)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask)
+    return scenario, group, mask, tix, inc
+
+
+def test_full_size_properties(field):
+    from artist_amd import HeliostatRayTracer
+    scenario, group, mask, tix, inc = field
+    rt = HeliostatRayTracer(scenario, group, blocking_active=False)
+    flux, intercept, on_target, blocking = rt.trace_rays(inc, mask, tix)
+    H = flux.shape[0]
+    assert flux.shape == (H, 256, 256) and bool(torch.isfinite(flux).all()) and float(flux.min()) >= 0
+    # energy: bilinear weights sum to 1, Lambert factor <= 1  =>  sum(flux) <= reflectivity * splatted rays
+    rays = 100 * group.active_surface_points.shape[1]
+    total = flux.sum((1, 2))
+    assert bool((total <= 0.935 * intercept * rays * (1 + 1e-5)).all())
+    assert bool((total >= 0.25 * 0.935 * intercept * rays).all())           # Lambert cosine >= 0.25 on this fan
+    assert bool((intercept <= on_target).all()) and bool((blocking == 1).all())
+    # linearity in reflectivity / extinction (pure scaling of every ray)
+    flux2, *_ = rt.trace_rays(inc, mask, tix, ray_extinction_factor=0.5, mirror_reflectivity=0.935)
+    assert rel_l2(n(flux2), 0.5 * n(flux)) < 1e-6
+    # per-target fused mode == sum of per-heliostat bitmaps
+    pt, *_ = rt.trace_rays_per_target(inc, mask, tix)
+    assert rel_l2(n(pt[0]), n(flux.sum(0))) < 1e-6
+    assert rel_l2(n(rt.get_bitmaps_per_target(flux, tix)[0]), n(flux.sum(0))) < 1e-6
+    # rank sharding: sum over ranks of the per-target bitmaps == single rank (SURVEY 8e invariant)
+    acc = torch.zeros_like(pt)
+    rows = []
+    for rank in range(3):
+        rtr = HeliostatRayTracer(scenario, group, blocking_active=False, world_size=3, rank=rank)
+        f_local, *_ = rtr.trace_rays(inc, mask, tix)
+        idx = rtr.get_sampler_indices()
+        rows.append(idx)
+        assert f_local.shape[0] == idx.numel()
+        np.testing.assert_allclose(n(f_local), n(flux[idx]), rtol=0, atol=2e-6 * float(flux.max()))
+        acc += rtr.get_bitmaps_per_target(f_local, tix[idx])
+    assert sorted(torch.cat(rows).tolist()) == list(range(H))
+    assert rel_l2(n(acc), n(pt)) < 1e-6
+    # one heliostat against the oracle at full size (10^6 rays)
+    planar = scenario.solar_tower.target_areas[0]
+    o_flux, o_fac = oracle.trace_fwd(n(group.active_surface_points[:1]), n(group.active_surface_normals[:1]), n(inc[:1]),
+                                     n(rt.distortions_dataset.distortions_u[:1]), n(rt.distortions_dataset.distortions_e[:1]),
+                                     n(tix[:1]), n(planar.centers), n(planar.normals), n(planar.dimensions), (256, 256))
+    assert rel_l2(n(flux[:1]), o_flux) < 1e-5, rel_l2(n(flux[:1]), o_flux)
+    np.testing.assert_array_equal(n(intercept[:1]), o_fac[0])
+
+
+def test_error_behaviour(field):
+    from artist_amd import ArtistHipError, HeliostatRayTracer, trace_rays
+    scenario, group, mask, tix, inc = field
+    with pytest.raises(NotImplementedError):
+        HeliostatRayTracer(scenario, group)                       # blocking_active defaults to True
+    rt = HeliostatRayTracer(scenario, group, blocking_active=False)
+    with pytest.raises(AssertionError, match="Some heliostats were not aligned and cannot be raytraced."):
+        rt.trace_rays(inc, torch.zeros_like(mask), tix)           # tests/raytracing/test_heliostat_ray_tracer.py:44-104
+    with pytest.raises(IndexError):
+        rt.trace_rays(inc, mask, tix + 5)
+    cpu = [torch.zeros(1, 4, 4), torch.zeros(1, 4, 4), torch.zeros(1, 4), torch.zeros(1, 2, 4), torch.zeros(1, 2, 4),
+           torch.zeros(1, dtype=torch.long), torch.zeros(1, 4), torch.zeros(1, 4), torch.ones(1, 2)]
+    with pytest.raises(ArtistHipError, match="no CPU fallback"):
+        trace_rays(*cpu)
+    with pytest.raises(ValueError, match="must have the same shape"):   # artist/geometry/transforms.py:47-50
+        trace_rays(*[c.to(DEV) for c in cpu[:4]], torch.zeros(1, 3, 4, device=DEV), *[c.to(DEV) for c in cpu[5:]])
