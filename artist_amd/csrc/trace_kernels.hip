@@ -11,6 +11,7 @@
 // :610-778 (bilinear_splatting), :498-506 (factors), :563-608 (per-target sums, mode 1).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ray_math.hpp"
 #include "launch_common.hpp"
@@ -36,6 +37,9 @@ struct TraceArgs {
     int r_chunk;              // samples per block
     int n_rchunks;            // ceil(R / r_chunk)
     int n_ptiles;             // ceil(P / kBlock)
+    int p_block;              // points per workgroup (LDS-window kernel)
+    int n_pblocks;            // ceil(P / p_block)
+    int tile_cap;             // LDS bitmap-window capacity in pixels
 };
 
 // Distortion fetch.  INTERLEAVED: (u,e) adjacent floats of one [H,R,P,2] buffer -> one 8-byte load.
@@ -113,6 +117,181 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
     if ((threadIdx.x & 63) == 0) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_on); }
     __syncthreads();
     if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x * a.H + h], s_cnt[threadIdx.x]);
+}
+
+// --------------------------------------------------------------------------------------------
+// Forward, LDS-privatised splat (the production kernel).
+//
+// A workgroup owns a block of `p_block` consecutive surface points of one heliostat and a chunk
+// of its distortion samples.  Rays of neighbouring mirror points land within a few pixels of each
+// other (plus the sun-shape blur), so the workgroup's footprint on the receiver is a small window
+// of the bitmap: it is accumulated in LDS with ds_add_f32 and flushed ONCE with row-contiguous
+// global atomics (one per touched pixel instead of four per ray - global float atomics execute at
+// the memory side at ~2e10 scattered lanes/s and bound the kernel otherwise).
+//
+//   phase 1  window:  chief rays (no scatter) of the block's points -> bounding box in pixels,
+//                     padded by the largest scatter angle seen in the block's first sample x the
+//                     longest path (a guess that only affects speed: rays that fall outside the
+//                     window take the global-atomic path, so the result never depends on it).
+//   phase 2  trace:   thread <-> point, loop over the chunk's samples, 4 LDS adds per ray.
+//   phase 3  flush:   window rows -> global bitmap (up-down flipped).
+//
+// grid.x = H * n_pblocks * n_rchunks ; block = any multiple of 64 ; dynamic LDS = tile_cap floats.
+// --------------------------------------------------------------------------------------------
+struct Window {
+    int e0, u0, tw, th;   // origin (un-flipped flat coordinates) and size; tw*th <= tile_cap
+};
+
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float* __restrict__ flux,
+                                                             unsigned int* __restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    __shared__ float s_red[7][16];     // per-wave partials: emin, emax, umin, umax, tmax, amin, angmax
+    __shared__ Window s_win;
+    __shared__ unsigned s_cnt[2];
+
+    const int bid = blockIdx.x;
+    const int rchunk = bid % a.n_rchunks;
+    const int pblock = (bid / a.n_rchunks) % a.n_pblocks;
+    const int h = bid / (a.n_rchunks * a.n_pblocks);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+
+    const int t = a.target_idx[h];
+    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
+    const float4 inc = a.incident[h];
+    const int p0 = pblock * a.p_block;
+    const int p1 = min(p0 + a.p_block, a.P);
+    const int r0 = rchunk * a.r_chunk;
+    const int r1 = min(r0 + a.r_chunk, a.R);
+    const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
+    const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
+    const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
+
+    // ---- phase 1: window ---------------------------------------------------------------------
+    float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, tmax = 0.0f, amin = 1.0f, angmax = 0.0f;
+    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+        const float4 o = org[p];
+        const float4 n = nrm[p];
+        float4 d; float s;
+        reflect(inc, n, d, s);
+        const float numer = plane_numer(pl, o);
+        const Hit hit = intersect(pl, o, numer, d.x, d.y, d.z);
+        if (hit.valid) {
+            emin = fminf(emin, hit.be); emax = fmaxf(emax, hit.be);
+            umin = fminf(umin, hit.bu); umax = fmaxf(umax, hit.bu);
+            tmax = fmaxf(tmax, hit.t); amin = fminf(amin, -hit.a);
+        }
+        float u, e;
+        load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e);
+        angmax = fmaxf(angmax, fmaxf(fabsf(u), fabsf(e)));
+    }
+    emin = wave_min_f32(emin); emax = wave_max_f32(emax); umin = wave_min_f32(umin); umax = wave_max_f32(umax);
+    tmax = wave_max_f32(tmax); amin = wave_min_f32(amin); angmax = wave_max_f32(angmax);
+    if (lane == 0) {
+        s_red[0][wave] = emin; s_red[1][wave] = emax; s_red[2][wave] = umin; s_red[3][wave] = umax;
+        s_red[4][wave] = tmax; s_red[5][wave] = amin; s_red[6][wave] = angmax;
+    }
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < nwaves; ++w) {
+            emin = fminf(emin, s_red[0][w]); emax = fmaxf(emax, s_red[1][w]);
+            umin = fminf(umin, s_red[2][w]); umax = fmaxf(umax, s_red[3][w]);
+            tmax = fmaxf(tmax, s_red[4][w]); amin = fminf(amin, s_red[5][w]); angmax = fmaxf(angmax, s_red[6][w]);
+        }
+        Window win = {0, 0, 0, 0};
+        if (emax >= emin) {
+            // pixels per metre along e / u, path length, obliquity; x1.3 because the first sample's extreme
+            // (~3.7 sigma of p_block draws) is below the extreme over all samples (~4.8 sigma).
+            const float ppm = fmaxf(pl.wm1 / pl.w, pl.hm1 / pl.h);
+            const float padf = 1.3f * angmax * tmax * ppm / fmaxf(amin, 0.05f) + 2.0f;
+            const int pad = (int)fminf(padf, 32768.0f);
+            int e0 = max((int)emin - pad, 0), e1 = min((int)emax + 1 + pad, a.W - 1);
+            int u0 = max((int)umin - pad, 0), u1 = min((int)umax + 1 + pad, a.Hh - 1);
+            int tw = e1 - e0 + 1, th = u1 - u0 + 1;
+            if ((int64_t)tw * th > a.tile_cap) {   // keep the centre, let the tails use global atomics
+                const float sc = sqrtf((float)a.tile_cap / ((float)tw * (float)th));
+                const int tw2 = max(2, min(tw, (int)((float)tw * sc)));
+                const int th2 = max(2, min(th, a.tile_cap / tw2));
+                e0 += (tw - tw2) / 2; u0 += (th - th2) / 2; tw = tw2; th = th2;
+            }
+            win.e0 = e0; win.u0 = u0; win.tw = tw; win.th = th;
+        }
+        s_win = win;
+    }
+    __syncthreads();
+    const Window win = s_win;
+    const int npx = win.tw * win.th;
+    for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0.0f;
+    __syncthreads();
+
+    // ---- phase 2: trace ----------------------------------------------------------------------
+    unsigned n_on = 0, n_int = 0;
+    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+        const float4 o = org[p];
+        const float4 n = nrm[p];
+        float4 d; float s;
+        reflect(inc, n, d, s);
+        const float numer = plane_numer(pl, o);
+        int64_t off = dbase + (int64_t)p * a.sp;
+#pragma unroll 2
+        for (int r = r0; r < r1; ++r, off += a.sr) {
+            float u, e;
+            load_dist<INTERLEAVED>(a, off, u, e);
+            const Rot m = make_rot(e, u);
+            float rx, ry, rz;
+            scatter(m, d, rx, ry, rz);
+            const Hit hit = intersect(pl, o, numer, rx, ry, rz);
+            const float I = ((hit.I0 * 1.0f) * pl.k_ext) * pl.k_refl;   // (1 - blocked) == 1
+            n_on += hit.I0 > 0.0f;
+            n_int += I > 0.0f;
+            const Splat sp = splat_weights(hit.be, hit.bu, a.W, a.Hh);
+            if (sp.on) {
+                const float v1 = sp.cle * sp.chu * I, v2 = sp.che * sp.chu * I;
+                const float v3 = sp.che * sp.clu * I, v4 = sp.cle * sp.clu * I;
+                const int le = sp.ie - win.e0, lu = sp.iu - win.u0;
+                if (le >= 0 && le + 1 < win.tw && lu >= 0 && lu + 1 < win.th) {
+                    float* lo = tile + lu * win.tw + le;     // flat row iu
+                    float* hi = lo + win.tw;                 // flat row iu + 1
+                    atomicAdd(hi, v1); atomicAdd(hi + 1, v2); atomicAdd(lo + 1, v3); atomicAdd(lo, v4);
+                } else {
+                    float* row_hi = bitmap + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;
+                    float* row_lo = row_hi + a.W;
+                    atomicAdd(row_hi, v1); atomicAdd(row_hi + 1, v2); atomicAdd(row_lo + 1, v3); atomicAdd(row_lo, v4);
+                }
+            }
+        }
+    }
+    n_on = wave_sum_u32(n_on);
+    n_int = wave_sum_u32(n_int);
+    if (lane == 0) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_on); }
+    __syncthreads();
+
+    // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
+    for (int row = wave; row < win.th; row += nwaves) {
+        float* g = bitmap + (int64_t)(a.Hh - 1 - (win.u0 + row)) * a.W + win.e0;
+        const float* trow = tile + row * win.tw;
+        for (int c = lane; c < win.tw; c += 64) {
+            const float v = trow[c];
+            if (v != 0.0f) atomicAdd(g + c, v);
+        }
+    }
+    if (tid < 2 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
 // counts (uint32, rows 0,1 of factors) -> fractions (heliostat_ray_tracer.py:498-506).
@@ -268,6 +447,39 @@ static bool interleaved_layout(const TraceArgs& a)
            (reinterpret_cast<uintptr_t>(a.dist_u) % 8) == 0;
 }
 
+// Launch geometry of the forward kernel.  Defaults are the tuned MI355X values; the environment
+// overrides exist for A/B measurements only (ARTIST_HIP_FWD=global selects the plain global-atomic
+// kernel, ARTIST_HIP_FWD_BLOCK / _TILE_KB / _BLOCKS / _MINCHUNK the geometry).
+struct FwdConfig {
+    int variant;        // 0 = LDS window, 1 = global atomics
+    int block;          // threads per workgroup
+    int tile_cap;       // window capacity in pixels
+    int target_blocks;  // grid size to aim for when chunking samples
+    int min_chunk;      // fewest samples per workgroup worth a window build + flush
+};
+
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static FwdConfig fwd_config()
+{
+    FwdConfig c;
+    const char* v = getenv("ARTIST_HIP_FWD");
+    c.variant = (v && v[0] == 'g') ? 1 : 0;
+    c.block = env_int("ARTIST_HIP_FWD_BLOCK", 1024);
+    if (c.block < 64 || c.block > 1024 || (c.block % 64) != 0) c.block = 1024;
+    int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 144);
+    if (kb < 4) kb = 4;
+    if (kb > 156) kb = 156;
+    c.tile_cap = kb * 256;
+    c.target_blocks = env_int("ARTIST_HIP_FWD_BLOCKS", 512);
+    c.min_chunk = env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
+    return c;
+}
+
 }  // namespace art
 
 using namespace art;
@@ -290,14 +502,46 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * n_maps * Hh * W, stream));
     if (H == 0) return ART_OK;
     ART_HIP(hipMemsetAsync(factors, 0, sizeof(float) * 3 * H, stream));
-    choose_chunks(a, 4096, 8);
-    const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
-    if (blocks > 2147483647LL) return ART_EINVAL;
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
-    if (interleaved_layout(a))
-        hipLaunchKernelGGL(trace_fwd_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, flux, counts);
-    else
-        hipLaunchKernelGGL(trace_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, flux, counts);
+    const FwdConfig cfg = fwd_config();
+    if (cfg.variant == 0) {
+        // LDS-window kernel.  p_block: a multiple of the block size close to P / ceil(P / 2048) so that
+        // point blocks are balanced; samples are chunked only as far as needed to fill the chip.
+        const int bs = cfg.block;
+        int nblk = (int)((P + 2047) / 2048);
+        int pb = (int)(((P + nblk - 1) / nblk + bs - 1) / bs * bs);
+        a.p_block = pb;
+        a.n_pblocks = (int)((P + pb - 1) / pb);
+        a.tile_cap = cfg.tile_cap;
+        const int64_t base = (int64_t)a.H * a.n_pblocks;
+        int64_t want = (cfg.target_blocks + base - 1) / base;
+        if (want < 1) want = 1;
+        int chunk = (int)((a.R + want - 1) / want);
+        if (chunk < cfg.min_chunk) chunk = cfg.min_chunk;
+        if (chunk > a.R) chunk = a.R;
+        a.r_chunk = chunk;
+        a.n_rchunks = (a.R + chunk - 1) / chunk;
+        const int64_t blocks = base * a.n_rchunks;
+        if (blocks > 2147483647LL) return ART_EINVAL;
+        const size_t lds = (size_t)a.tile_cap * sizeof(float);
+        if (interleaved_layout(a)) {
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(trace_fwd_lds_kernel<true>, dim3((unsigned)blocks), dim3(bs), lds, stream, a, flux, counts);
+        } else {
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(trace_fwd_lds_kernel<false>, dim3((unsigned)blocks), dim3(bs), lds, stream, a, flux, counts);
+        }
+    } else {
+        choose_chunks(a, 4096, 8);
+        const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
+        if (blocks > 2147483647LL) return ART_EINVAL;
+        if (interleaved_layout(a))
+            hipLaunchKernelGGL(trace_fwd_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, flux, counts);
+        else
+            hipLaunchKernelGGL(trace_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, flux, counts);
+    }
     ART_HIP(hipGetLastError());
     hipLaunchKernelGGL(finalize_factors_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, factors,
                        (int)H, (float)(R * P));

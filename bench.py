@@ -134,7 +134,7 @@ def main():
     T = planar.centers.shape[0]
     # distortions for the owned rows only: ONE interleaved [H,R,P,2] buffer, (u,e) = stride-2 views
     g = torch.Generator(device=dev).manual_seed(7 + rank)
-    both = torch.randn((H, R, P, 2), generator=g, device=dev, dtype=torch.float32) * (4.3681e-06 ** 0.5)
+    both = torch.randn((H, R, P, 2), generator=g, device=dev, dtype=torch.float32).mul_(4.3681e-06 ** 0.5)
     dist_u, dist_e = both[..., 0], both[..., 1]
 
     from artist_amd import ops

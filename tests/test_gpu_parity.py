@@ -271,3 +271,55 @@ def test_error_behaviour(field):
         trace_rays(*cpu)
     with pytest.raises(ValueError, match="must have the same shape"):   # artist/geometry/transforms.py:47-50
         trace_rays(*[c.to(DEV) for c in cpu[:4]], torch.zeros(1, 3, 4, device=DEV), *[c.to(DEV) for c in cpu[5:]])
+
+
+# ---- kernel-variant / rare-branch coverage --------------------------------------------------------------
+@pytest.mark.parametrize("env", [
+    {},                                                     # production geometry
+    {"ARTIST_HIP_FWD": "global"},                           # plain global-atomic kernel
+    {"ARTIST_HIP_FWD_TILE_KB": "4"},                        # window overflow -> centre in LDS, tails global
+    {"ARTIST_HIP_FWD_BLOCK": "256", "ARTIST_HIP_FWD_TILE_KB": "36", "ARTIST_HIP_FWD_BLOCKS": "4096",
+     "ARTIST_HIP_FWD_MINCHUNK": "1"},                       # many small workgroups, 1-sample chunks
+])
+def test_forward_variants_agree(golden, monkeypatch, env):
+    """Every launch geometry of the forward kernel must give the same bitmap (the LDS window is a pure
+    performance device: rays outside it take the global-atomic path)."""
+    from artist_amd import trace_rays
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in ("mid_256", "small_deg2_tilted", "small_offtarget"):
+        d = golden(name)
+        flux, fac = trace_rays(**trace_inputs(d))
+        o_flux, o_fac = oracle_fwd(d)
+        assert rel_l2(n(flux), o_flux) < 2e-4, (name, env, rel_l2(n(flux), o_flux))
+        np.testing.assert_array_equal(n(fac), o_fac)
+
+
+def test_large_scatter_angles_take_the_full_range_path():
+    """|angle| > 2^-3 rad leaves the small-angle sin/cos kernel (ray_math.hpp: sincos_angle); force it with a
+    0.3 rad sun shape so that most rays use the OCML branch, and compare with the oracle ray by ray via the
+    bitmap (64x64 on a 400 m x 400 m target so that widely scattered rays still land)."""
+    from artist_amd import trace_rays
+    g = torch.Generator().manual_seed(11)
+    H, R, P = 2, 16, 600
+    origins = torch.cat([torch.rand(H, P, 3, generator=g) * 2 - 1 + torch.tensor([0.0, 80.0, 0.0]), torch.ones(H, P, 1)], -1)
+    nrm = torch.nn.functional.normalize(torch.tensor([0.0, -0.8, 0.6]) + 0.01 * torch.randn(H, P, 3, generator=g), dim=-1)
+    normals = torch.cat([nrm, torch.zeros(H, P, 1)], -1)
+    incident = torch.tensor([[0.0, 1.0, 0.0, 0.0]]).repeat(H, 1)
+    both = 0.3 * torch.randn(H, R, P, 2, generator=g)
+    both[0, 0, :10] = 0.0                                    # a few exact-zero and threshold angles
+    both[0, 1, :10, 0] = 0.125
+    both[0, 1, :10, 1] = -0.125
+    centers = torch.tensor([[0.0, 0.0, 60.0, 1.0]])
+    pn = torch.tensor([[0.0, 1.0, 0.0, 0.0]])
+    dims = torch.tensor([[400.0, 400.0]])
+    tix = torch.zeros(H, dtype=torch.long)
+    bd = both.to(DEV)
+    flux, fac = trace_rays(origins.to(DEV), normals.to(DEV), incident.to(DEV), bd[..., 0], bd[..., 1], tix.to(DEV),
+                           centers.to(DEV), pn.to(DEV), dims.to(DEV), resolution=(64, 64))
+    assert float((both.abs() > 0.125).float().mean()) > 0.5
+    o_flux, o_fac = oracle.trace_fwd(origins.numpy(), normals.numpy(), incident.numpy(), both[..., 0].numpy(),
+                                     both[..., 1].numpy(), tix.numpy(), centers.numpy(), pn.numpy(), dims.numpy(), (64, 64))
+    assert o_fac[0].min() > 0.2                              # plenty of rays land
+    assert rel_l2(n(flux), o_flux) < 1e-5, rel_l2(n(flux), o_flux)
+    np.testing.assert_array_equal(n(fac), o_fac)
