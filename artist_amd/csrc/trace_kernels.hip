@@ -125,9 +125,20 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
 // A workgroup owns a block of `p_block` consecutive surface points of one heliostat and a chunk
 // of its distortion samples.  Rays of neighbouring mirror points land within a few pixels of each
 // other (plus the sun-shape blur), so the workgroup's footprint on the receiver is a small window
-// of the bitmap: it is accumulated in LDS with ds_add_f32 and flushed ONCE with row-contiguous
-// global atomics (one per touched pixel instead of four per ray - global float atomics execute at
-// the memory side at ~2e10 scattered lanes/s and bound the kernel otherwise).
+// of the bitmap: it is accumulated in LDS and flushed ONCE with row-contiguous global atomics (one
+// per touched pixel instead of four per ray - global float atomics execute at the memory side at
+// ~2e10 scattered lanes/s and bound the kernel otherwise).
+//
+// The LDS accumulator is 32-bit FIXED POINT with carry-out, not float: measured on gfx950
+// (tools/lds_atomic_bench.hip) ds_add_f32 retires one lane every ~3 cycles (193 cycles per wave
+// instruction, for any address pattern) whereas ds_add_rtn_u32 takes ~12 cycles per wave instruction
+// on random addresses.  All contributions of one launch have the sign of mag*k_ext*k_refl, so |v| is
+// scaled by a power of two S chosen per workgroup such that |v| S < 2^22, rounded to an integer
+// (quantum 2^-22 of the largest possible contribution; the rounding errors are independent and
+// average out over the rays that share a pixel) and added exactly.  When a 32-bit cell wraps, the
+// returning atomic shows it and 2^32/S goes straight to the global pixel; the cell residue follows
+// at the flush.  The window sum is therefore independent of the order of the adds.  4-byte cells
+// give a 36 864-pixel window in 144 KB, which the oblique near-field heliostats need.
 //
 //   phase 1  window:  chief rays (no scatter) of the block's points -> bounding box in pixels,
 //                     padded by the largest scatter angle seen in the block's first sample x the
@@ -136,10 +147,13 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
 //   phase 2  trace:   thread <-> point, loop over the chunk's samples, 4 LDS adds per ray.
 //   phase 3  flush:   window rows -> global bitmap (up-down flipped).
 //
-// grid.x = H * n_pblocks * n_rchunks ; block = any multiple of 64 ; dynamic LDS = tile_cap floats.
+// grid.x = H * n_pblocks * n_rchunks ; block = any multiple of 64 ; dynamic LDS = 4 B * tile_cap.
 // --------------------------------------------------------------------------------------------
 struct Window {
     int e0, u0, tw, th;   // origin (un-flipped flat coordinates) and size; tw*th <= tile_cap
+    float scale;          // S  (power of two)
+    float inv_scale;      // sign / S           (sign of mag*k_ext*k_refl)
+    float carry;          // sign * 2^32 / S    (value of one cell wrap)
 };
 
 __device__ __forceinline__ float wave_min_f32(float v)
@@ -155,12 +169,108 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return v;
 }
 
+// round-half-up float -> int32 in one instruction (floor(x + 0.5)); 0 <= x < 2^22 by construction.
+__device__ __forceinline__ unsigned cvt_nearest_u32(float x)
+{
+    int q;
+    asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(q) : "v"(x));
+    return (unsigned)q;
+}
+
+// cell += round(|v| S); on wrap-around push one carry to the global pixel `g`.
+__device__ __forceinline__ void lds_add_fixed(unsigned* cell, float v, const float scale, const float carry, float* g)
+{
+    const unsigned q = cvt_nearest_u32(fabsf(v) * scale);
+    const unsigned old = atomicAdd(cell, q);        // ds_add_rtn_u32
+    if (__builtin_expect(old + q < old, 0)) atomicAdd(g, carry);
+}
+
+// Phase 1 of the windowed kernels: bounding box (in un-flipped bitmap coordinates) of where the
+// workgroup's rays can land, clipped to `tile_cap` pixels, plus the fixed-point scale of the forward
+// accumulator.  Result is left in *s_win after a __syncthreads().
+template <bool INTERLEAVED>
+__device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& pl, const float4 inc,
+                                               const float4* __restrict__ org, const float4* __restrict__ nrm,
+                                               int p0, int p1, int64_t dbase, float (*s_red)[16], Window* s_win)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    // ke / ku: metres of hit-point travel along world E / U per radian of scatter, |t| sqrt(1 + (r_E/a)^2):
+    // the footprint of an oblique beam is stretched by the obliquity along the projection of the ray only.
+    float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, ke = 0.0f, ku = 0.0f, angmax = 0.0f;
+    float dmax2 = 0.0f;
+    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+        const float4 o = org[p];
+        const float4 n = nrm[p];
+        float4 d; float s;
+        reflect(inc, n, d, s);
+        dmax2 = fmaxf(dmax2, d.x * d.x + d.y * d.y + d.z * d.z);
+        const float numer = plane_numer(pl, o);
+        const Hit hit = intersect(pl, o, numer, d.x, d.y, d.z);
+        if (hit.valid) {
+            emin = fminf(emin, hit.be); emax = fmaxf(emax, hit.be);
+            umin = fminf(umin, hit.bu); umax = fmaxf(umax, hit.bu);
+            const float ia = 1.0f / hit.a, qe = d.x * ia, qu = d.z * ia;
+            ke = fmaxf(ke, hit.t * sqrtf(1.0f + qe * qe));
+            ku = fmaxf(ku, hit.t * sqrtf(1.0f + qu * qu));
+        }
+        float u, e;
+        load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e);
+        angmax = fmaxf(angmax, fmaxf(fabsf(u), fabsf(e)));
+    }
+    emin = wave_min_f32(emin); emax = wave_max_f32(emax); umin = wave_min_f32(umin); umax = wave_max_f32(umax);
+    ke = wave_max_f32(ke); ku = wave_max_f32(ku); angmax = wave_max_f32(angmax); dmax2 = wave_max_f32(dmax2);
+    if (lane == 0) {
+        s_red[0][wave] = emin; s_red[1][wave] = emax; s_red[2][wave] = umin; s_red[3][wave] = umax;
+        s_red[4][wave] = ke; s_red[5][wave] = ku; s_red[6][wave] = angmax; s_red[7][wave] = dmax2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < nwaves; ++w) {
+            emin = fminf(emin, s_red[0][w]); emax = fmaxf(emax, s_red[1][w]);
+            umin = fminf(umin, s_red[2][w]); umax = fmaxf(umax, s_red[3][w]);
+            ke = fmaxf(ke, s_red[4][w]); ku = fmaxf(ku, s_red[5][w]); angmax = fmaxf(angmax, s_red[6][w]);
+            dmax2 = fmaxf(dmax2, s_red[7][w]);
+        }
+        Window win = {0, 0, 0, 0, 1.0f, 1.0f, 0.0f};
+        if (emax >= emin) {
+            // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
+            // worth keeping in the window (~4.2 sigma); +2 px for the bilinear footprint and rounding.
+            const float pad_e = fminf(1.15f * angmax * ke * (pl.wm1 / fabsf(pl.w)) + 2.0f, 32768.0f);
+            const float pad_u = fminf(1.15f * angmax * ku * (pl.hm1 / fabsf(pl.h)) + 2.0f, 32768.0f);
+            int e0 = max((int)emin - (int)pad_e, 0), e1 = min((int)emax + 1 + (int)pad_e, a.W - 1);
+            int u0 = max((int)umin - (int)pad_u, 0), u1 = min((int)umax + 1 + (int)pad_u, a.Hh - 1);
+            int tw = e1 - e0 + 1, th = u1 - u0 + 1;
+            if ((int64_t)tw * th > a.tile_cap) {   // keep the centre, let the tails use global memory
+                const float sc = sqrtf((float)a.tile_cap / ((float)tw * (float)th));
+                const int tw2 = max(2, min(tw, (int)((float)tw * sc)));
+                const int th2 = max(2, min(th, a.tile_cap / tw2));
+                e0 += (tw - tw2) / 2; u0 += (th - th2) / 2; tw = tw2; th = th2;
+            }
+            win.e0 = e0; win.u0 = u0; win.tw = tw; win.th = th;
+            // |contribution| <= |I| = |mag k_ext k_refl| |r.m| <= |mag k_ext k_refl| |d| |m| (the scatter
+            // matrix is a rotation); 2^ex > bound, so |v| * 2^(22-ex) < 2^22.
+            const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
+            const float mnorm = sqrtf(pl.mx * pl.mx + pl.my * pl.my + pl.mz * pl.mz);
+            const float bound = fabsf(kI) * sqrtf(dmax2) * mnorm * 1.001f;
+            int ex = 0;
+            if (bound > 0.0f && bound < 3.0e38f) (void)frexpf(bound, &ex);
+            ex = min(max(ex, -90), 90);
+            const float sgn = kI < 0.0f ? -1.0f : 1.0f;
+            win.scale = ldexpf(1.0f, 22 - ex);
+            win.inv_scale = sgn * ldexpf(1.0f, ex - 22);
+            win.carry = sgn * ldexpf(1.0f, ex + 10);
+        }
+        *s_win = win;
+    }
+    __syncthreads();
+}
+
 template <bool INTERLEAVED>
 __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float* __restrict__ flux,
                                                              unsigned int* __restrict__ counts)
 {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    __shared__ float s_red[7][16];     // per-wave partials: emin, emax, umin, umax, tmax, amin, angmax
+    extern __shared__ __attribute__((aligned(16))) unsigned tile[];
+    __shared__ float s_red[8][16];     // per-wave partials: emin, emax, umin, umax, ke, ku, angmax, dmax2
     __shared__ Window s_win;
     __shared__ unsigned s_cnt[2];
 
@@ -183,61 +293,11 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
     // ---- phase 1: window ---------------------------------------------------------------------
-    float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, tmax = 0.0f, amin = 1.0f, angmax = 0.0f;
-    for (int p = p0 + tid; p < p1; p += blockDim.x) {
-        const float4 o = org[p];
-        const float4 n = nrm[p];
-        float4 d; float s;
-        reflect(inc, n, d, s);
-        const float numer = plane_numer(pl, o);
-        const Hit hit = intersect(pl, o, numer, d.x, d.y, d.z);
-        if (hit.valid) {
-            emin = fminf(emin, hit.be); emax = fmaxf(emax, hit.be);
-            umin = fminf(umin, hit.bu); umax = fmaxf(umax, hit.bu);
-            tmax = fmaxf(tmax, hit.t); amin = fminf(amin, -hit.a);
-        }
-        float u, e;
-        load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e);
-        angmax = fmaxf(angmax, fmaxf(fabsf(u), fabsf(e)));
-    }
-    emin = wave_min_f32(emin); emax = wave_max_f32(emax); umin = wave_min_f32(umin); umax = wave_max_f32(umax);
-    tmax = wave_max_f32(tmax); amin = wave_min_f32(amin); angmax = wave_max_f32(angmax);
-    if (lane == 0) {
-        s_red[0][wave] = emin; s_red[1][wave] = emax; s_red[2][wave] = umin; s_red[3][wave] = umax;
-        s_red[4][wave] = tmax; s_red[5][wave] = amin; s_red[6][wave] = angmax;
-    }
     if (tid < 2) s_cnt[tid] = 0;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < nwaves; ++w) {
-            emin = fminf(emin, s_red[0][w]); emax = fmaxf(emax, s_red[1][w]);
-            umin = fminf(umin, s_red[2][w]); umax = fmaxf(umax, s_red[3][w]);
-            tmax = fmaxf(tmax, s_red[4][w]); amin = fminf(amin, s_red[5][w]); angmax = fmaxf(angmax, s_red[6][w]);
-        }
-        Window win = {0, 0, 0, 0};
-        if (emax >= emin) {
-            // pixels per metre along e / u, path length, obliquity; x1.3 because the first sample's extreme
-            // (~3.7 sigma of p_block draws) is below the extreme over all samples (~4.8 sigma).
-            const float ppm = fmaxf(pl.wm1 / pl.w, pl.hm1 / pl.h);
-            const float padf = 1.3f * angmax * tmax * ppm / fmaxf(amin, 0.05f) + 2.0f;
-            const int pad = (int)fminf(padf, 32768.0f);
-            int e0 = max((int)emin - pad, 0), e1 = min((int)emax + 1 + pad, a.W - 1);
-            int u0 = max((int)umin - pad, 0), u1 = min((int)umax + 1 + pad, a.Hh - 1);
-            int tw = e1 - e0 + 1, th = u1 - u0 + 1;
-            if ((int64_t)tw * th > a.tile_cap) {   // keep the centre, let the tails use global atomics
-                const float sc = sqrtf((float)a.tile_cap / ((float)tw * (float)th));
-                const int tw2 = max(2, min(tw, (int)((float)tw * sc)));
-                const int th2 = max(2, min(th, a.tile_cap / tw2));
-                e0 += (tw - tw2) / 2; u0 += (th - th2) / 2; tw = tw2; th = th2;
-            }
-            win.e0 = e0; win.u0 = u0; win.tw = tw; win.th = th;
-        }
-        s_win = win;
-    }
-    __syncthreads();
+    compute_window<INTERLEAVED>(a, pl, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
     const int npx = win.tw * win.th;
-    for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0.0f;
+    for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
     __syncthreads();
 
     // ---- phase 2: trace ----------------------------------------------------------------------
@@ -249,7 +309,6 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
         int64_t off = dbase + (int64_t)p * a.sp;
-#pragma unroll 2
         for (int r = r0; r < r1; ++r, off += a.sr) {
             float u, e;
             load_dist<INTERLEAVED>(a, off, u, e);
@@ -265,13 +324,16 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
                 const float v1 = sp.cle * sp.chu * I, v2 = sp.che * sp.chu * I;
                 const float v3 = sp.che * sp.clu * I, v4 = sp.cle * sp.clu * I;
                 const int le = sp.ie - win.e0, lu = sp.iu - win.u0;
+                float* row_hi = bitmap + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;   // flat row iu + 1
+                float* row_lo = row_hi + a.W;                                          // flat row iu
                 if (le >= 0 && le + 1 < win.tw && lu >= 0 && lu + 1 < win.th) {
-                    float* lo = tile + lu * win.tw + le;     // flat row iu
-                    float* hi = lo + win.tw;                 // flat row iu + 1
-                    atomicAdd(hi, v1); atomicAdd(hi + 1, v2); atomicAdd(lo + 1, v3); atomicAdd(lo, v4);
+                    unsigned* lo = tile + lu * win.tw + le;
+                    unsigned* hi = lo + win.tw;
+                    lds_add_fixed(hi, v1, win.scale, win.carry, row_hi);
+                    lds_add_fixed(hi + 1, v2, win.scale, win.carry, row_hi + 1);
+                    lds_add_fixed(lo + 1, v3, win.scale, win.carry, row_lo + 1);
+                    lds_add_fixed(lo, v4, win.scale, win.carry, row_lo);
                 } else {
-                    float* row_hi = bitmap + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;
-                    float* row_lo = row_hi + a.W;
                     atomicAdd(row_hi, v1); atomicAdd(row_hi + 1, v2); atomicAdd(row_lo + 1, v3); atomicAdd(row_lo, v4);
                 }
             }
@@ -285,10 +347,10 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
     for (int row = wave; row < win.th; row += nwaves) {
         float* g = bitmap + (int64_t)(a.Hh - 1 - (win.u0 + row)) * a.W + win.e0;
-        const float* trow = tile + row * win.tw;
+        const unsigned* trow = tile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) {
-            const float v = trow[c];
-            if (v != 0.0f) atomicAdd(g + c, v);
+            const unsigned q = trow[c];
+            if (q != 0u) atomicAdd(g + c, (float)q * win.inv_scale);
         }
     }
     if (tid < 2 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
@@ -391,6 +453,118 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// Backward, LDS-staged gradient window (the production kernel).  Same decomposition as the forward:
+// a workgroup owns `p_block` points x a chunk of samples; the part of dL/dflux its rays can touch is
+// copied once into LDS (row-contiguous loads) and the four per-ray gathers become LDS reads; rays
+// outside the window read global memory.  Gradients are accumulated per point in registers.
+// --------------------------------------------------------------------------------------------
+template <bool INTERLEAVED, bool ATOMIC_OUT>
+__global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
+                                                             float4* __restrict__ grad_origins,
+                                                             float4* __restrict__ grad_normals)
+{
+    extern __shared__ __attribute__((aligned(16))) float gtile[];
+    __shared__ float s_red[8][16];
+    __shared__ Window s_win;
+
+    const int bid = blockIdx.x;
+    const int rchunk = bid % a.n_rchunks;
+    const int pblock = (bid / a.n_rchunks) % a.n_pblocks;
+    const int h = bid / (a.n_rchunks * a.n_pblocks);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+
+    const int t = a.target_idx[h];
+    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
+    const float4 inc = a.incident[h];
+    const int p0 = pblock * a.p_block;
+    const int p1 = min(p0 + a.p_block, a.P);
+    const int r0 = rchunk * a.r_chunk;
+    const int r1 = min(r0 + a.r_chunk, a.R);
+    const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
+    const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
+    const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
+
+    compute_window<INTERLEAVED>(a, pl, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
+    const Window win = s_win;
+    // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped
+    for (int row = wave; row < win.th; row += nwaves) {
+        const float* g = G + (int64_t)(a.Hh - 1 - (win.u0 + row)) * a.W + win.e0;
+        float* trow = gtile + row * win.tw;
+        for (int c = lane; c < win.tw; c += 64) trow[c] = g[c];
+    }
+    __syncthreads();
+
+    const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
+    const float sx = pl.wm1 / pl.w, sz = pl.hm1 / pl.h;
+    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+        const float4 o = org[p];
+        const float4 n = nrm[p];
+        float4 d; float s;
+        reflect(inc, n, d, s);
+        const float numer = plane_numer(pl, o);
+        float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;
+        int64_t off = dbase + (int64_t)p * a.sp;
+        for (int r = r0; r < r1; ++r, off += a.sr) {
+            float u, e;
+            load_dist<INTERLEAVED>(a, off, u, e);
+            const Rot m = make_rot(e, u);
+            float rx, ry, rz;
+            scatter(m, d, rx, ry, rz);
+            const Hit hit = intersect(pl, o, numer, rx, ry, rz);
+            if (!hit.valid) continue;
+            const Splat sp = splat_weights(hit.be, hit.bu, a.W, a.Hh);
+            if (!sp.on) continue;
+            const float I = (hit.I0 * pl.k_ext) * pl.k_refl;
+            float g1, g2, g3, g4;
+            const int le = sp.ie - win.e0, lu = sp.iu - win.u0;
+            if (le >= 0 && le + 1 < win.tw && lu >= 0 && lu + 1 < win.th) {
+                const float* lo = gtile + lu * win.tw + le;
+                const float* hi = lo + win.tw;
+                g1 = hi[0]; g2 = hi[1]; g3 = lo[1]; g4 = lo[0];
+            } else {
+                const float* g_hi = G + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;
+                const float* g_lo = g_hi + a.W;
+                g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
+            }
+            const float gI = sp.cle * sp.chu * g1 + sp.che * sp.chu * g2 + sp.che * sp.clu * g3 + sp.cle * sp.clu * g4;
+            const float g_be = ((sp.chu * g2 + sp.clu * g3) - (sp.chu * g1 + sp.clu * g4)) * I;
+            const float g_bu = ((sp.cle * g1 + sp.che * g2) - (sp.che * g3 + sp.cle * g4)) * I;
+            const float g_hx = -g_be * sx;          // be = wm1 - te / w * wm1
+            const float g_hz = g_bu * sz;
+            const float g_t = g_hx * rx + g_hz * rz;
+            const float inv_a = 1.0f / hit.a;
+            const float tt = numer * inv_a;          // t = numer / a (front facing)
+            const float g_a = -kI * gI - g_t * tt * inv_a;
+            const float g_numer = g_t * inv_a;
+            const float grx = g_hx * tt + g_a * pl.mx;
+            const float gry = g_a * pl.my;
+            const float grz = g_hz * tt + g_a * pl.mz;
+            gox += g_hx - g_numer * pl.mx;
+            goy += -g_numer * pl.my;
+            goz += g_hz - g_numer * pl.mz;
+            gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
+            gdy += -m.su * grx + m.m11 * gry + m.m21 * grz;
+            gdz += -m.se * gry + m.ce * grz;
+        }
+        const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
+        const float4 go = make_float4(gox, goy, goz, 0.0f);
+        const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
+                                      -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
+        const int64_t idx = (int64_t)h * a.P + p;
+        if constexpr (ATOMIC_OUT) {
+            float* po = reinterpret_cast<float*>(grad_origins + idx);
+            float* pn = reinterpret_cast<float*>(grad_normals + idx);
+            atomicAdd(po + 0, go.x); atomicAdd(po + 1, go.y); atomicAdd(po + 2, go.z);
+            atomicAdd(pn + 0, gn.x); atomicAdd(pn + 1, gn.y); atomicAdd(pn + 2, gn.z); atomicAdd(pn + 3, gn.w);
+        } else {
+            grad_origins[idx] = go;
+            grad_normals[idx] = gn;
+        }
+    }
+}
+
 // out[t] = sum_h [target_idx[h] == t] bitmaps[h]   (heliostat_ray_tracer.py:593-608)
 // One thread per (t, pixel); heliostats summed in index order (deterministic).
 __global__ void per_target_sum_kernel(const float* __restrict__ bitmaps, const int32_t* __restrict__ target_idx,
@@ -456,6 +630,7 @@ struct FwdConfig {
     int tile_cap;       // window capacity in pixels
     int target_blocks;  // grid size to aim for when chunking samples
     int min_chunk;      // fewest samples per workgroup worth a window build + flush
+    int p_block;        // target points per workgroup
 };
 
 static int env_int(const char* name, int dflt)
@@ -474,10 +649,33 @@ static FwdConfig fwd_config()
     int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 144);
     if (kb < 4) kb = 4;
     if (kb > 156) kb = 156;
-    c.tile_cap = kb * 256;
+    c.tile_cap = kb * 256;   // 4-byte fixed-point cells
     c.target_blocks = env_int("ARTIST_HIP_FWD_BLOCKS", 512);
     c.min_chunk = env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
+    c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 2048);
+    if (c.p_block < 64) c.p_block = 64;
     return c;
+}
+
+// Launch geometry of the windowed kernels.  p_block: a multiple of the block size close to
+// P / ceil(P / 2048) so that point blocks are balanced; samples are chunked only as far as needed to
+// fill the chip (each chunk pays a window build + flush).
+static void window_geometry(TraceArgs& a, const FwdConfig& cfg)
+{
+    const int bs = cfg.block;
+    const int nblk = (a.P + cfg.p_block - 1) / cfg.p_block;
+    const int pb = ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
+    a.p_block = pb;
+    a.n_pblocks = (a.P + pb - 1) / pb;
+    a.tile_cap = cfg.tile_cap;
+    const int64_t base = (int64_t)a.H * a.n_pblocks;
+    int64_t want = (cfg.target_blocks + base - 1) / base;
+    if (want < 1) want = 1;
+    int chunk = (int)((a.R + want - 1) / want);
+    if (chunk < cfg.min_chunk) chunk = cfg.min_chunk;
+    if (chunk > a.R) chunk = a.R;
+    a.r_chunk = chunk;
+    a.n_rchunks = (a.R + chunk - 1) / chunk;
 }
 
 }  // namespace art
@@ -505,33 +703,19 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
     const FwdConfig cfg = fwd_config();
     if (cfg.variant == 0) {
-        // LDS-window kernel.  p_block: a multiple of the block size close to P / ceil(P / 2048) so that
-        // point blocks are balanced; samples are chunked only as far as needed to fill the chip.
-        const int bs = cfg.block;
-        int nblk = (int)((P + 2047) / 2048);
-        int pb = (int)(((P + nblk - 1) / nblk + bs - 1) / bs * bs);
-        a.p_block = pb;
-        a.n_pblocks = (int)((P + pb - 1) / pb);
-        a.tile_cap = cfg.tile_cap;
+        window_geometry(a, cfg);
         const int64_t base = (int64_t)a.H * a.n_pblocks;
-        int64_t want = (cfg.target_blocks + base - 1) / base;
-        if (want < 1) want = 1;
-        int chunk = (int)((a.R + want - 1) / want);
-        if (chunk < cfg.min_chunk) chunk = cfg.min_chunk;
-        if (chunk > a.R) chunk = a.R;
-        a.r_chunk = chunk;
-        a.n_rchunks = (a.R + chunk - 1) / chunk;
         const int64_t blocks = base * a.n_rchunks;
         if (blocks > 2147483647LL) return ART_EINVAL;
-        const size_t lds = (size_t)a.tile_cap * sizeof(float);
+        const size_t lds = (size_t)a.tile_cap * sizeof(unsigned);
         if (interleaved_layout(a)) {
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(trace_fwd_lds_kernel<true>, dim3((unsigned)blocks), dim3(bs), lds, stream, a, flux, counts);
+            hipLaunchKernelGGL(trace_fwd_lds_kernel<true>, dim3((unsigned)blocks), dim3(cfg.block), lds, stream, a, flux, counts);
         } else {
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(trace_fwd_lds_kernel<false>, dim3((unsigned)blocks), dim3(bs), lds, stream, a, flux, counts);
+            hipLaunchKernelGGL(trace_fwd_lds_kernel<false>, dim3((unsigned)blocks), dim3(cfg.block), lds, stream, a, flux, counts);
         }
     } else {
         choose_chunks(a, 4096, 8);
@@ -565,12 +749,38 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                    Hh, mode))
         return ART_EINVAL;
     if (H == 0) return ART_OK;
-    choose_chunks(a, 2048, 16);
-    const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
-    if (blocks > 2147483647LL) return ART_EINVAL;
     float4* go = reinterpret_cast<float4*>(grad_origins);
     float4* gn = reinterpret_cast<float4*>(grad_normals);
     const bool il = interleaved_layout(a);
+    const FwdConfig cfg = fwd_config();
+    if (cfg.variant == 0) {
+        window_geometry(a, cfg);
+        const int64_t blocks = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
+        if (blocks > 2147483647LL) return ART_EINVAL;
+        const size_t lds = (size_t)a.tile_cap * sizeof(float);
+        const bool atomic_out = a.n_rchunks > 1;
+        if (atomic_out) {
+            ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
+            ART_HIP(hipMemsetAsync(grad_normals, 0, sizeof(float) * 4 * H * P, stream));
+        }
+#define ART_LAUNCH_BWD(IL, AT)                                                                                   \
+        do {                                                                                                     \
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT>),            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT>), dim3((unsigned)blocks), dim3(cfg.block), lds,     \
+                               stream, a, grad_flux, go, gn);                                                    \
+        } while (0)
+        if (il && atomic_out) ART_LAUNCH_BWD(true, true);
+        else if (il) ART_LAUNCH_BWD(true, false);
+        else if (atomic_out) ART_LAUNCH_BWD(false, true);
+        else ART_LAUNCH_BWD(false, false);
+#undef ART_LAUNCH_BWD
+        ART_HIP(hipGetLastError());
+        return ART_OK;
+    }
+    choose_chunks(a, 2048, 16);
+    const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
+    if (blocks > 2147483647LL) return ART_EINVAL;
     if (a.n_rchunks > 1) {
         ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
         ART_HIP(hipMemsetAsync(grad_normals, 0, sizeof(float) * 4 * H * P, stream));
