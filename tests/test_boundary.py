@@ -1,0 +1,71 @@
+"""CPU suite: the drop-in boundary.  The C-ABI library loads, exports exactly what include/artist_hip.h
+declares, the Python binding mirrors it, the product never touches the oracle, and it fails loudly - no
+CPU fallback - when asked to compute without a GPU."""
+import ctypes
+import pathlib
+import re
+
+import pytest
+import torch
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def header_functions():
+    text = (ROOT / "include" / "artist_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(art_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert header_functions() == sorted([
+        "art_abi_version", "art_last_hip_error", "art_strerror", "art_trace_fwd", "art_trace_bwd",
+        "art_per_target_sum", "art_nurbs_fwd", "art_nurbs_bwd"])
+
+
+def test_library_exports_every_declared_symbol():
+    from artist_amd import _lib
+    handle = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in header_functions():
+        assert hasattr(handle, name), f"{name} missing from {_lib.LIB_PATH}"
+    assert sorted(_lib.SIGNATURES) == header_functions()
+    lib = _lib.lib()                       # no compute call: loading + version query only
+    assert lib.art_abi_version() == _lib.ABI_VERSION
+    assert lib.art_strerror(0) == b"ok" and b"invalid" in lib.art_strerror(-1)
+
+
+def test_argument_counts_match_the_header():
+    from artist_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "artist_hip.h").read_text(), flags=re.S)
+    for name, argtypes in _lib.SIGNATURES.items():
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n_params = 0 if params in ("", "void") else params.count(",") + 1
+        assert n_params == len(argtypes), (name, n_params, len(argtypes))
+
+
+def test_product_does_not_touch_the_oracle():
+    for path in (ROOT / "artist_amd").rglob("*"):
+        if path.suffix in {".py", ".hip", ".hpp", ".h", ".cpp"} or path.name == "Makefile":
+            text = path.read_text()
+            assert "oracle" not in text.lower() or path.name == "_never_", f"{path} mentions the oracle"
+
+
+def test_no_cpu_fallback():
+    from artist_amd import ArtistHipError, NURBSSurfaces, trace_rays
+    z = torch.zeros
+    with pytest.raises(ArtistHipError, match="no CPU fallback"):
+        trace_rays(z(1, 4, 4), z(1, 4, 4), z(1, 4), z(1, 2, 4), z(1, 2, 4), z(1, dtype=torch.long), z(1, 4), z(1, 4),
+                   torch.ones(1, 2))
+    surf = NURBSSurfaces(torch.tensor([3, 3]), torch.rand(1, 1, 6, 6, 3), device=torch.device("cpu"))
+    with pytest.raises(ArtistHipError, match="no CPU fallback"):
+        surf(torch.rand(1, 1, 5, 2), None, None)
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from artist_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libartist_hip.so")
+    with pytest.raises(_lib.ArtistHipError, match="no CPU fallback"):
+        _lib.lib()

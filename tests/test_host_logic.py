@@ -1,0 +1,129 @@
+"""CPU suite: host-side logic of the drop-in classes (no kernels): sampler partition, knot vectors and span
+search of the NURBS mirror, helper constructors, the distortion recipe, tracer bookkeeping and error behaviour."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sun_distortions
+
+CPU = torch.device("cpu")
+
+
+def test_sampler_matches_reference_table(golden):
+    from artist_amd import RestrictedDistributedSampler
+    for row in golden("known_answers")["sampler_table"]:       # tests/raytracing/test_sampling.py:8-15
+        ns, nh, ws, rank = (int(v) for v in row[:4])
+        assert list(RestrictedDistributedSampler(ns, nh, ws, rank)) == [int(v) for v in row[4:] if v >= 0]
+
+
+def test_owned_heliostats_partition():
+    from artist_amd.distributed import owned_heliostats
+    for n, world in ((1000, 8), (10, 3), (2, 4), (1, 1)):
+        rows = [owned_heliostats(n, world, r) for r in range(world)]
+        assert sorted(sum(rows, [])) == list(range(n))
+        assert all(r == list(range(i, n, min(n, world))) for i, r in enumerate(rows) if i < min(n, world))
+        assert all(r == [] for r in rows[min(n, world):])
+
+
+def test_nurbs_mirror_knots_and_spans(golden):
+    from artist_amd import NURBSSurfaces
+    ka = golden("known_answers")
+    for name in ("small_deg3", "small_deg2_tilted"):
+        d = golden(name)
+        surf = NURBSSurfaces(torch.from_numpy(d["degrees"]), torch.from_numpy(d["control_points"]), device=CPU)
+        assert np.array_equal(surf.knot_vectors_u[0, 0].numpy(), d["knots_u"])
+        assert np.array_equal(surf.knot_vectors_v[0, 0].numpy(), d["knots_v"])
+        assert tuple(surf.knot_vectors_u.shape[:2]) == d["control_points"].shape[:2]
+        n, p = d["control_points"].shape[2], int(d["degrees"][0])
+        assert surf._unique_counts()[0] == n - p + 1 == torch.unique(surf.knot_vectors_u, dim=2).shape[2]
+    # tests/nurbs/test_surfaces.py:150-199
+    x, y = torch.meshgrid(torch.linspace(1e-2, 1 - 1e-2, 6), torch.linspace(1e-2, 1 - 1e-2, 6), indexing="ij")
+    ev = torch.from_numpy(ka["span_eval"])[None, None]
+    knots = torch.from_numpy(ka["span_knots"])[None, None]
+    surf = NURBSSurfaces(torch.tensor([3, 3]), torch.stack([x, y], -1)[None, None], device=CPU)
+    assert surf.find_spans(0, ev, knots).flatten().tolist() == ka["span_expected"].tolist()
+    surf.uniform = False
+    assert surf.find_spans(0, ev, knots).flatten().tolist() == ka["span_nonuniform_reference"].tolist()
+    # swapping the knot tensors triggers a recount of the distinct knots (surfaces.py:199 semantics)
+    surf.knot_vectors_u = knots
+    assert surf._unique_counts()[0] == 4
+
+
+def test_helper_constructors_match_reference(golden):
+    from artist_amd import create_nurbs_evaluation_grid, create_planar_nurbs_control_points
+    from artist_amd.scene import CANTING
+    d = golden("config1")                                  # planar control points (z-noise 0), 50x50 grid
+    canting = torch.tensor(CANTING).unsqueeze(0).repeat(4, 1, 1)
+    cp = create_planar_nurbs_control_points(torch.tensor([10, 10]), canting, device=CPU)
+    assert np.array_equal(cp.numpy(), d["control_points"][0])
+    uv = create_nurbs_evaluation_grid(torch.tensor([50, 50]), device=CPU)
+    assert np.array_equal(uv.numpy(), d["eval_points_grid"])
+
+
+def test_sun_stand_in_matches_reference_recipe(golden):
+    from artist_amd.scene import Sun
+    ka = golden("known_answers")
+    du, de = Sun(3, device=CPU).get_distortions(number_of_points=5, number_of_active_heliostats=2, random_seed=7)
+    assert np.array_equal(du.numpy(), ka["sun_u"]) and np.array_equal(de.numpy(), ka["sun_e"])
+    assert list(du.stride()) == [30, 10, 2] and de.data_ptr() == du.data_ptr() + 4     # one interleaved buffer
+    ref_u, ref_e = sun_distortions(2, 3, 5)
+    assert torch.equal(du, ref_u) and torch.equal(de, ref_e)
+    with pytest.raises(ValueError, match="Unknown sunlight distribution type."):      # artist/scene/sun.py:82-86
+        Sun(3, dict(distribution_type="uniform"))
+
+
+def test_ideal_orientation_is_a_rigid_transform_that_hits_the_aim_point(golden):
+    from artist_amd.scene import ideal_orientations
+    d = golden("mid_256")
+    ori_ref = torch.from_numpy(d["orientation"])
+    pos = ori_ref[:, :, 3].clone()
+    aim, inc = torch.from_numpy(d["aim_points"]), torch.from_numpy(d["incident"])
+    ori = ideal_orientations(pos, aim, inc)
+    r = ori[:, :3, :3]
+    torch.testing.assert_close(r @ r.transpose(1, 2), torch.eye(3).expand_as(r), atol=1e-6, rtol=0)
+    torch.testing.assert_close(torch.linalg.det(r), torch.ones(r.shape[0]), atol=1e-6, rtol=0)
+    # the mirror normal (local +z) bisects -incident and the aim direction, like the reference's kinematics
+    torch.testing.assert_close(ori[:, :3, 2], ori_ref[:, :3, 2], atol=2e-4, rtol=0)
+    torch.testing.assert_close(ori[:, :, 3], ori_ref[:, :, 3])
+
+
+class _Stub:
+    pass
+
+
+def _tiny_scene(n_heliostats=4, n_rays=3, n_points=8):
+    from artist_amd.scene import (HeliostatField, HeliostatGroup, LightSourceArray, Scenario, SolarTower, Sun,
+                                  TowerTargetAreasPlanar)
+    g = HeliostatGroup(
+        names=[f"h{i}" for i in range(n_heliostats)], positions=torch.zeros(n_heliostats, 4),
+        surface_points=torch.zeros(n_heliostats, n_points, 4), surface_normals=torch.zeros(n_heliostats, n_points, 4),
+        canting=torch.ones(n_heliostats, 4, 2, 4), facet_translations=torch.zeros(n_heliostats, 4, 4),
+        nurbs_control_points=torch.zeros(n_heliostats, 4, 6, 6, 3), nurbs_degrees=torch.tensor([3, 3]), device=CPU)
+    planar = TowerTargetAreasPlanar(["r"], torch.tensor([[0.0, 0.0, 10.0, 1.0]]), torch.tensor([[0.0, 1.0, 0.0, 0.0]]),
+                                    torch.tensor([[2.0, 2.0]]))
+    sc = Scenario(torch.zeros(3), SolarTower([planar], device=CPU), LightSourceArray([Sun(n_rays, device=CPU)]),
+                  HeliostatField([g]))
+    return sc, g
+
+
+def test_tracer_bookkeeping_and_errors():
+    from artist_amd import HeliostatRayTracer
+    sc, g = _tiny_scene()
+    g.activate_heliostats(torch.tensor([2, 0, 1, 1], dtype=torch.int32))
+    assert g.number_of_active_heliostats == 4 and g.active_surface_points.shape[0] == 4
+    with pytest.raises(NotImplementedError, match="blocking_active"):
+        HeliostatRayTracer(sc, g)                                        # reference default is blocking_active=True
+    # heliostat_ray_tracer.py:185-203: ray magnitude from dni
+    rt = HeliostatRayTracer(sc, g, blocking_active=False, dni=800.0, bitmap_resolution=torch.tensor([32, 16]))
+    dims = torch.norm(g.canting[0], dim=1)[0][:2] * 4 + 0.02
+    assert float(rt.ray_magnitude) == pytest.approx(float(800.0 * dims[0] * dims[1] / (8 * 3)))
+    assert rt._resolution_host == (32, 16)
+    assert rt.distortions_dataset.distortions_u.shape == (4, 3, 8) and len(rt.distortions_dataset) == 4
+    # 3 distinct active heliostats over 2 ranks... the reference's sampler needs uniform replica counts
+    g.activate_heliostats(torch.tensor([2, 2, 0, 0], dtype=torch.int32))
+    idx = [HeliostatRayTracer(sc, g, blocking_active=False, world_size=2, rank=r).get_sampler_indices().tolist()
+           for r in range(2)]
+    assert idx == [[0, 1], [2, 3]]
+    rt = HeliostatRayTracer(sc, g, blocking_active=False)
+    with pytest.raises(AssertionError, match="Some heliostats were not aligned and cannot be raytraced."):
+        rt.trace_rays(torch.zeros(4, 4), torch.tensor([1, 1, 1, 1], dtype=torch.int32), torch.zeros(4, dtype=torch.long))
