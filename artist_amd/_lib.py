@@ -12,7 +12,7 @@ import pathlib
 import subprocess
 
 _PKG = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libartist_hip.so"
+LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
 ABI_VERSION = 1

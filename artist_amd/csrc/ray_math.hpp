@@ -22,6 +22,7 @@ struct Plane {
     float mx, my, mz;       // plane normal
     float w, h;             // plane dimensions (east, up)
     float half_w, half_h;   // dims / 2                       (geometry.py:150,156)
+    float inv_w, inv_h;     // RN(1/w), RN(1/h) for div_const()
     float wm1, hm1;         // float(resolution - 1)          (geometry.py:168,173)
     float mag;              // ray magnitude                  (heliostat_ray_tracer.py:556-560)
     float k_ext, k_refl;    // float(1 - extinction), float(reflectivity)  (:485-486)
@@ -36,9 +37,21 @@ __device__ __forceinline__ Plane load_plane(const float* __restrict__ centers, c
     pl.mx = pnormals[4 * t + 0]; pl.my = pnormals[4 * t + 1]; pl.mz = pnormals[4 * t + 2];
     pl.w = dims[2 * t + 0]; pl.h = dims[2 * t + 1];
     pl.half_w = pl.w / 2.0f; pl.half_h = pl.h / 2.0f;
+    pl.inv_w = 1.0f / pl.w; pl.inv_h = 1.0f / pl.h;
     pl.wm1 = (float)(W - 1); pl.hm1 = (float)(Hh - 1);
     pl.mag = mag; pl.k_ext = k_ext; pl.k_refl = k_refl;
     return pl;
+}
+
+// a / b for a divisor b whose correctly rounded reciprocal y = RN(1/b) is known (Markstein): q0 = RN(a y),
+// r = a - b q0 (exact in an FMA), q = RN(q0 + r y).  The result is the IEEE-correctly-rounded quotient -
+// bit-identical to `a / b` - for normal operands (checked on 2e9 random pairs incl. all-ones significands,
+// tools/div_const_check.c), at 3 instructions instead of the ~10 of the generic division expansion.
+__device__ __forceinline__ float div_const(float a, float b, float y)
+{
+    const float q0 = a * y;
+    const float r = fmaf(-b, q0, a);
+    return fmaf(r, y, q0);
 }
 
 // geometry.py:32-41: d = i - 2 (i.n) n over all four components (torch.sum over dim -1).
@@ -84,11 +97,32 @@ __device__ __forceinline__ void sincos_angle(float x, float& s, float& c)
     }
 }
 
+__device__ __forceinline__ void sincos_small(float x, float& s, float& c)
+{
+    const float z = x * x;
+    const float ps = fmaf(z, fmaf(z, -1.98412698e-4f, 8.33333333e-3f), -1.66666667e-1f);
+    const float pc = fmaf(z, fmaf(z, -1.38888889e-3f, 4.16666667e-2f), -0.5f);
+    s = fmaf(x * z, ps, x);
+    c = fmaf(z, pc, 1.0f);
+}
+
+// true iff `cond` holds for at least one active lane; the result is wave-uniform, so `if (wave_any(c))`
+// compiles to a scalar branch (s_cbranch_scc*) that the hot path falls through without touching EXEC.
+__device__ __forceinline__ bool wave_any(bool cond) { return __builtin_amdgcn_ballot_w64(cond) != 0ull; }
+
 __device__ __forceinline__ Rot make_rot(float e, float u)
 {
     Rot m;
-    sincos_angle(e, m.se, m.ce);
-    sincos_angle(u, m.su, m.cu);
+    // One wave-uniform test for both angles keeps the full-range code (and its EXEC juggling) off the
+    // hot path; NaN angles compare false and take the full-range branch.
+    const bool small = fmaxf(fabsf(e), fabsf(u)) <= kSmallAngle;
+    if (__builtin_expect(wave_any(!small), 0)) {
+        sincos_angle(e, m.se, m.ce);
+        sincos_angle(u, m.su, m.cu);
+    } else {
+        sincos_small(e, m.se, m.ce);
+        sincos_small(u, m.su, m.cu);
+    }
     m.m10 = m.ce * m.su; m.m11 = m.ce * m.cu; m.m20 = m.se * m.su; m.m21 = m.se * m.cu;
     return m;
 }
@@ -122,8 +156,8 @@ __device__ __forceinline__ Hit intersect(const Plane& pl, const float4 o, float 
     const float hz = o.z + rz * h.t;
     const float te = (hx + pl.half_w) - pl.cx;
     const float tu = (hz + pl.half_h) - pl.cz;
-    const float be0 = (te / pl.w) * pl.wm1;
-    const float bu0 = (tu / pl.h) * pl.hm1;
+    const float be0 = div_const(te, pl.w, pl.inv_w) * pl.wm1;
+    const float bu0 = div_const(tu, pl.h, pl.inv_h) * pl.hm1;
     h.valid = (0.0f <= be0) && (be0 <= pl.wm1) && (0.0f <= bu0) && (bu0 <= pl.hm1) && front;
     const float v = h.valid ? 1.0f : 0.0f;
     h.be = pl.wm1 - be0 * v;
@@ -149,6 +183,50 @@ __device__ __forceinline__ Splat splat_weights(float be, float bu, int W, int Hh
     s.chu = bu - (float)s.iu;
     s.on = (0 <= s.ie) && (s.ie + 1 < W) && (0 <= s.iu) && (s.iu + 1 < Hh);
     return s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused hit + bilinear weights for the production kernels.  Arithmetic of a ray that reaches the
+// bitmap is exactly that of intersect() + splat_weights() above (same operations, same order, same
+// roundings); what is dropped are the multiplications by the 0/1 masks, which are exact no-ops for
+// such a ray, and all work for rays the reference zeroes out (not front-facing, off the plane, or on
+// the last pixel row/column): those end with `on == false` and contribute nothing, as in the reference
+// (geometry.py:186-197 moves them to pixel (W-1, 0), which fails heliostat_ray_tracer.py:723-728).
+// ---------------------------------------------------------------------------------------------------
+struct RaySplat {
+    float a;                     // r . m
+    float t;                     // numer / a for front-facing rays
+    float I0;                    // mag * (-a)                                   (valid rays)
+    float cle, clu, che, chu;    // bilinear weights                             (valid rays)
+    int ie, iu;                  // low pixel indices (un-flipped flat rows)     (valid rays)
+    bool valid;                  // geometry.py:178-184
+    bool on;                     // valid && heliostat_ray_tracer.py:723-728
+};
+
+__device__ __forceinline__ RaySplat hit_and_weights(const Plane& pl, const float4 o, float numer, float rx, float ry,
+                                                    float rz, float Wf, float Hf)
+{
+    RaySplat h;
+    h.a = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
+    const bool front = h.a < 0.0f;
+    const float den = front ? h.a : 1.0f;
+    h.t = numer / den;
+    const float hx = o.x + rx * h.t;
+    const float hz = o.z + rz * h.t;
+    const float te = (hx + pl.half_w) - pl.cx;
+    const float tu = (hz + pl.half_h) - pl.cz;
+    const float be0 = div_const(te, pl.w, pl.inv_w) * pl.wm1;
+    const float bu = div_const(tu, pl.h, pl.inv_h) * pl.hm1;
+    h.valid = (0.0f <= be0) && (be0 <= pl.wm1) && (0.0f <= bu) && (bu <= pl.hm1) && front;
+    const float be = pl.wm1 - be0;               // e-flip (geometry.py:195-197); be, bu in [0, res-1]
+    h.I0 = pl.mag * (-h.a);
+    const float tbe = truncf(be), tbu = truncf(bu);          // == float(int(be)) for 0 <= be < 2^24
+    const float tbe1 = tbe + 1.0f, tbu1 = tbu + 1.0f;        // == float(ie + 1)
+    h.cle = tbe1 - be; h.clu = tbu1 - bu;
+    h.che = be - tbe; h.chu = bu - tbu;
+    h.ie = (int)tbe; h.iu = (int)tbu;
+    h.on = h.valid && (tbe1 < Wf) && (tbu1 < Hf);            // ie + 1 < W, iu + 1 < Hh; ie, iu >= 0 when valid
+    return h;
 }
 
 }  // namespace art

@@ -54,6 +54,24 @@ __device__ __forceinline__ void load_dist(const TraceArgs& a, int64_t off, float
     }
 }
 
+// Same fetch with the address split into a wave-uniform row pointer (heliostat, sample -> SGPRs) and a 32-bit
+// per-lane offset (point): compiles to global_load ... v_off, s[base:base+1] with no per-ray VALU address math.
+template <bool INTERLEAVED>
+__device__ __forceinline__ void load_dist_row(const float* __restrict__ row_u, const float* __restrict__ row_e,
+                                              int lane_off, float& u, float& e)
+{
+#ifdef ART_ABLATE_NO_LOADS   // diagnostic build: synthesise angles in registers, no HBM stream
+    u = 1e-6f * (float)(lane_off & 1023); e = -1e-6f * (float)((lane_off >> 3) & 1023);
+    return;
+#endif
+    if constexpr (INTERLEAVED) {
+        const float2 v = *reinterpret_cast<const float2*>(row_u + lane_off);
+        u = v.x; e = v.y;
+    } else {
+        u = row_u[lane_off]; e = row_e[lane_off];
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // Forward, global-atomic splat.
 // grid.x = H * n_rchunks * n_ptiles ; block = 256.
@@ -177,12 +195,31 @@ __device__ __forceinline__ unsigned cvt_nearest_u32(float x)
     return (unsigned)q;
 }
 
-// cell += round(|v| S); on wrap-around push one carry to the global pixel `g`.
-__device__ __forceinline__ void lds_add_fixed(unsigned* cell, float v, const float scale, const float carry, float* g)
+// q = round(|v| S) as an unsigned fixed-point increment.
+__device__ __forceinline__ unsigned to_fixed(float v, float scale) { return cvt_nearest_u32(fabsf(v) * scale); }
+
+// Four returning LDS adds of one ray whose results are examined one ray LATER (software pipelining:
+// the returns have long arrived by then, so no wave ever waits on the LDS round trip).
+struct PendingSplat {
+    unsigned o1, o2, o3, o4;   // cell values before the add
+    unsigned q1, q2, q3, q4;   // increments (0 = nothing pending)
+    int ie, iu;                // low pixel of the pending ray (pointer math only if a carry happened)
+};
+
+// A cell wrapped iff old + q < old (unsigned).  Rare: a cell holds ~2^10 full-size contributions.
+__device__ __forceinline__ void resolve_carries(const PendingSplat& ps, float* __restrict__ bitmap, int W, int Hh,
+                                                float carry)
 {
-    const unsigned q = cvt_nearest_u32(fabsf(v) * scale);
-    const unsigned old = atomicAdd(cell, q);        // ds_add_rtn_u32
-    if (__builtin_expect(old + q < old, 0)) atomicAdd(g, carry);
+    const bool c1 = ps.o1 + ps.q1 < ps.o1, c2 = ps.o2 + ps.q2 < ps.o2;
+    const bool c3 = ps.o3 + ps.q3 < ps.o3, c4 = ps.o4 + ps.q4 < ps.o4;
+    if (__builtin_expect(wave_any(c1 | c2 | c3 | c4), 0)) {
+        float* row_hi = bitmap + (int64_t)(Hh - 2 - ps.iu) * W + ps.ie;   // flat row iu + 1 of the flipped bitmap
+        float* row_lo = row_hi + W;
+        if (c1) atomicAdd(row_hi, carry);
+        if (c2) atomicAdd(row_hi + 1, carry);
+        if (c3) atomicAdd(row_lo + 1, carry);
+        if (c4) atomicAdd(row_lo, carry);
+    }
 }
 
 // Phase 1 of the windowed kernels: bounding box (in un-flipped bitmap coordinates) of where the
@@ -301,47 +338,88 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     __syncthreads();
 
     // ---- phase 2: trace ----------------------------------------------------------------------
+    // Every ray issues its four LDS adds unconditionally: rays that are off the bitmap or outside the
+    // window add 0 to a dummy cell behind the window (no divergence in the common path); the rare
+    // in-bitmap-but-outside-window ray goes to global memory.
     unsigned n_on = 0, n_int = 0;
+    const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
+    const unsigned twm1 = (unsigned)(win.tw - 1), thm1 = (unsigned)(win.th - 1);
+    const float Wf = (float)a.W, Hf = (float)a.Hh;
+    PendingSplat ps = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
         const float4 o = org[p];
         const float4 n = nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
-        int64_t off = dbase + (int64_t)p * a.sp;
-        for (int r = r0; r < r1; ++r, off += a.sr) {
-            float u, e;
-            load_dist<INTERLEAVED>(a, off, u, e);
+        // One ray: scatter -> hit -> weights -> 4 pipelined LDS adds.
+        auto trace_one = [&](const float u, const float e) {
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            const Hit hit = intersect(pl, o, numer, rx, ry, rz);
-            const float I = ((hit.I0 * 1.0f) * pl.k_ext) * pl.k_refl;   // (1 - blocked) == 1
-            n_on += hit.I0 > 0.0f;
-            n_int += I > 0.0f;
-            const Splat sp = splat_weights(hit.be, hit.bu, a.W, a.Hh);
-            if (sp.on) {
-                const float v1 = sp.cle * sp.chu * I, v2 = sp.che * sp.chu * I;
-                const float v3 = sp.che * sp.clu * I, v4 = sp.cle * sp.clu * I;
-                const int le = sp.ie - win.e0, lu = sp.iu - win.u0;
-                float* row_hi = bitmap + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;   // flat row iu + 1
-                float* row_lo = row_hi + a.W;                                          // flat row iu
-                if (le >= 0 && le + 1 < win.tw && lu >= 0 && lu + 1 < win.th) {
-                    unsigned* lo = tile + lu * win.tw + le;
-                    unsigned* hi = lo + win.tw;
-                    lds_add_fixed(hi, v1, win.scale, win.carry, row_hi);
-                    lds_add_fixed(hi + 1, v2, win.scale, win.carry, row_hi + 1);
-                    lds_add_fixed(lo + 1, v3, win.scale, win.carry, row_lo + 1);
-                    lds_add_fixed(lo, v4, win.scale, win.carry, row_lo);
-                } else {
-                    atomicAdd(row_hi, v1); atomicAdd(row_hi + 1, v2); atomicAdd(row_lo + 1, v3); atomicAdd(row_lo, v4);
-                }
+            const RaySplat hs = hit_and_weights(pl, o, numer, rx, ry, rz, Wf, Hf);
+            const float I = (hs.I0 * pl.k_ext) * pl.k_refl;             // (1 - blocked) == 1 (:482-487)
+            // ray counters live in SGPRs: one v_cmp + s_bcnt1 per counter instead of per-lane adds
+            n_on += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && hs.I0 > 0.0f));
+            n_int += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && I > 0.0f));
+            const int le = hs.ie - win.e0, lu = hs.iu - win.u0;
+            const bool inwin = hs.on && (unsigned)le < twm1 && (unsigned)lu < thm1;
+            const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;   // flat row iu
+            const int cell_hi = inwin ? cell_lo + win.tw : dummy;                  // flat row iu + 1
+            // S is a power of two, so (w I) S == w (I S) bit for bit: scale the intensity once
+            const float Is = inwin ? fabsf(I) * win.scale : 0.0f;
+            resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);          // previous ray's adds have landed
+            ps.q1 = cvt_nearest_u32(hs.cle * hs.chu * Is); ps.q2 = cvt_nearest_u32(hs.che * hs.chu * Is);
+            ps.q3 = cvt_nearest_u32(hs.che * hs.clu * Is); ps.q4 = cvt_nearest_u32(hs.cle * hs.clu * Is);
+            ps.ie = hs.ie; ps.iu = hs.iu;
+#ifdef ART_ABLATE_NO_LDS_ATOMICS   // diagnostic build: keep the operands alive, skip the LDS traffic
+            asm volatile("" ::"v"(cell_hi), "v"(cell_lo), "v"(ps.q1), "v"(ps.q2), "v"(ps.q3), "v"(ps.q4));
+#elif defined(ART_ABLATE_NORTN)      // diagnostic build: non-returning adds (no carry detection)
+            atomicAdd(tile + cell_hi, ps.q1); atomicAdd(tile + cell_hi + 1, ps.q2);
+            atomicAdd(tile + cell_lo + 1, ps.q3); atomicAdd(tile + cell_lo, ps.q4);
+#else
+            ps.o1 = atomicAdd(tile + cell_hi, ps.q1);
+            ps.o2 = atomicAdd(tile + cell_hi + 1, ps.q2);
+            ps.o3 = atomicAdd(tile + cell_lo + 1, ps.q3);
+            ps.o4 = atomicAdd(tile + cell_lo, ps.q4);
+#endif
+            if (__builtin_expect(wave_any(hs.on && !inwin), 0) && hs.on && !inwin) {
+                float* row_hi = bitmap + (int64_t)(a.Hh - 2 - hs.iu) * a.W + hs.ie;
+                float* row_lo = row_hi + a.W;
+                atomicAdd(row_hi, hs.cle * hs.chu * I); atomicAdd(row_hi + 1, hs.che * hs.chu * I);
+                atomicAdd(row_lo + 1, hs.che * hs.clu * I); atomicAdd(row_lo, hs.cle * hs.clu * I);
             }
+        };
+        // Distortion stream, software-prefetched in groups of four samples: the loads of group g+1 are issued
+        // before group g is traced, so their HBM latency hides behind ~700 VALU instructions.  (The loads are
+        // consumed in the iteration after the one that issues them; hipcc drains vmcnt at the loop back-edge,
+        // by which time they have landed.)
+        const int lane_off = p * (int)a.sp;
+        const int nr = r1 - r0;
+        const float* __restrict__ bu = a.dist_u + dbase;     // wave-uniform
+        const float* __restrict__ be = a.dist_e + dbase;
+        float cu0, ce0, cu1, ce1, cu2, ce2, cu3, ce3;
+        load_dist_row<INTERLEAVED>(bu, be, lane_off, cu0, ce0);
+        load_dist_row<INTERLEAVED>(bu + (int64_t)min(1, nr - 1) * a.sr, be + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
+        load_dist_row<INTERLEAVED>(bu + (int64_t)min(2, nr - 1) * a.sr, be + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
+        load_dist_row<INTERLEAVED>(bu + (int64_t)min(3, nr - 1) * a.sr, be + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
+        for (int k = 0; k < nr; k += 4) {
+            float nu0, ne0, nu1, ne1, nu2, ne2, nu3, ne3;
+            const int64_t o4 = (int64_t)min(k + 4, nr - 1) * a.sr, o5 = (int64_t)min(k + 5, nr - 1) * a.sr;
+            const int64_t o6 = (int64_t)min(k + 6, nr - 1) * a.sr, o7 = (int64_t)min(k + 7, nr - 1) * a.sr;
+            load_dist_row<INTERLEAVED>(bu + o4, be + o4, lane_off, nu0, ne0);
+            load_dist_row<INTERLEAVED>(bu + o5, be + o5, lane_off, nu1, ne1);
+            load_dist_row<INTERLEAVED>(bu + o6, be + o6, lane_off, nu2, ne2);
+            load_dist_row<INTERLEAVED>(bu + o7, be + o7, lane_off, nu3, ne3);
+            trace_one(cu0, ce0);
+            if (k + 1 < nr) trace_one(cu1, ce1);
+            if (k + 2 < nr) trace_one(cu2, ce2);
+            if (k + 3 < nr) trace_one(cu3, ce3);
+            cu0 = nu0; ce0 = ne0; cu1 = nu1; ce1 = ne1; cu2 = nu2; ce2 = ne2; cu3 = nu3; ce3 = ne3;
         }
     }
-    n_on = wave_sum_u32(n_on);
-    n_int = wave_sum_u32(n_int);
-    if (lane == 0) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_on); }
+    resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+    if (lane == 0) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_on); }   // already wave totals
     __syncthreads();
 
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
@@ -498,6 +576,8 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
 
     const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
     const float sx = pl.wm1 / pl.w, sz = pl.hm1 / pl.h;
+    const float Wf = (float)a.W, Hf = (float)a.Hh;
+    const unsigned twm1 = (unsigned)(win.tw - 1), thm1 = (unsigned)(win.th - 1);
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
         const float4 o = org[p];
         const float4 n = nrm[p];
@@ -505,48 +585,66 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
         float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;
-        int64_t off = dbase + (int64_t)p * a.sp;
-        for (int r = r0; r < r1; ++r, off += a.sr) {
-            float u, e;
-            load_dist<INTERLEAVED>(a, off, u, e);
+        auto trace_one = [&](const float u, const float e) {
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            const Hit hit = intersect(pl, o, numer, rx, ry, rz);
-            if (!hit.valid) continue;
-            const Splat sp = splat_weights(hit.be, hit.bu, a.W, a.Hh);
-            if (!sp.on) continue;
-            const float I = (hit.I0 * pl.k_ext) * pl.k_refl;
+            const RaySplat hs = hit_and_weights(pl, o, numer, rx, ry, rz, Wf, Hf);
+            if (!hs.on) return;                       // masked rays carry no gradient (masks are constants)
+            const float I = (hs.I0 * pl.k_ext) * pl.k_refl;
             float g1, g2, g3, g4;
-            const int le = sp.ie - win.e0, lu = sp.iu - win.u0;
-            if (le >= 0 && le + 1 < win.tw && lu >= 0 && lu + 1 < win.th) {
-                const float* lo = gtile + lu * win.tw + le;
+            const int le = hs.ie - win.e0, lu = hs.iu - win.u0;
+            if ((unsigned)le < twm1 && (unsigned)lu < thm1) {
+                const float* lo = gtile + (int)__umul24(lu, win.tw) + le;
                 const float* hi = lo + win.tw;
                 g1 = hi[0]; g2 = hi[1]; g3 = lo[1]; g4 = lo[0];
             } else {
-                const float* g_hi = G + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;
+                const float* g_hi = G + (int64_t)(a.Hh - 2 - hs.iu) * a.W + hs.ie;
                 const float* g_lo = g_hi + a.W;
                 g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
             }
-            const float gI = sp.cle * sp.chu * g1 + sp.che * sp.chu * g2 + sp.che * sp.clu * g3 + sp.cle * sp.clu * g4;
-            const float g_be = ((sp.chu * g2 + sp.clu * g3) - (sp.chu * g1 + sp.clu * g4)) * I;
-            const float g_bu = ((sp.cle * g1 + sp.che * g2) - (sp.che * g3 + sp.cle * g4)) * I;
+            const float gI = hs.cle * hs.chu * g1 + hs.che * hs.chu * g2 + hs.che * hs.clu * g3 + hs.cle * hs.clu * g4;
+            const float g_be = ((hs.chu * g2 + hs.clu * g3) - (hs.chu * g1 + hs.clu * g4)) * I;
+            const float g_bu = ((hs.cle * g1 + hs.che * g2) - (hs.che * g3 + hs.cle * g4)) * I;
             const float g_hx = -g_be * sx;          // be = wm1 - te / w * wm1
             const float g_hz = g_bu * sz;
             const float g_t = g_hx * rx + g_hz * rz;
-            const float inv_a = 1.0f / hit.a;
-            const float tt = numer * inv_a;          // t = numer / a (front facing)
-            const float g_a = -kI * gI - g_t * tt * inv_a;
+            const float inv_a = 1.0f / hs.a;
+            const float g_a = -kI * gI - g_t * hs.t * inv_a;          // t = numer / a
             const float g_numer = g_t * inv_a;
-            const float grx = g_hx * tt + g_a * pl.mx;
+            const float grx = g_hx * hs.t + g_a * pl.mx;
             const float gry = g_a * pl.my;
-            const float grz = g_hz * tt + g_a * pl.mz;
+            const float grz = g_hz * hs.t + g_a * pl.mz;
             gox += g_hx - g_numer * pl.mx;
             goy += -g_numer * pl.my;
             goz += g_hz - g_numer * pl.mz;
             gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
             gdy += -m.su * grx + m.m11 * gry + m.m21 * grz;
             gdz += -m.se * gry + m.ce * grz;
+        };
+        // distortion stream prefetched in groups of four samples (see the forward kernel)
+        const int lane_off = p * (int)a.sp;
+        const int nr = r1 - r0;
+        const float* __restrict__ bu = a.dist_u + dbase;     // wave-uniform
+        const float* __restrict__ be = a.dist_e + dbase;
+        float cu0, ce0, cu1, ce1, cu2, ce2, cu3, ce3;
+        load_dist_row<INTERLEAVED>(bu, be, lane_off, cu0, ce0);
+        load_dist_row<INTERLEAVED>(bu + (int64_t)min(1, nr - 1) * a.sr, be + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
+        load_dist_row<INTERLEAVED>(bu + (int64_t)min(2, nr - 1) * a.sr, be + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
+        load_dist_row<INTERLEAVED>(bu + (int64_t)min(3, nr - 1) * a.sr, be + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
+        for (int k = 0; k < nr; k += 4) {
+            float nu0, ne0, nu1, ne1, nu2, ne2, nu3, ne3;
+            const int64_t o4 = (int64_t)min(k + 4, nr - 1) * a.sr, o5 = (int64_t)min(k + 5, nr - 1) * a.sr;
+            const int64_t o6 = (int64_t)min(k + 6, nr - 1) * a.sr, o7 = (int64_t)min(k + 7, nr - 1) * a.sr;
+            load_dist_row<INTERLEAVED>(bu + o4, be + o4, lane_off, nu0, ne0);
+            load_dist_row<INTERLEAVED>(bu + o5, be + o5, lane_off, nu1, ne1);
+            load_dist_row<INTERLEAVED>(bu + o6, be + o6, lane_off, nu2, ne2);
+            load_dist_row<INTERLEAVED>(bu + o7, be + o7, lane_off, nu3, ne3);
+            trace_one(cu0, ce0);
+            if (k + 1 < nr) trace_one(cu1, ce1);
+            if (k + 2 < nr) trace_one(cu2, ce2);
+            if (k + 3 < nr) trace_one(cu3, ce3);
+            cu0 = nu0; ce0 = ne0; cu1 = nu1; ce1 = ne1; cu2 = nu2; ce2 = ne2; cu3 = nu3; ce3 = ne3;
         }
         const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
         const float4 go = make_float4(gox, goy, goz, 0.0f);
@@ -590,6 +688,7 @@ static bool fill_args(TraceArgs& a, const float* origins, const float* normals, 
     if (H < 0 || R <= 0 || P <= 0 || T <= 0 || W < 2 || Hh < 2 || (mode != 0 && mode != 1)) return false;
     if (H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || W > 32768 || Hh > 32768) return false;
     if ((double)R * (double)P >= 4294967296.0) return false;   // uint32 ray counters
+    if (sp < 0 || (double)P * (double)sp >= 1073741824.0) return false;   // 32-bit per-lane distortion offsets
     a.origins = reinterpret_cast<const float4*>(origins);
     a.normals = reinterpret_cast<const float4*>(normals);
     a.incident = reinterpret_cast<const float4*>(incident);
@@ -648,7 +747,7 @@ static FwdConfig fwd_config()
     if (c.block < 64 || c.block > 1024 || (c.block % 64) != 0) c.block = 1024;
     int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 144);
     if (kb < 4) kb = 4;
-    if (kb > 156) kb = 156;
+    if (kb > 152) kb = 152;
     c.tile_cap = kb * 256;   // 4-byte fixed-point cells
     c.target_blocks = env_int("ARTIST_HIP_FWD_BLOCKS", 512);
     c.min_chunk = env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
@@ -707,7 +806,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const int64_t base = (int64_t)a.H * a.n_pblocks;
         const int64_t blocks = base * a.n_rchunks;
         if (blocks > 2147483647LL) return ART_EINVAL;
-        const size_t lds = (size_t)a.tile_cap * sizeof(unsigned);
+        const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         if (interleaved_layout(a)) {
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
