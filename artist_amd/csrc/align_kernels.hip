@@ -1,0 +1,158 @@
+// align_kernels.hip - rigid alignment of surface points and normals, forward + backward (gfx950).
+//
+// Replaces the two batched 4x4 matmuls of HeliostatGroupRigidBody.align_surfaces_with_* :
+//     active_surface_points  = active_surface_points  @ orientations.transpose(1, 2)
+//     active_surface_normals = active_surface_normals @ orientations.transpose(1, 2)
+// (artist/field/heliostat_group_rigid_body.py:217-222, 265-270).  As a BLAS call each of them streams
+// 32 B/point at ~0.5 TB/s (the GEMM kernel is built for large K); here both tensors go through ONE
+// HBM-bound pass (64 B in + 64 B out per point, float4 accesses) with the 4x4 matrix in SGPRs, and the
+// backward produces dL/dpoints, dL/dnormals and - for kinematics optimisation - dL/dorientation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch_common.hpp"
+
+namespace art {
+
+constexpr int kAlignBlock = 256;
+
+// out_j = sum_k x_k M[j][k], k sequential (row vector times M^T)
+__device__ __forceinline__ float4 apply_mt(const float4 x, const float* __restrict__ M)
+{
+    float4 o;
+    o.x = ((x.x * M[0] + x.y * M[1]) + x.z * M[2]) + x.w * M[3];
+    o.y = ((x.x * M[4] + x.y * M[5]) + x.z * M[6]) + x.w * M[7];
+    o.z = ((x.x * M[8] + x.y * M[9]) + x.z * M[10]) + x.w * M[11];
+    o.w = ((x.x * M[12] + x.y * M[13]) + x.z * M[14]) + x.w * M[15];
+    return o;
+}
+
+// g_x_k = sum_j g_j M[j][k]
+__device__ __forceinline__ float4 apply_m(const float4 g, const float* __restrict__ M)
+{
+    float4 o;
+    o.x = ((g.x * M[0] + g.y * M[4]) + g.z * M[8]) + g.w * M[12];
+    o.y = ((g.x * M[1] + g.y * M[5]) + g.z * M[9]) + g.w * M[13];
+    o.z = ((g.x * M[2] + g.y * M[6]) + g.z * M[10]) + g.w * M[14];
+    o.w = ((g.x * M[3] + g.y * M[7]) + g.z * M[11]) + g.w * M[15];
+    return o;
+}
+
+__global__ __launch_bounds__(kAlignBlock) void align_fwd_kernel(const float4* __restrict__ points,
+                                                                 const float4* __restrict__ normals,
+                                                                 const float* __restrict__ orientation, int P, int n_tiles,
+                                                                 float4* __restrict__ out_points,
+                                                                 float4* __restrict__ out_normals)
+{
+    const int h = blockIdx.x / n_tiles;
+    const int p = (blockIdx.x % n_tiles) * kAlignBlock + threadIdx.x;
+    if (p >= P) return;
+    const float* M = orientation + (int64_t)h * 16;       // wave-uniform -> scalar loads
+    const int64_t i = (int64_t)h * P + p;
+    out_points[i] = apply_mt(points[i], M);
+    out_normals[i] = apply_mt(normals[i], M);
+}
+
+// WITH_GM: also accumulate dL/dM[j][k] = sum_p (gP_j xP_k + gN_j xN_k) (wave shuffle tree, LDS across
+// the 4 waves, 16 global atomics per workgroup into the pre-zeroed [H,4,4]).
+template <bool WITH_GM>
+__global__ __launch_bounds__(kAlignBlock) void align_bwd_kernel(const float4* __restrict__ points,
+                                                                 const float4* __restrict__ normals,
+                                                                 const float* __restrict__ orientation,
+                                                                 const float4* __restrict__ g_out_points,
+                                                                 const float4* __restrict__ g_out_normals, int P, int n_tiles,
+                                                                 float4* __restrict__ g_points,
+                                                                 float4* __restrict__ g_normals,
+                                                                 float* __restrict__ g_orientation)
+{
+    __shared__ float s_part[kAlignBlock / 64][16];
+    const int h = blockIdx.x / n_tiles;
+    const int p = (blockIdx.x % n_tiles) * kAlignBlock + threadIdx.x;
+    const float* M = orientation + (int64_t)h * 16;
+    const int64_t i = (int64_t)h * P + p;
+    float gm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gm[k] = 0.0f;
+    if (p < P) {
+        const float4 gp = g_out_points[i], gn = g_out_normals[i];
+        g_points[i] = apply_m(gp, M);
+        g_normals[i] = apply_m(gn, M);
+        if constexpr (WITH_GM) {
+            const float4 xp = points[i], xn = normals[i];
+            const float g4[4] = {gp.x, gp.y, gp.z, gp.w}, h4[4] = {gn.x, gn.y, gn.z, gn.w};
+            const float x4[4] = {xp.x, xp.y, xp.z, xp.w}, y4[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gm[4 * j + k] = g4[j] * x4[k] + h4[j] * y4[k];
+        }
+    }
+    if constexpr (WITH_GM) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float v = wave_sum_f32(gm[k]);
+            if (lane == 0) s_part[wave][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kAlignBlock / 64; ++w) v += s_part[w][threadIdx.x];
+            atomicAdd(g_orientation + (int64_t)h * 16 + threadIdx.x, v);
+        }
+    }
+}
+
+}  // namespace art
+
+using namespace art;
+
+extern "C" int art_align_fwd(const float* points, const float* normals, const float* orientation, int64_t H,
+                             int64_t P, float* out_points, float* out_normals, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!points || !normals || !orientation || !out_points || !out_normals || H < 0 || P <= 0 || P > 2147483647LL ||
+        H * ((P + kAlignBlock - 1) / kAlignBlock) > 2147483647LL)
+        return ART_EINVAL;
+    if (H == 0) return ART_OK;
+    const int n_tiles = (int)((P + kAlignBlock - 1) / kAlignBlock);
+    hipLaunchKernelGGL(align_fwd_kernel, dim3((unsigned)(H * n_tiles)), dim3(kAlignBlock), 0, stream,
+                       reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals), orientation,
+                       (int)P, n_tiles,
+                       reinterpret_cast<float4*>(out_points), reinterpret_cast<float4*>(out_normals));
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_align_bwd(const float* points, const float* normals, const float* orientation,
+                             const float* grad_out_points, const float* grad_out_normals, int64_t H, int64_t P,
+                             float* grad_points, float* grad_normals, float* grad_orientation, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!orientation || !grad_out_points || !grad_out_normals || !grad_points || !grad_normals || H < 0 || P <= 0 ||
+        P > 2147483647LL || H * ((P + kAlignBlock - 1) / kAlignBlock) > 2147483647LL ||
+        (grad_orientation && (!points || !normals)))
+        return ART_EINVAL;
+    if (H == 0) return ART_OK;
+    const int n_tiles = (int)((P + kAlignBlock - 1) / kAlignBlock);
+    const dim3 grid((unsigned)(H * n_tiles));
+    if (grad_orientation) {
+        ART_HIP(hipMemsetAsync(grad_orientation, 0, sizeof(float) * 16 * H, stream));
+        hipLaunchKernelGGL(align_bwd_kernel<true>, grid, dim3(kAlignBlock), 0, stream,
+                           reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals),
+                           orientation, reinterpret_cast<const float4*>(grad_out_points),
+                           reinterpret_cast<const float4*>(grad_out_normals), (int)P, n_tiles,
+                           reinterpret_cast<float4*>(grad_points), reinterpret_cast<float4*>(grad_normals),
+                           grad_orientation);
+    } else {
+        hipLaunchKernelGGL(align_bwd_kernel<false>, grid, dim3(kAlignBlock), 0, stream,
+                           reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals),
+                           orientation, reinterpret_cast<const float4*>(grad_out_points),
+                           reinterpret_cast<const float4*>(grad_out_normals), (int)P, n_tiles,
+                           reinterpret_cast<float4*>(grad_points), reinterpret_cast<float4*>(grad_normals),
+                           grad_orientation);
+    }
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}

@@ -4,8 +4,10 @@
 // One workgroup per (heliostat, facet) x tile of evaluation points.  The facet's control-point
 // net (nu*nv*3 floats, 1.2 KB at 10x10) and its two knot vectors are staged once in LDS and
 // then gathered from there (16 control points per evaluation at degree 3); one thread owns one
-// evaluation point.  Backward privatises the facet's gradient net in LDS (ds_add_f32) and
-// writes it out once with plain stores - no global atomics.
+// evaluation point.  Backward privatises the facet's gradient net in LDS and writes it out once
+// with plain stores - no global atomics.  The LDS accumulator is DOUBLE: on gfx950 ds_add_f64 retires
+// a wave instruction in ~25 cycles whereas ds_add_f32 needs ~193 (tools/lds_atomic_bench.hip), and the
+// wider accumulator makes the sum insensitive to the order of the adds at fp32 output precision.
 //
 // Replaces (ARTIST v2.0.0): artist/nurbs/surfaces.py:157-245 (find_spans), :247-417
 // (basis_functions_and_derivatives, NURBS Book A2.3), :419-473 + :578-613 (gather + A3.6),
@@ -117,6 +119,13 @@ __device__ __forceinline__ void canting_basis(const float* cant, float* B)
     const float no = fmaxf(norm3(ox, oy, oz), 1e-8f);
     ox = ox / no; oy = oy / no; oz = oz / no;
     B[0] = ex; B[1] = ey; B[2] = ez; B[3] = ox; B[4] = oy; B[5] = oz; B[6] = ux; B[7] = uy; B[8] = uz;
+}
+
+// float index (even) at which the backward's double accumulator starts inside the dynamic LDS block
+__host__ __device__ inline int nurbs_f64_offset(const NurbsArgs& a)
+{
+    const int n = a.nu * a.nv * 3 + (a.nu + a.p + 1) + (a.nv + a.q + 1) + 12;
+    return (n + 1) & ~1;
 }
 
 template <int DEG>
@@ -243,8 +252,8 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
     float *s_cp, *s_ku, *s_kv, *s_B;
     stage_facet(a, hf, lds, s_cp, s_ku, s_kv, s_B);
     const int ncp = a.nu * a.nv * 3;
-    float* s_g = s_B + 12;
-    for (int i = threadIdx.x; i < ncp; i += blockDim.x) s_g[i] = 0.0f;
+    double* s_g = reinterpret_cast<double*>(lds + nurbs_f64_offset(a));   // 8-byte aligned tail of the LDS block
+    for (int i = threadIdx.x; i < ncp; i += blockDim.x) s_g[i] = 0.0;
     __syncthreads();
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int h = hf / a.F, f = hf % a.F;
@@ -291,15 +300,15 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
             for (int s = 0; s < S; ++s) {
                 if (s > q) break;
                 const float w00 = E.Nu[r] * E.Nv[s], w10 = E.Du[r] * E.Nv[s], w01 = E.Nu[r] * E.Dv[s];
-                float* g3 = s_g + ((E.su - p + r) * a.nv + (E.sv - q + s)) * 3;
+                double* g3 = s_g + ((E.su - p + r) * a.nv + (E.sv - q + s)) * 3;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) atomicAdd(g3 + k, w00 * gS[k] + w10 * gSu[k] + w01 * gSv[k]);
+                for (int k = 0; k < 3; ++k) atomicAdd(g3 + k, (double)(w00 * gS[k] + w10 * gSu[k] + w01 * gSv[k]));
             }
         }
     }
     __syncthreads();
     float* out = g_cp + (int64_t)hf * ncp;
-    for (int i = threadIdx.x; i < ncp; i += blockDim.x) out[i] = s_g[i];
+    for (int i = threadIdx.x; i < ncp; i += blockDim.x) out[i] = (float)s_g[i];
 }
 
 static bool fill_nurbs(NurbsArgs& a, const float* cp, const float* uv, int64_t uv_sh, int64_t uv_sf,
@@ -324,7 +333,7 @@ static size_t nurbs_lds_bytes(const NurbsArgs& a, bool bwd)
 {
     const size_t ncp = (size_t)a.nu * a.nv * 3;
     size_t n = ncp + (a.nu + a.p + 1) + (a.nv + a.q + 1) + 12;
-    if (bwd) n += ncp;
+    if (bwd) n = (size_t)nurbs_f64_offset(a) + 2 * ncp;
     return n * sizeof(float);
 }
 

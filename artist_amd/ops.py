@@ -12,7 +12,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["trace_rays", "nurbs_surface_points_and_normals", "per_target_sum", "TraceRays", "NurbsEval"]
+__all__ = ["trace_rays", "nurbs_surface_points_and_normals", "per_target_sum", "align_surfaces", "TraceRays",
+           "NurbsEval", "AlignSurfaces"]
 
 
 def _stream(device: torch.device) -> int:
@@ -216,3 +217,44 @@ def nurbs_surface_points_and_normals(control_points, eval_points, knots_u, knots
         n_unique = (nu - p + 1, nv - q + 1)
     return NurbsEval.apply(control_points, eval_points, knots_u, knots_v, canting, translations, p, q,
                            bool(uniform), int(n_unique[0]), int(n_unique[1]))
+
+
+class AlignSurfaces(torch.autograd.Function):
+    """``points @ orientation^T`` and ``normals @ orientation^T`` in one pass
+    (artist/field/heliostat_group_rigid_body.py:217-222, 265-270), differentiable w.r.t. all three inputs."""
+
+    @staticmethod
+    def forward(ctx, points, normals, orientation):
+        dev = _require_cuda(points, normals, orientation)
+        points, normals, orientation = _f32c(points), _f32c(normals), _f32c(orientation)
+        H, P = points.shape[0], points.shape[1]
+        if points.shape != (H, P, 4) or normals.shape != (H, P, 4) or orientation.shape != (H, 4, 4):
+            raise ValueError("points/normals must be [H,P,4] and orientation [H,4,4]")
+        out_p, out_n = torch.empty_like(points), torch.empty_like(normals)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_align_fwd(points.data_ptr(), normals.data_ptr(), orientation.data_ptr(), H, P,
+                                          out_p.data_ptr(), out_n.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_align_fwd")
+        ctx.save_for_backward(points, normals, orientation)
+        return out_p, out_n
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out_p, g_out_n):
+        points, normals, orientation = ctx.saved_tensors
+        dev = points.device
+        H, P = points.shape[0], points.shape[1]
+        g_out_p, g_out_n = _f32c(g_out_p), _f32c(g_out_n)
+        g_p, g_n = torch.empty_like(points), torch.empty_like(normals)
+        g_m = torch.empty_like(orientation) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_align_bwd(points.data_ptr(), normals.data_ptr(), orientation.data_ptr(),
+                                          g_out_p.data_ptr(), g_out_n.data_ptr(), H, P, g_p.data_ptr(), g_n.data_ptr(),
+                                          None if g_m is None else g_m.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_align_bwd")
+        return g_p, g_n, g_m
+
+
+def align_surfaces(points: torch.Tensor, normals: torch.Tensor, orientation: torch.Tensor):
+    """Aligned ``(points, normals)`` = ``(points @ orientation^T, normals @ orientation^T)``."""
+    return AlignSurfaces.apply(points, normals, orientation)

@@ -142,8 +142,9 @@ class HeliostatGroup:
             "Some heliostats were not activated and cannot be aligned."
         orientations = ideal_orientations(self.active_positions, aim_points, incident_ray_directions)
         self.active_orientations = orientations
-        self.active_surface_points = self.active_surface_points @ orientations.transpose(1, 2)
-        self.active_surface_normals = self.active_surface_normals @ orientations.transpose(1, 2)
+        from .ops import align_surfaces
+        self.active_surface_points, self.active_surface_normals = align_surfaces(
+            self.active_surface_points, self.active_surface_normals, orientations)
 
 
 class HeliostatField:

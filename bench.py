@@ -6,7 +6,7 @@ workload : the metric config of BASELINE.md section 4 - H=1000 heliostats x R=10
            P=10^4 points (4 facets x 50x50), 10x10 degree-3 NURBS control nets, one 8 m x 8 m planar
            receiver, 256x256 bitmap, Gaussian sun; synthetic data, random (seeded) surface noise.
 step     : one surface-reconstruction epoch over the whole field:
-           NURBS points+normals (HIP) -> alignment bmm -> trace_rays (HIP) -> per-target sum ->
+           NURBS points+normals (HIP) -> alignment (HIP) -> trace_rays (HIP) -> per-target sum ->
            [N>1: RCCL all_reduce of the [T,256,256] flux] -> MSE loss vs fixed target bitmaps ->
            backward (trace_bwd HIP, alignment, nurbs_bwd HIP) -> [N>1: RCCL all_reduce of the
            control-point gradients, like surface_reconstructor.py:767-777].
@@ -142,8 +142,7 @@ def main():
 
     def forward():
         pts, nrm = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl)
-        ap = pts.reshape(H, P, 4) @ orientation.transpose(1, 2)
-        an = nrm.reshape(H, P, 4) @ orientation.transpose(1, 2)
+        ap, an = ops.align_surfaces(pts.reshape(H, P, 4), nrm.reshape(H, P, 4), orientation)
         flux, factors = ops.trace_rays(ap, an, inc, dist_u, dist_e, tix, planar.centers, planar.normals,
                                        planar.dimensions, 1.0, 0.0, 0.935, (256, 256))
         return flux, factors
@@ -203,8 +202,7 @@ def main():
 
     with torch.no_grad():
         pts, nrm = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl)
-        ap = (pts.reshape(H, P, 4) @ orientation.transpose(1, 2)).contiguous()
-        an = (nrm.reshape(H, P, 4) @ orientation.transpose(1, 2)).contiguous()
+        ap, an = ops.align_surfaces(pts.reshape(H, P, 4), nrm.reshape(H, P, 4), orientation)
     ms_fwd = kernel_ms(lambda: ops.trace_rays(ap, an, inc, dist_u, dist_e, tix, planar.centers, planar.normals,
                                               planar.dimensions, 1.0, 0.0, 0.935, (256, 256)))
     apg, ang = ap.clone().requires_grad_(True), an.clone().requires_grad_(True)

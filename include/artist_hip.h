@@ -119,6 +119,21 @@ int art_nurbs_bwd(const float *control_points, const float *eval_points, int64_t
                   int64_t H, int64_t F, int64_t M, int64_t nu, int64_t nv,
                   const float *grad_points, const float *grad_normals, float *grad_control_points, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * art_align_fwd - the alignment apply of HeliostatGroupRigidBody.align_surfaces_with_incident_ray_directions /
+ * align_surfaces_with_motor_positions (artist/field/heliostat_group_rigid_body.py:217-222, 265-270):
+ *   out_points = points @ orientation^T, out_normals = normals @ orientation^T, one pass over both.
+ *   points, normals [H,P,4]; orientation [H,4,4]; outputs [H,P,4].
+ * art_align_bwd - its autograd: grad_points = g @ orientation (same for normals) and, when
+ *   grad_orientation != NULL, grad_orientation[h] = sum_p (g_points^T x_points + g_normals^T x_normals)
+ *   ([H,4,4], fully written) - the path by which kinematic parameters receive gradients.
+ * ------------------------------------------------------------------------------------------- */
+int art_align_fwd(const float *points, const float *normals, const float *orientation, int64_t H, int64_t P,
+                  float *out_points, float *out_normals, void *stream);
+int art_align_bwd(const float *points, const float *normals, const float *orientation,
+                  const float *grad_out_points, const float *grad_out_normals, int64_t H, int64_t P,
+                  float *grad_points, float *grad_normals, float *grad_orientation, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

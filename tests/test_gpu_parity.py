@@ -51,7 +51,7 @@ def oracle_fwd(d, **kw):
 
 def test_library_is_the_hip_one():
     from artist_amd import _lib
-    assert _lib.lib().art_abi_version() == 1
+    assert _lib.lib().art_abi_version() == _lib.ABI_VERSION
     assert len(_lib.loaded_hip_runtimes()) == 1, _lib.loaded_hip_runtimes()
 
 
@@ -368,3 +368,28 @@ def test_fixed_point_cells_wrap_correctly():
         # identical rays round identically (no averaging): error <= half a quantum = 2^-23 of the contribution bound each
         np.testing.assert_allclose(n(flux), expected, rtol=1e-6, atol=2.0 ** -22 * abs(mag) * R * P)
         assert float(fac[0]) == (1.0 if mag > 0 else 0.0)
+
+
+@pytest.mark.parametrize("name", STAGE_CASES)
+def test_align_surfaces(golden, name):
+    """art_align_fwd/bwd vs the reference's two bmm calls (heliostat_group_rigid_body.py:217-222) and their autograd."""
+    from artist_amd import align_surfaces
+    d = golden(name)
+    H = d["orientation"].shape[0]
+    pts = t(d["nurbs_points"].reshape(H, -1, 4)).requires_grad_(True)
+    nrm = t(d["nurbs_normals"].reshape(H, -1, 4)).requires_grad_(True)
+    ori = t(d["orientation"]).requires_grad_(True)
+    ap, an = align_surfaces(pts, nrm, ori)
+    # reference used a BLAS bmm (unspecified accumulation order): a few ULP of ~100 m coordinates
+    np.testing.assert_allclose(n(ap), d["aligned_points"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(n(an), d["aligned_normals"], rtol=0, atol=3e-7)
+    gp, gn = t(d["grad_aligned_points"]), t(d["grad_aligned_normals"])
+    torch.autograd.backward([ap, an], [gp, gn])
+    p2, n2, o2 = (x.detach().clone().requires_grad_(True) for x in (pts, nrm, ori))
+    torch.autograd.backward([p2 @ o2.transpose(1, 2), n2 @ o2.transpose(1, 2)], [gp, gn])
+    for got, want in ((pts.grad, p2.grad), (nrm.grad, n2.grad), (ori.grad, o2.grad)):
+        scale = float(want.abs().max()) + 1e-30
+        np.testing.assert_allclose(n(got), n(want), rtol=0, atol=2e-5 * scale)
+    if np.linalg.norm(d["grad_orientation"]) > 0:
+        assert rel_l2(n(ori.grad), d["grad_orientation"]) < 1e-4
+        assert rel_l2(n(pts.grad), d["grad_nurbs_points"]) < 1e-5
