@@ -40,6 +40,7 @@ struct TraceArgs {
     int p_block;              // points per workgroup (LDS-window kernel)
     int n_pblocks;            // ceil(P / p_block)
     int tile_cap;             // LDS bitmap-window capacity in pixels
+    int multipass_ratio;      // footprints above ratio x capacity are swept in several passes
 };
 
 // Distortion fetch.  INTERLEAVED: (u,e) adjacent floats of one [H,R,P,2] buffer -> one 8-byte load.
@@ -168,7 +169,10 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
 // grid.x = H * n_pblocks * n_rchunks ; block = any multiple of 64 ; dynamic LDS = 4 B * tile_cap.
 // --------------------------------------------------------------------------------------------
 struct Window {
-    int e0, u0, tw, th;   // origin (un-flipped flat coordinates) and size; tw*th <= tile_cap
+    int e0, u0, tw, th;   // union window: origin (un-flipped flat coordinates) and size
+    int ths, npass;       // rows per pass (tw*ths <= tile_cap) and number of passes; pass k covers flat rows
+                          // [u0 + k(ths-1), u0 + k(ths-1) + ths): consecutive passes share one row because a
+                          // ray splats rows iu and iu+1 and belongs to the pass that holds row iu
     float scale;          // S  (power of two)
     float inv_scale;      // sign / S           (sign of mag*k_ext*k_refl)
     float carry;          // sign * 2^32 / S    (value of one cell wrap)
@@ -178,6 +182,12 @@ __device__ __forceinline__ float wave_min_f32(float v)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_all_f32(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max_f32(float v)
@@ -234,7 +244,7 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
     // ke / ku: metres of hit-point travel along world E / U per radian of scatter, |t| sqrt(1 + (r_E/a)^2):
     // the footprint of an oblique beam is stretched by the obliquity along the projection of the ray only.
     float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, ke = 0.0f, ku = 0.0f, angmax = 0.0f;
-    float dmax2 = 0.0f;
+    float dmax2 = 0.0f, esum = 0.0f, usum = 0.0f, cnt = 0.0f, esq = 0.0f, usq = 0.0f;
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
         const float4 o = org[p];
         const float4 n = nrm[p];
@@ -246,6 +256,8 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
         if (hit.valid) {
             emin = fminf(emin, hit.be); emax = fmaxf(emax, hit.be);
             umin = fminf(umin, hit.bu); umax = fmaxf(umax, hit.bu);
+            esum += hit.be; usum += hit.bu; cnt += 1.0f;
+            esq += hit.be * hit.be; usq += hit.bu * hit.bu;
             const float ia = 1.0f / hit.a, qe = d.x * ia, qu = d.z * ia;
             ke = fmaxf(ke, hit.t * sqrtf(1.0f + qe * qe));
             ku = fmaxf(ku, hit.t * sqrtf(1.0f + qu * qu));
@@ -256,7 +268,10 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
     }
     emin = wave_min_f32(emin); emax = wave_max_f32(emax); umin = wave_min_f32(umin); umax = wave_max_f32(umax);
     ke = wave_max_f32(ke); ku = wave_max_f32(ku); angmax = wave_max_f32(angmax); dmax2 = wave_max_f32(dmax2);
+    esum = wave_sum_all_f32(esum); usum = wave_sum_all_f32(usum); cnt = wave_sum_all_f32(cnt);
+    esq = wave_sum_all_f32(esq); usq = wave_sum_all_f32(usq);
     if (lane == 0) {
+        s_red[8][wave] = esum; s_red[9][wave] = usum; s_red[10][wave] = cnt; s_red[11][wave] = esq; s_red[12][wave] = usq;
         s_red[0][wave] = emin; s_red[1][wave] = emax; s_red[2][wave] = umin; s_red[3][wave] = umax;
         s_red[4][wave] = ke; s_red[5][wave] = ku; s_red[6][wave] = angmax; s_red[7][wave] = dmax2;
     }
@@ -267,8 +282,9 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             umin = fminf(umin, s_red[2][w]); umax = fmaxf(umax, s_red[3][w]);
             ke = fmaxf(ke, s_red[4][w]); ku = fmaxf(ku, s_red[5][w]); angmax = fmaxf(angmax, s_red[6][w]);
             dmax2 = fmaxf(dmax2, s_red[7][w]);
+            esum += s_red[8][w]; usum += s_red[9][w]; cnt += s_red[10][w]; esq += s_red[11][w]; usq += s_red[12][w];
         }
-        Window win = {0, 0, 0, 0, 1.0f, 1.0f, 0.0f};
+        Window win = {0, 0, 0, 0, 0, 1, 1.0f, 1.0f, 0.0f};
         if (emax >= emin) {
             // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
             // worth keeping in the window (~4.2 sigma); +2 px for the bilinear footprint and rounding.
@@ -277,13 +293,33 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             int e0 = max((int)emin - (int)pad_e, 0), e1 = min((int)emax + 1 + (int)pad_e, a.W - 1);
             int u0 = max((int)umin - (int)pad_u, 0), u1 = min((int)umax + 1 + (int)pad_u, a.Hh - 1);
             int tw = e1 - e0 + 1, th = u1 - u0 + 1;
-            if ((int64_t)tw * th > a.tile_cap) {   // keep the centre, let the tails use global memory
-                const float sc = sqrtf((float)a.tile_cap / ((float)tw * (float)th));
-                const int tw2 = max(2, min(tw, (int)((float)tw * sc)));
-                const int th2 = max(2, min(th, a.tile_cap / tw2));
-                e0 += (tw - tw2) / 2; u0 += (th - th2) / 2; tw = tw2; th = th2;
+            if ((int64_t)tw * th > a.tile_cap && (int64_t)tw * th <= (int64_t)a.tile_cap * a.multipass_ratio) {
+                // Too large, but by less than multipass_ratio (2): keep the densest part, centred on the mean
+                // chief-ray hit, and let the tails take the global-memory path.  A stray ray costs ~30x a
+                // window ray (scattered global atomics) while a second pass costs every ray 2x, so trimming
+                // wins as long as the tails hold less than a few percent of the rays - which a peaked
+                // (Gaussian-like) footprint does at <= 2x the capacity.
+                // Aspect ratio from the second moments of the chief-ray hits widened by the scatter pad
+                // (pad ~ 4.25 sigma of the sun shape): the window spans the same number of standard deviations
+                // along E and U, which minimises the stray fraction of a Gaussian-like footprint.
+                const float n1 = fmaxf(cnt, 1.0f);
+                const float me = esum / n1, mu = usum / n1;
+                const float se = sqrtf(fmaxf(esq / n1 - me * me, 0.0f) + (pad_e * pad_e) * (1.0f / 18.0f)) + 0.5f;
+                const float su = sqrtf(fmaxf(usq / n1 - mu * mu, 0.0f) + (pad_u * pad_u) * (1.0f / 18.0f)) + 0.5f;
+                const float kk = sqrtf((float)a.tile_cap / (se * su));
+                int tw2 = max(2, min(tw, (int)(kk * se)));
+                int th2 = max(2, min(th, a.tile_cap / tw2));
+                tw2 = max(2, min(tw, a.tile_cap / th2));             // hand back what the clamp on th freed
+                const int ce = (int)me, cu = (int)mu;
+                e0 = min(max(ce - tw2 / 2, e0), e0 + tw - tw2);
+                u0 = min(max(cu - th2 / 2, u0), u0 + th - th2);
+                tw = tw2; th = th2;
             }
+            if (tw > a.tile_cap / 2) { e0 += (tw - a.tile_cap / 2) / 2; tw = a.tile_cap / 2; }   // absurdly wide bitmaps
             win.e0 = e0; win.u0 = u0; win.tw = tw; win.th = th;
+            // larger footprints (near, oblique heliostats) are swept in several passes over row bands
+            win.ths = min(th, a.tile_cap / tw);
+            win.npass = win.ths >= th ? 1 : (th - 1 + win.ths - 2) / (win.ths - 1);
             // |contribution| <= |I| = |mag k_ext k_refl| |r.m| <= |mag k_ext k_refl| |d| |m| (the scatter
             // matrix is a rotation); 2^ex > bound, so |v| * 2^(22-ex) < 2^22.
             const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
@@ -307,7 +343,7 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
                                                              unsigned int* __restrict__ counts)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned tile[];
-    __shared__ float s_red[8][16];     // per-wave partials: emin, emax, umin, umax, ke, ku, angmax, dmax2
+    __shared__ float s_red[13][16];    // per-wave partials: emin, emax, umin, umax, ke, ku, angmax, dmax2, sums
     __shared__ Window s_win;
     __shared__ unsigned s_cnt[2];
 
@@ -333,7 +369,16 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     if (tid < 2) s_cnt[tid] = 0;
     compute_window<INTERLEAVED>(a, pl, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
-    const int npx = win.tw * win.th;
+    const unsigned twm1 = (unsigned)(win.tw - 1), uthm1 = (unsigned)(win.th - 1);
+    unsigned n_on = 0, n_int = 0;
+    const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
+    const float Wf = (float)a.W, Hf = (float)a.Hh;
+  for (int pass = 0; pass < win.npass; ++pass) {
+    const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
+    const int pth = min(win.ths, win.u0 + win.th - pu0);                 // rows held in LDS in this pass
+    const unsigned thm1 = (unsigned)(pth - 1);
+    const bool first = pass == 0;
+    const int npx = win.tw * pth;
     for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
     __syncthreads();
 
@@ -341,10 +386,6 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     // Every ray issues its four LDS adds unconditionally: rays that are off the bitmap or outside the
     // window add 0 to a dummy cell behind the window (no divergence in the common path); the rare
     // in-bitmap-but-outside-window ray goes to global memory.
-    unsigned n_on = 0, n_int = 0;
-    const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
-    const unsigned twm1 = (unsigned)(win.tw - 1), thm1 = (unsigned)(win.th - 1);
-    const float Wf = (float)a.W, Hf = (float)a.Hh;
     PendingSplat ps = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
         const float4 o = org[p];
@@ -360,9 +401,11 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             const RaySplat hs = hit_and_weights(pl, o, numer, rx, ry, rz, Wf, Hf);
             const float I = (hs.I0 * pl.k_ext) * pl.k_refl;             // (1 - blocked) == 1 (:482-487)
             // ray counters live in SGPRs: one v_cmp + s_bcnt1 per counter instead of per-lane adds
-            n_on += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && hs.I0 > 0.0f));
-            n_int += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && I > 0.0f));
-            const int le = hs.ie - win.e0, lu = hs.iu - win.u0;
+            if (first) {                                                    // wave-uniform
+                n_on += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && hs.I0 > 0.0f));
+                n_int += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && I > 0.0f));
+            }
+            const int le = hs.ie - win.e0, lu = hs.iu - pu0;
             const bool inwin = hs.on && (unsigned)le < twm1 && (unsigned)lu < thm1;
             const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;   // flat row iu
             const int cell_hi = inwin ? cell_lo + win.tw : dummy;                  // flat row iu + 1
@@ -383,7 +426,9 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             ps.o3 = atomicAdd(tile + cell_lo + 1, ps.q3);
             ps.o4 = atomicAdd(tile + cell_lo, ps.q4);
 #endif
-            if (__builtin_expect(wave_any(hs.on && !inwin), 0) && hs.on && !inwin) {
+            // outside the union window (not merely outside this pass's band): global atomics, once
+            const bool stray = first && hs.on && !((unsigned)le < twm1 && (unsigned)(hs.iu - win.u0) < uthm1);
+            if (__builtin_expect(wave_any(stray), 0) && stray) {
                 float* row_hi = bitmap + (int64_t)(a.Hh - 2 - hs.iu) * a.W + hs.ie;
                 float* row_lo = row_hi + a.W;
                 atomicAdd(row_hi, hs.cle * hs.chu * I); atomicAdd(row_hi + 1, hs.che * hs.chu * I);
@@ -419,18 +464,20 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         }
     }
     resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
-    if (lane == 0) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_on); }   // already wave totals
+    if (first && lane == 0) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_on); }   // already wave totals
     __syncthreads();
 
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
-    for (int row = wave; row < win.th; row += nwaves) {
-        float* g = bitmap + (int64_t)(a.Hh - 1 - (win.u0 + row)) * a.W + win.e0;
+    for (int row = wave; row < pth; row += nwaves) {
+        float* g = bitmap + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
         const unsigned* trow = tile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) {
             const unsigned q = trow[c];
             if (q != 0u) atomicAdd(g + c, (float)q * win.inv_scale);
         }
     }
+    __syncthreads();   // the band is flushed before the next pass re-zeroes the tile
+  }
     if (tid < 2 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
@@ -543,7 +590,7 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
                                                              float4* __restrict__ grad_normals)
 {
     extern __shared__ __attribute__((aligned(16))) float gtile[];
-    __shared__ float s_red[8][16];
+    __shared__ float s_red[13][16];
     __shared__ Window s_win;
 
     const int bid = blockIdx.x;
@@ -566,18 +613,24 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
 
     compute_window<INTERLEAVED>(a, pl, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
+  for (int pass = 0; pass < win.npass; ++pass) {
+    const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
+    const int pth = min(win.ths, win.u0 + win.th - pu0);
+    const bool first = pass == 0;
     // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped
-    for (int row = wave; row < win.th; row += nwaves) {
-        const float* g = G + (int64_t)(a.Hh - 1 - (win.u0 + row)) * a.W + win.e0;
+    for (int row = wave; row < pth; row += nwaves) {
+        const float* g = G + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
         float* trow = gtile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) trow[c] = g[c];
     }
+    if (tid < 2) gtile[a.tile_cap + tid] = 0.0f;
     __syncthreads();
 
     const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
     const float sx = pl.wm1 / pl.w, sz = pl.hm1 / pl.h;
     const float Wf = (float)a.W, Hf = (float)a.Hh;
-    const unsigned twm1 = (unsigned)(win.tw - 1), thm1 = (unsigned)(win.th - 1);
+    const unsigned twm1 = (unsigned)(win.tw - 1), thm1 = (unsigned)(pth - 1), uthm1 = (unsigned)(win.th - 1);
+    const int dummy = a.tile_cap;                    // two spare cells holding 0
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
         const float4 o = org[p];
         const float4 n = nrm[p];
@@ -585,42 +638,50 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
         float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;
+        // One ray, branch-free on the common path: a ray that is masked, owned by another pass, or (rarely)
+        // a stray gets zero gradient weights instead of an early exit, and reads the spare LDS cells.
         auto trace_one = [&](const float u, const float e) {
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
+            // forward re-computation: exact reference arithmetic (decides which cells the ray touched)
             const RaySplat hs = hit_and_weights(pl, o, numer, rx, ry, rz, Wf, Hf);
-            if (!hs.on) return;                       // masked rays carry no gradient (masks are constants)
-            const float I = (hs.I0 * pl.k_ext) * pl.k_refl;
-            float g1, g2, g3, g4;
-            const int le = hs.ie - win.e0, lu = hs.iu - win.u0;
-            if ((unsigned)le < twm1 && (unsigned)lu < thm1) {
-                const float* lo = gtile + (int)__umul24(lu, win.tw) + le;
-                const float* hi = lo + win.tw;
-                g1 = hi[0]; g2 = hi[1]; g3 = lo[1]; g4 = lo[0];
-            } else {
+            const int le = hs.ie - win.e0, lu = hs.iu - pu0;
+            const bool incol = (unsigned)le < twm1;
+            const bool inwin = hs.on && incol && (unsigned)lu < thm1;
+            const bool stray = first && hs.on && !(incol && (unsigned)(hs.iu - win.u0) < uthm1);
+            const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;
+            const int cell_hi = inwin ? cell_lo + win.tw : dummy;
+            float g1 = gtile[cell_hi], g2 = gtile[cell_hi + 1], g3 = gtile[cell_lo + 1], g4 = gtile[cell_lo];
+            if (__builtin_expect(wave_any(stray), 0) && stray) {      // outside the union window: global gather
                 const float* g_hi = G + (int64_t)(a.Hh - 2 - hs.iu) * a.W + hs.ie;
                 const float* g_lo = g_hi + a.W;
                 g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
             }
-            const float gI = hs.cle * hs.chu * g1 + hs.che * hs.chu * g2 + hs.che * hs.clu * g3 + hs.cle * hs.clu * g4;
-            const float g_be = ((hs.chu * g2 + hs.clu * g3) - (hs.chu * g1 + hs.clu * g4)) * I;
-            const float g_bu = ((hs.cle * g1 + hs.che * g2) - (hs.che * g3 + hs.cle * g4)) * I;
-            const float g_hx = -g_be * sx;          // be = wm1 - te / w * wm1
-            const float g_hz = g_bu * sz;
-            const float g_t = g_hx * rx + g_hz * rz;
-            const float inv_a = 1.0f / hs.a;
-            const float g_a = -kI * gI - g_t * hs.t * inv_a;          // t = numer / a
-            const float g_numer = g_t * inv_a;
-            const float grx = g_hx * hs.t + g_a * pl.mx;
-            const float gry = g_a * pl.my;
-            const float grz = g_hz * hs.t + g_a * pl.mz;
-            gox += g_hx - g_numer * pl.mx;
-            goy += -g_numer * pl.my;
-            goz += g_hz - g_numer * pl.mz;
-            gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
-            gdy += -m.su * grx + m.m11 * gry + m.m21 * grz;
-            gdz += -m.se * gry + m.ce * grz;
+            const float I = (inwin || stray) ? (hs.I0 * pl.k_ext) * pl.k_refl : 0.0f;
+            const float kIm = (inwin || stray) ? kI : 0.0f;
+            // gradient arithmetic: fused multiply-adds are welcome here (no parity constraint on the op order)
+            {
+#pragma clang fp contract(fast)
+                const float gI = hs.cle * (hs.chu * g1 + hs.clu * g4) + hs.che * (hs.chu * g2 + hs.clu * g3);
+                const float g_be = (hs.chu * (g2 - g1) + hs.clu * (g3 - g4)) * I;
+                const float g_bu = (hs.cle * (g1 - g4) + hs.che * (g2 - g3)) * I;
+                const float g_hx = -g_be * sx;          // be = wm1 - te / w * wm1
+                const float g_hz = g_bu * sz;
+                const float g_t = g_hx * rx + g_hz * rz;
+                const float inv_a = __builtin_amdgcn_rcpf(hs.a);          // 1 ulp is plenty for a gradient
+                const float g_numer = g_t * inv_a;
+                const float g_a = -kIm * gI - g_numer * hs.t;             // t = numer / a
+                const float grx = g_hx * hs.t + g_a * pl.mx;
+                const float gry = g_a * pl.my;
+                const float grz = g_hz * hs.t + g_a * pl.mz;
+                gox += g_hx - g_numer * pl.mx;
+                goy -= g_numer * pl.my;
+                goz += g_hz - g_numer * pl.mz;
+                gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
+                gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
+                gdz += m.ce * grz - m.se * gry;
+            }
         };
         // distortion stream prefetched in groups of four samples (see the forward kernel)
         const int lane_off = p * (int)a.sp;
@@ -656,11 +717,17 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
             float* pn = reinterpret_cast<float*>(grad_normals + idx);
             atomicAdd(po + 0, go.x); atomicAdd(po + 1, go.y); atomicAdd(po + 2, go.z);
             atomicAdd(pn + 0, gn.x); atomicAdd(pn + 1, gn.y); atomicAdd(pn + 2, gn.z); atomicAdd(pn + 3, gn.w);
-        } else {
+        } else if (first) {
             grad_origins[idx] = go;
             grad_normals[idx] = gn;
+        } else {                                      // this thread owns the point in every pass: plain add
+            const float4 o0 = grad_origins[idx], n0 = grad_normals[idx];
+            grad_origins[idx] = make_float4(o0.x + go.x, o0.y + go.y, o0.z + go.z, 0.0f);
+            grad_normals[idx] = make_float4(n0.x + gn.x, n0.y + gn.y, n0.z + gn.z, n0.w + gn.w);
         }
     }
+    __syncthreads();   // every wave is done with this band before it is overwritten
+  }
 }
 
 // out[t] = sum_h [target_idx[h] == t] bitmaps[h]   (heliostat_ray_tracer.py:593-608)
@@ -729,7 +796,9 @@ struct FwdConfig {
     int tile_cap;       // window capacity in pixels
     int target_blocks;  // grid size to aim for when chunking samples
     int min_chunk;      // fewest samples per workgroup worth a window build + flush
-    int p_block;        // target points per workgroup
+    int p_block;        // target points per workgroup, forward
+    int p_block_bwd;    // ... backward (gathers are cheaper than atomics when a ray strays: larger blocks pay)
+    int multipass_ratio;
 };
 
 static int env_int(const char* name, int dflt)
@@ -745,28 +814,33 @@ static FwdConfig fwd_config()
     c.variant = (v && v[0] == 'g') ? 1 : 0;
     c.block = env_int("ARTIST_HIP_FWD_BLOCK", 1024);
     if (c.block < 64 || c.block > 1024 || (c.block % 64) != 0) c.block = 1024;
-    int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 144);
+    int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 152);
     if (kb < 4) kb = 4;
     if (kb > 152) kb = 152;
     c.tile_cap = kb * 256;   // 4-byte fixed-point cells
     c.target_blocks = env_int("ARTIST_HIP_FWD_BLOCKS", 512);
     c.min_chunk = env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
-    c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 2048);
+    c.multipass_ratio = env_int("ARTIST_HIP_FWD_MULTIPASS", 2);
+    if (c.multipass_ratio < 1) c.multipass_ratio = 1;
+    c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
     if (c.p_block < 64) c.p_block = 64;
+    c.p_block_bwd = env_int("ARTIST_HIP_BWD_PBLOCK", 2048);
+    if (c.p_block_bwd < 64) c.p_block_bwd = 64;
     return c;
 }
 
 // Launch geometry of the windowed kernels.  p_block: a multiple of the block size close to
 // P / ceil(P / 2048) so that point blocks are balanced; samples are chunked only as far as needed to
 // fill the chip (each chunk pays a window build + flush).
-static void window_geometry(TraceArgs& a, const FwdConfig& cfg)
+static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_target)
 {
     const int bs = cfg.block;
-    const int nblk = (a.P + cfg.p_block - 1) / cfg.p_block;
+    const int nblk = (a.P + p_block_target - 1) / p_block_target;
     const int pb = ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
     a.p_block = pb;
     a.n_pblocks = (a.P + pb - 1) / pb;
     a.tile_cap = cfg.tile_cap;
+    a.multipass_ratio = cfg.multipass_ratio;
     const int64_t base = (int64_t)a.H * a.n_pblocks;
     int64_t want = (cfg.target_blocks + base - 1) / base;
     if (want < 1) want = 1;
@@ -802,7 +876,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
     const FwdConfig cfg = fwd_config();
     if (cfg.variant == 0) {
-        window_geometry(a, cfg);
+        window_geometry(a, cfg, cfg.p_block);
         const int64_t base = (int64_t)a.H * a.n_pblocks;
         const int64_t blocks = base * a.n_rchunks;
         if (blocks > 2147483647LL) return ART_EINVAL;
@@ -853,10 +927,10 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     const bool il = interleaved_layout(a);
     const FwdConfig cfg = fwd_config();
     if (cfg.variant == 0) {
-        window_geometry(a, cfg);
+        window_geometry(a, cfg, cfg.p_block_bwd);
         const int64_t blocks = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (blocks > 2147483647LL) return ART_EINVAL;
-        const size_t lds = (size_t)a.tile_cap * sizeof(float);
+        const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float);
         const bool atomic_out = a.n_rchunks > 1;
         if (atomic_out) {
             ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
