@@ -112,6 +112,7 @@ extern "C" int art_align_fwd(const float* points, const float* normals, const fl
                              int64_t P, float* out_points, float* out_normals, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (H == 0) return ART_OK;
     if (!points || !normals || !orientation || !out_points || !out_normals || H < 0 || P <= 0 || P > 2147483647LL ||
         H * ((P + kAlignBlock - 1) / kAlignBlock) > 2147483647LL)
         return ART_EINVAL;
@@ -130,6 +131,7 @@ extern "C" int art_align_bwd(const float* points, const float* normals, const fl
                              float* grad_points, float* grad_normals, float* grad_orientation, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (H == 0) return ART_OK;
     if (!orientation || !grad_out_points || !grad_out_normals || !grad_points || !grad_normals || H < 0 || P <= 0 ||
         P > 2147483647LL || H * ((P + kAlignBlock - 1) / kAlignBlock) > 2147483647LL ||
         (grad_orientation && (!points || !normals)))

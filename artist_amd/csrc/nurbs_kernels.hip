@@ -257,7 +257,19 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
     __syncthreads();
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int h = hf / a.F, f = hf % a.F;
-    for (int m = threadIdx.x; m < a.M; m += blockDim.x) {
+    // Neighbouring evaluation points share their 16 control points, so lanes that walk the points in order
+    // would all add to the same LDS cells (up to 64-way serialisation).  Walk them in a strided order instead
+    // (i -> i*K mod M, K prime and coprime to M: a bijection) so that the lanes of a wave sit in different
+    // knot spans; the gradient loads become gathers, but they are 32 B per point and L2-resident.
+    int K = 1;
+    {
+        const int primes[8] = {61, 59, 53, 47, 43, 41, 37, 31};
+#pragma unroll
+        for (int i = 7; i >= 0; --i)
+            if (a.M % primes[i] != 0) K = primes[i];
+    }
+    for (int i = threadIdx.x; i < a.M; i += blockDim.x) {
+        const int m = (int)(((int64_t)i * K) % a.M);
         const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * m);
         Eval<DEG> E;
         evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
@@ -361,6 +373,7 @@ extern "C" int art_nurbs_fwd(const float* control_points, const float* eval_poin
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     NurbsArgs a;
+    if (H == 0) return ART_OK;
     if (!points || !normals ||
         !fill_nurbs(a, control_points, eval_points, uv_sh, uv_sf, knots_u, knots_v, canting, translations, p, q,
                     uniform, n_unique_u, n_unique_v, H, F, M, nu, nv))
@@ -385,6 +398,7 @@ extern "C" int art_nurbs_bwd(const float* control_points, const float* eval_poin
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     NurbsArgs a;
     static const float dummy_transl[4] = {0, 0, 0, 0};
+    if (H == 0) return ART_OK;
     if (!grad_points || !grad_normals || !grad_control_points ||
         !fill_nurbs(a, control_points, eval_points, uv_sh, uv_sf, knots_u, knots_v, canting,
                     canting ? dummy_transl : nullptr, p, q, uniform, n_unique_u, n_unique_v, H, F, M, nu, nv))

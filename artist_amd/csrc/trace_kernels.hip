@@ -864,6 +864,10 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
+    if (H == 0) {   // empty field: nothing to trace; a per-target bitmap is still all zeros
+        if (mode == 1 && flux && T > 0 && W > 0 && Hh > 0) ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * T * Hh * W, stream));
+        return ART_OK;
+    }
     if (!flux || !factors ||
         !fill_args(a, origins, normals, incident, dist_u, dist_e, dist_sh, dist_sr, dist_sp, target_idx,
                    plane_centers, plane_normals, plane_dims, ray_magnitude, extinction, reflectivity, H, R, P, T, W,
@@ -916,6 +920,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
+    if (H == 0) return ART_OK;
     if (!grad_flux || !grad_origins || !grad_normals ||
         !fill_args(a, origins, normals, incident, dist_u, dist_e, dist_sh, dist_sr, dist_sp, target_idx,
                    plane_centers, plane_normals, plane_dims, ray_magnitude, extinction, reflectivity, H, R, P, T, W,

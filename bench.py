@@ -54,7 +54,8 @@ def cpu_baseline(args, cp_host, canting, transl, uv, orientation, incident, plan
     import numpy as np
 
     import oracle
-    threads = oracle.max_threads()
+    # the GPU box gives a one-GPU job a 16-core share of the host; stay inside it
+    threads = max(1, min(oracle.max_threads(), int(os.environ.get("ARTIST_CPU_THREADS", "16"))))
     H1 = cp_host.shape[0]
     R, P = args.rays, 4 * args.n_eval * args.n_eval
     rng = np.random.default_rng(7)
@@ -97,11 +98,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm (xGMI inside a node).  ARTIST_BENCH_BACKEND=gloo exists only to rehearse the
+        # N>1 code path with several ranks sharing one GPU (RCCL refuses duplicate devices).
+        backend = os.environ.get("ARTIST_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from artist_amd import HeliostatRayTracer, NURBSSurfaces
     from artist_amd.distributed import all_reduce_sum, owned_heliostats
@@ -218,10 +226,20 @@ def main():
     bytes_fwd = rays_local * 8 + H * P * 32 + H * 256 * 256 * 4
     bytes_bwd = rays_local * 8 + H * P * 32 + H * P * 32 + H * 256 * 256 * 4
     if ms_bwd >= ms_fwd:
-        dom = dict(kernel="trace_bwd_kernel", ms=ms_bwd, bytes=bytes_bwd)
+        dom = dict(kernel="trace_bwd_lds_kernel", ms=ms_bwd, bytes=bytes_bwd)
     else:
-        dom = dict(kernel="trace_fwd_kernel", ms=ms_fwd, bytes=bytes_fwd)
+        dom = dict(kernel="trace_fwd_lds_kernel", ms=ms_fwd, bytes=bytes_fwd)
     achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r01_hbm_traffic.json,
+    # FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes); only valid for the profiled workload.
+    traffic = None
+    try:
+        prof = json.load(open(ROOT / "profiles" / "r01_hbm_traffic.json"))
+        c = prof["config"]
+        if (c["heliostats"], c["rays_per_point"], c["points_per_heliostat"]) == (H, R, P) and world == 1:
+            traffic = prof[dom["kernel"]]["total_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         total_rays = H_total * R * P
@@ -245,9 +263,11 @@ def main():
                          "ms_per_step": dt_fwd / args.steps * 1e3},
             "kernels": {"trace_fwd_ms": ms_fwd, "trace_bwd_ms": ms_bwd,
                         "trace_fwd_rays_per_s": rays_local / (ms_fwd * 1e-3),
-                        "trace_bwd_rays_per_s": rays_local / (ms_bwd * 1e-3)},
+                        "trace_bwd_rays_per_s": rays_local / (ms_bwd * 1e-3),
+                        "trace_fwd_GBps": bytes_fwd / (ms_fwd * 1e-3) / 1e9,
+                        "trace_bwd_GBps": bytes_bwd / (ms_bwd * 1e-3) / 1e9},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -393,3 +393,91 @@ def test_align_surfaces(golden, name):
     if np.linalg.norm(d["grad_orientation"]) > 0:
         assert rel_l2(n(ori.grad), d["grad_orientation"]) < 1e-4
         assert rel_l2(n(pts.grad), d["grad_nurbs_points"]) < 1e-5
+
+
+# ---- edge cases the reference's tests exercise: empty, ragged, minimal and non-square shapes -------------------
+def _random_scene(H, R, P, W, Hh, seed=0, T=2, spread=2e-3):
+    g = torch.Generator().manual_seed(seed)
+    origins = torch.cat([torch.rand(H, P, 3, generator=g) * 3 - 1.5 + torch.tensor([0.0, 60.0, 0.0]), torch.ones(H, P, 1)], -1)
+    aim = torch.tensor([0.0, 0.0, 40.0])
+    to_aim = torch.nn.functional.normalize(aim - origins[..., :3], dim=-1)
+    nrm = torch.nn.functional.normalize(to_aim - torch.tensor([0.0, 1.0, 0.0]) + 2e-3 * torch.randn(H, P, 3, generator=g), dim=-1)
+    normals = torch.cat([nrm, torch.zeros(H, P, 1)], -1)
+    incident = torch.tensor([[0.0, 1.0, 0.0, 0.0]]).repeat(H, 1)
+    both = spread * torch.randn(H, R, P, 2, generator=g)
+    centers = torch.tensor([[0.0, 0.0, 40.0, 1.0], [0.5, -1.0, 41.0, 1.0]])[:T]
+    pn = torch.nn.functional.normalize(torch.tensor([[0.0, 1.0, 0.0, 0.0], [0.1, 1.0, 0.2, 0.0]]), dim=1)[:T]
+    dims = torch.tensor([[5.0, 4.0], [3.0, 6.0]])[:T]
+    tix = torch.arange(H) % T
+    return origins, normals, incident, both, tix, centers, pn, dims, (W, Hh)
+
+
+@pytest.mark.parametrize("H,R,P,W,Hh", [(1, 1, 1, 2, 2), (3, 1, 63, 5, 3), (2, 7, 65, 17, 300), (5, 3, 1025, 64, 64),
+                                        (1, 33, 2049, 256, 8), (4, 2, 4097, 33, 47)])
+def test_ragged_shapes(H, R, P, W, Hh):
+    """Point counts that are not multiples of the wave / block size, sample counts that are not multiples of the
+    prefetch group, 1-ray / 1-point inputs, tiny and non-square bitmaps, several targets - forward and backward."""
+    from artist_amd import trace_rays
+    o, nrm, inc, both, tix, c, pn, dims, res = _random_scene(H, R, P, W, Hh, seed=H * 1000 + P)
+    bd = both.to(DEV)
+    od, nd = o.to(DEV).requires_grad_(True), nrm.to(DEV).requires_grad_(True)
+    flux, fac = trace_rays(od, nd, inc.to(DEV), bd[..., 0], bd[..., 1], tix.to(DEV), c.to(DEV), pn.to(DEV),
+                           dims.to(DEV), ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=res)
+    o_flux, o_fac = oracle.trace_fwd(o.numpy(), nrm.numpy(), inc.numpy(), both[..., 0].numpy(), both[..., 1].numpy(),
+                                     tix.numpy(), c.numpy(), pn.numpy(), dims.numpy(), res, 0.7, 0.05, 0.9)
+    assert flux.shape == (H, Hh, W)
+    np.testing.assert_array_equal(n(fac), o_fac)
+    scale = float(np.abs(o_flux).max()) + 1e-30
+    np.testing.assert_allclose(n(flux), o_flux, rtol=0, atol=2e-3 * scale)     # per-ray 1e-4 px noise, few rays per pixel
+    assert abs(float(flux.detach().sum()) - float(o_flux.sum())) <= 1e-5 * abs(float(o_flux.sum())) + 1e-6
+    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    (flux * w).sum().backward()
+    go, gn = oracle.trace_bwd(o.numpy(), nrm.numpy(), inc.numpy(), both[..., 0].numpy(), both[..., 1].numpy(),
+                              tix.numpy(), c.numpy(), pn.numpy(), dims.numpy(), res, n(w), 0.7, 0.05, 0.9)
+    if np.linalg.norm(go) > 0:
+        assert rel_l2(n(od.grad), go) < 5e-3 and rel_l2(n(nd.grad), gn) < 5e-3   # cell flips at pixel borders
+
+
+def test_empty_field_and_all_rays_missing():
+    from artist_amd import per_target_sum, trace_rays
+    o, nrm, inc, both, tix, c, pn, dims, res = _random_scene(2, 3, 70, 16, 16)
+    bd = both.to(DEV)
+    # H = 0: empty outputs, no launch
+    flux, fac = trace_rays(o[:0].to(DEV), nrm[:0].to(DEV), inc[:0].to(DEV), bd[:0, ..., 0], bd[:0, ..., 1], tix[:0].to(DEV),
+                           c.to(DEV), pn.to(DEV), dims.to(DEV), resolution=res)
+    assert flux.shape == (0, 16, 16) and fac.shape == (3, 0)
+    assert float(per_target_sum(flux, tix[:0].to(DEV), 2).abs().sum()) == 0
+    # every ray hits the BACK of the target (plane normals flipped): zero flux, zero factors, zero gradients
+    od = o.to(DEV).requires_grad_(True)
+    flux, fac = trace_rays(od, nrm.to(DEV), inc.to(DEV), bd[..., 0], bd[..., 1], tix.to(DEV), c.to(DEV), -pn.to(DEV),
+                           dims.to(DEV), resolution=res)
+    assert float(flux.abs().sum()) == 0 and float(fac[:2].abs().sum()) == 0 and bool((fac[2] == 1).all())
+    flux.sum().backward()
+    assert float(od.grad.abs().sum()) == 0
+
+
+def test_nurbs_nonuniform_knots_and_many_points():
+    """uniform=False span search with clamped non-uniform knot vectors swapped in (surfaces.py:209-243), M not a
+    multiple of the block size, evaluation points on knots and at both ends."""
+    from artist_amd import NURBSSurfaces
+    g = torch.Generator().manual_seed(5)
+    cp = torch.rand(2, 2, 7, 6, 3, generator=g)
+    uv = torch.rand(2, 2, 777, 2, generator=g)
+    uv[0, 0, :6, 0] = torch.tensor([0.0, 0.1, 0.7, 1.0, 1.0 - 1e-6, 0.4])
+    uv[0, 0, :6, 1] = torch.tensor([1.0, 0.0, 0.35, 0.9, 0.5, 0.35])
+    ku = torch.tensor([0.0, 0.0, 0.0, 0.0, 0.1, 0.4, 0.7, 1.0, 1.0, 1.0, 1.0])
+    kv = torch.tensor([0.0, 0.0, 0.0, 0.35, 0.5, 0.9, 1.0, 1.0, 1.0])
+    surf = NURBSSurfaces(torch.tensor([3, 2]), cp.to(DEV).requires_grad_(True), uniform=False, device=DEV)
+    surf.knot_vectors_u = ku.to(DEV)[None, None].expand(2, 2, -1)
+    surf.knot_vectors_v = kv.to(DEV)[None, None].expand(2, 2, -1)
+    pts, nrm = surf(uv.to(DEV), None, None)
+    o_pts, o_nrm = oracle.nurbs_fwd(cp.numpy(), uv.numpy(), [3, 2], knots_u=ku.numpy(), knots_v=kv.numpy(), uniform=False)
+    np.testing.assert_allclose(n(pts), o_pts, rtol=0, atol=1e-6)
+    ok = np.linalg.norm(o_nrm[..., :3], axis=-1) > 0.5          # degenerate normals (zero cross product) excluded
+    np.testing.assert_allclose(n(nrm)[ok], o_nrm[ok], rtol=0, atol=5e-5)
+    gp = torch.rand(pts.shape, generator=g)
+    gn = torch.rand(nrm.shape, generator=g) * torch.from_numpy(ok[..., None].astype(np.float32))
+    torch.autograd.backward([pts, nrm], [gp.to(DEV), gn.to(DEV)])
+    o_g = oracle.nurbs_bwd(cp.numpy(), uv.numpy(), [3, 2], gp.numpy(), gn.numpy(), knots_u=ku.numpy(), knots_v=kv.numpy(),
+                           uniform=False)
+    assert rel_l2(n(surf.control_points.grad), o_g) < 1e-4
