@@ -370,14 +370,17 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     compute_window<INTERLEAVED>(a, pl, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
     const unsigned twm1 = (unsigned)(win.tw - 1), uthm1 = (unsigned)(win.th - 1);
-    unsigned n_on = 0, n_int = 0;
     const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
     const float Wf = (float)a.W, Hf = (float)a.Hh;
+    // lean mode needs I0 > 0 and I > 0 to be implied by `valid`: positive, sanely scaled intensity factors
+    const bool lean = pl.mag >= 1e-6f && pl.k_ext >= 1e-6f && pl.k_refl >= 1e-6f && pl.mag <= 1e6f && pl.k_ext <= 1e6f &&
+                      pl.k_refl <= 1e6f;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
     const int pth = min(win.ths, win.u0 + win.th - pu0);                 // rows held in LDS in this pass
     const unsigned thm1 = (unsigned)(pth - 1);
     const bool first = pass == 0;
+    unsigned n_valid = 0, n_int = 0;     // rays with I0 > 0 / I > 0 among the valid ones (wave totals)
     const int npx = win.tw * pth;
     for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
     __syncthreads();
@@ -393,69 +396,89 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         float4 d; float s;
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
-        // One ray: scatter -> hit -> weights -> 4 pipelined LDS adds.
+        // One ray: scatter -> hit -> weights -> 4 pipelined LDS adds.  Ray arithmetic is the reference's
+        // (ray_math.hpp); the masks are reduced to the one question the LDS path asks ("does this ray land inside
+        // this pass's window?"), and everything rare - a scatter angle beyond the small-angle kernel, a valid ray
+        // outside the window, a cell that may have wrapped - sits behind wave-uniform branches.
         auto trace_one = [&](const float u, const float e) {
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            const RaySplat hs = hit_and_weights(pl, o, numer, rx, ry, rz, Wf, Hf);
-            const float I = (hs.I0 * pl.k_ext) * pl.k_refl;             // (1 - blocked) == 1 (:482-487)
-            // ray counters live in SGPRs: one v_cmp + s_bcnt1 per counter instead of per-lane adds
-            if (first) {                                                    // wave-uniform
-                n_on += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && hs.I0 > 0.0f));
-                n_int += __popcll(__builtin_amdgcn_ballot_w64(hs.valid && I > 0.0f));
-            }
-            const int le = hs.ie - win.e0, lu = hs.iu - pu0;
-            const bool inwin = hs.on && (unsigned)le < twm1 && (unsigned)lu < thm1;
-            const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;   // flat row iu
-            const int cell_hi = inwin ? cell_lo + win.tw : dummy;                  // flat row iu + 1
+            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
+            const bool front = ah < 0.0f;
+            const float tt = numer / (front ? ah : 1.0f);                      // :130-131
+            const float hx = o.x + rx * tt, hz = o.z + rz * tt;                // :133-136
+            const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
+            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;    // :154-174
+            // :178-184.  0 <= x <= hi  <=>  x == med3(x, 0, hi)   (NaN compares false)
+            const bool valid = front && be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1) &&
+                               bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
+            const float be = pl.wm1 - be0;                                     // :195-197
+            const float tbe = truncf(be), tbu = truncf(bu);                    // heliostat_ray_tracer.py:674-675
+            const float cle = (tbe + 1.0f) - be, clu = (tbu + 1.0f) - bu, che = be - tbe, chu = bu - tbu;   // :694-700
+            const int ie = (int)tbe, iu = (int)tbu;
+            const int le = ie - win.e0, lu = iu - pu0;
+            const bool inwin = valid && (unsigned)le < twm1 && (unsigned)lu < thm1;     // implies ie+1 < W, iu+1 < Hh
+            const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;        // flat row iu
+            const int cell_hi = inwin ? cell_lo + win.tw : dummy;                       // flat row iu + 1
+            const float I0 = pl.mag * (-ah);                                            // geometry.py:139
+            const float I = (I0 * pl.k_ext) * pl.k_refl;                                // heliostat_ray_tracer.py:482-487
             // S is a power of two, so (w I) S == w (I S) bit for bit: scale the intensity once
             const float Is = inwin ? fabsf(I) * win.scale : 0.0f;
-            resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);          // previous ray's adds have landed
-            ps.q1 = cvt_nearest_u32(hs.cle * hs.chu * Is); ps.q2 = cvt_nearest_u32(hs.che * hs.chu * Is);
-            ps.q3 = cvt_nearest_u32(hs.che * hs.clu * Is); ps.q4 = cvt_nearest_u32(hs.cle * hs.clu * Is);
-            ps.ie = hs.ie; ps.iu = hs.iu;
+            // ray counters live in SGPRs (v_cmp + s_bcnt1).  With positive, sanely scaled intensity factors
+            // (`lean`) I0 > 0 and I > 0 follow from `valid` and one count serves both.
+            n_valid += __popcll(__builtin_amdgcn_ballot_w64(valid && (lean || I0 > 0.0f)));
+            if (!lean) n_int += __popcll(__builtin_amdgcn_ballot_w64(valid && I > 0.0f));
+            // the previous ray's adds have landed; a carry needs a cell that was already above 2^31 (q < 2^22)
+            if (__builtin_expect(wave_any(((ps.o1 | ps.o2 | ps.o3 | ps.o4) >> 31) != 0u), 0))
+                resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+            ps.q1 = cvt_nearest_u32(cle * chu * Is); ps.q2 = cvt_nearest_u32(che * chu * Is);
+            ps.q3 = cvt_nearest_u32(che * clu * Is); ps.q4 = cvt_nearest_u32(cle * clu * Is);
+            ps.ie = ie; ps.iu = iu;
 #ifdef ART_ABLATE_NO_LDS_ATOMICS   // diagnostic build: keep the operands alive, skip the LDS traffic
             asm volatile("" ::"v"(cell_hi), "v"(cell_lo), "v"(ps.q1), "v"(ps.q2), "v"(ps.q3), "v"(ps.q4));
-#elif defined(ART_ABLATE_NORTN)      // diagnostic build: non-returning adds (no carry detection)
-            atomicAdd(tile + cell_hi, ps.q1); atomicAdd(tile + cell_hi + 1, ps.q2);
-            atomicAdd(tile + cell_lo + 1, ps.q3); atomicAdd(tile + cell_lo, ps.q4);
 #else
             ps.o1 = atomicAdd(tile + cell_hi, ps.q1);
             ps.o2 = atomicAdd(tile + cell_hi + 1, ps.q2);
             ps.o3 = atomicAdd(tile + cell_lo + 1, ps.q3);
             ps.o4 = atomicAdd(tile + cell_lo, ps.q4);
 #endif
-            // outside the union window (not merely outside this pass's band): global atomics, once
-            const bool stray = first && hs.on && !((unsigned)le < twm1 && (unsigned)(hs.iu - win.u0) < uthm1);
-            if (__builtin_expect(wave_any(stray), 0) && stray) {
-                float* row_hi = bitmap + (int64_t)(a.Hh - 2 - hs.iu) * a.W + hs.ie;
-                float* row_lo = row_hi + a.W;
-                atomicAdd(row_hi, hs.cle * hs.chu * I); atomicAdd(row_hi + 1, hs.che * hs.chu * I);
-                atomicAdd(row_lo + 1, hs.che * hs.clu * I); atomicAdd(row_lo, hs.cle * hs.clu * I);
+            if (__builtin_expect(wave_any(valid && !inwin), 0)) {
+                // valid but not in this pass's band: another band's ray, the last pixel row/column
+                // (heliostat_ray_tracer.py:723-728), or a stray of the union window -> global atomics, once
+                const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
+                const bool in_union = (unsigned)le < twm1 && (unsigned)(iu - win.u0) < uthm1;
+#ifndef ART_ABLATE_NO_STRAYS   // diagnostic build drops the stray rays (wrong bitmap) to price them
+                if (first && valid && on && !in_union) {
+                    float* row_hi = bitmap + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
+                    float* row_lo = row_hi + a.W;
+                    atomicAdd(row_hi, cle * chu * I); atomicAdd(row_hi + 1, che * chu * I);
+                    atomicAdd(row_lo + 1, che * clu * I); atomicAdd(row_lo, cle * clu * I);
+                }
+#endif
             }
         };
         // Distortion stream, software-prefetched in groups of four samples: the loads of group g+1 are issued
-        // before group g is traced, so their HBM latency hides behind ~700 VALU instructions.  (The loads are
+        // before group g is traced, so their HBM latency hides behind ~600 instructions.  (The loads are
         // consumed in the iteration after the one that issues them; hipcc drains vmcnt at the loop back-edge,
         // by which time they have landed.)
         const int lane_off = p * (int)a.sp;
         const int nr = r1 - r0;
-        const float* __restrict__ bu = a.dist_u + dbase;     // wave-uniform
-        const float* __restrict__ be = a.dist_e + dbase;
+        const float* __restrict__ bu_ = a.dist_u + dbase;     // wave-uniform
+        const float* __restrict__ be_ = a.dist_e + dbase;
         float cu0, ce0, cu1, ce1, cu2, ce2, cu3, ce3;
-        load_dist_row<INTERLEAVED>(bu, be, lane_off, cu0, ce0);
-        load_dist_row<INTERLEAVED>(bu + (int64_t)min(1, nr - 1) * a.sr, be + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
-        load_dist_row<INTERLEAVED>(bu + (int64_t)min(2, nr - 1) * a.sr, be + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
-        load_dist_row<INTERLEAVED>(bu + (int64_t)min(3, nr - 1) * a.sr, be + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
+        load_dist_row<INTERLEAVED>(bu_, be_, lane_off, cu0, ce0);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr - 1) * a.sr, be_ + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr - 1) * a.sr, be_ + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr - 1) * a.sr, be_ + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
         for (int k = 0; k < nr; k += 4) {
             float nu0, ne0, nu1, ne1, nu2, ne2, nu3, ne3;
             const int64_t o4 = (int64_t)min(k + 4, nr - 1) * a.sr, o5 = (int64_t)min(k + 5, nr - 1) * a.sr;
             const int64_t o6 = (int64_t)min(k + 6, nr - 1) * a.sr, o7 = (int64_t)min(k + 7, nr - 1) * a.sr;
-            load_dist_row<INTERLEAVED>(bu + o4, be + o4, lane_off, nu0, ne0);
-            load_dist_row<INTERLEAVED>(bu + o5, be + o5, lane_off, nu1, ne1);
-            load_dist_row<INTERLEAVED>(bu + o6, be + o6, lane_off, nu2, ne2);
-            load_dist_row<INTERLEAVED>(bu + o7, be + o7, lane_off, nu3, ne3);
+            load_dist_row<INTERLEAVED>(bu_ + o4, be_ + o4, lane_off, nu0, ne0);
+            load_dist_row<INTERLEAVED>(bu_ + o5, be_ + o5, lane_off, nu1, ne1);
+            load_dist_row<INTERLEAVED>(bu_ + o6, be_ + o6, lane_off, nu2, ne2);
+            load_dist_row<INTERLEAVED>(bu_ + o7, be_ + o7, lane_off, nu3, ne3);
             trace_one(cu0, ce0);
             if (k + 1 < nr) trace_one(cu1, ce1);
             if (k + 2 < nr) trace_one(cu2, ce2);
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         }
     }
     resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
-    if (first && lane == 0) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_on); }   // already wave totals
+    if (first && lane == 0) { atomicAdd(&s_cnt[0], lean ? n_valid : n_int); atomicAdd(&s_cnt[1], n_valid); }   // wave totals
     __syncthreads();
 
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
@@ -638,43 +661,56 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
         float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;
-        // One ray, branch-free on the common path: a ray that is masked, owned by another pass, or (rarely)
-        // a stray gets zero gradient weights instead of an early exit, and reads the spare LDS cells.
+        // One ray.  The forward re-computation is the reference's arithmetic (it decides which cells the ray
+        // touched); masks are reduced to "inside this pass's window?", strays and other bands' rays are handled by
+        // a wave-uniform cold branch, and masked rays get zero gradient weights instead of an early exit.
         auto trace_one = [&](const float u, const float e) {
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            // forward re-computation: exact reference arithmetic (decides which cells the ray touched)
-            const RaySplat hs = hit_and_weights(pl, o, numer, rx, ry, rz, Wf, Hf);
-            const int le = hs.ie - win.e0, lu = hs.iu - pu0;
-            const bool incol = (unsigned)le < twm1;
-            const bool inwin = hs.on && incol && (unsigned)lu < thm1;
-            const bool stray = first && hs.on && !(incol && (unsigned)(hs.iu - win.u0) < uthm1);
+            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
+            const bool front = ah < 0.0f;
+            const float tt = numer / (front ? ah : 1.0f);
+            const float hx = o.x + rx * tt, hz = o.z + rz * tt;
+            const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;
+            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;
+            const bool valid = front && be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1) &&
+                               bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
+            const float be = pl.wm1 - be0;
+            const float tbe = truncf(be), tbu = truncf(bu);
+            const float cle = (tbe + 1.0f) - be, clu = (tbu + 1.0f) - bu, che = be - tbe, chu = bu - tbu;
+            const int ie = (int)tbe, iu = (int)tbu;
+            const int le = ie - win.e0, lu = iu - pu0;
+            const bool inwin = valid && (unsigned)le < twm1 && (unsigned)lu < thm1;
             const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;
             const int cell_hi = inwin ? cell_lo + win.tw : dummy;
             float g1 = gtile[cell_hi], g2 = gtile[cell_hi + 1], g3 = gtile[cell_lo + 1], g4 = gtile[cell_lo];
-            if (__builtin_expect(wave_any(stray), 0) && stray) {      // outside the union window: global gather
-                const float* g_hi = G + (int64_t)(a.Hh - 2 - hs.iu) * a.W + hs.ie;
-                const float* g_lo = g_hi + a.W;
-                g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
+            bool use = inwin;
+            if (__builtin_expect(wave_any(valid && !inwin), 0)) {
+                const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
+                const bool in_union = (unsigned)le < twm1 && (unsigned)(iu - win.u0) < uthm1;
+                if (first && valid && on && !in_union) {              // stray: global gather, once
+                    const float* g_hi = G + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
+                    const float* g_lo = g_hi + a.W;
+                    g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
+                    use = true;
+                }
             }
-            const float I = (inwin || stray) ? (hs.I0 * pl.k_ext) * pl.k_refl : 0.0f;
-            const float kIm = (inwin || stray) ? kI : 0.0f;
-            // gradient arithmetic: fused multiply-adds are welcome here (no parity constraint on the op order)
+            const float I = use ? ((pl.mag * (-ah)) * pl.k_ext) * pl.k_refl : 0.0f;
+            const float kIm = use ? kI : 0.0f;
             {
 #pragma clang fp contract(fast)
-                const float gI = hs.cle * (hs.chu * g1 + hs.clu * g4) + hs.che * (hs.chu * g2 + hs.clu * g3);
-                const float g_be = (hs.chu * (g2 - g1) + hs.clu * (g3 - g4)) * I;
-                const float g_bu = (hs.cle * (g1 - g4) + hs.che * (g2 - g3)) * I;
-                const float g_hx = -g_be * sx;          // be = wm1 - te / w * wm1
+                const float gI = cle * (chu * g1 + clu * g4) + che * (chu * g2 + clu * g3);
+                const float g_be = (chu * (g2 - g1) + clu * (g3 - g4)) * I;
+                const float g_bu = (cle * (g1 - g4) + che * (g2 - g3)) * I;
+                const float g_hx = -g_be * sx;
                 const float g_hz = g_bu * sz;
                 const float g_t = g_hx * rx + g_hz * rz;
-                const float inv_a = __builtin_amdgcn_rcpf(hs.a);          // 1 ulp is plenty for a gradient
-                const float g_numer = g_t * inv_a;
-                const float g_a = -kIm * gI - g_numer * hs.t;             // t = numer / a
-                const float grx = g_hx * hs.t + g_a * pl.mx;
+                const float g_numer = g_t * __builtin_amdgcn_rcpf(ah);
+                const float g_a = -kIm * gI - g_numer * tt;
+                const float grx = g_hx * tt + g_a * pl.mx;
                 const float gry = g_a * pl.my;
-                const float grz = g_hz * hs.t + g_a * pl.mz;
+                const float grz = g_hz * tt + g_a * pl.mz;
                 gox += g_hx - g_numer * pl.mx;
                 goy -= g_numer * pl.my;
                 goz += g_hz - g_numer * pl.mz;
@@ -686,21 +722,21 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
         // distortion stream prefetched in groups of four samples (see the forward kernel)
         const int lane_off = p * (int)a.sp;
         const int nr = r1 - r0;
-        const float* __restrict__ bu = a.dist_u + dbase;     // wave-uniform
-        const float* __restrict__ be = a.dist_e + dbase;
+        const float* __restrict__ bu_ = a.dist_u + dbase;     // wave-uniform
+        const float* __restrict__ be_ = a.dist_e + dbase;
         float cu0, ce0, cu1, ce1, cu2, ce2, cu3, ce3;
-        load_dist_row<INTERLEAVED>(bu, be, lane_off, cu0, ce0);
-        load_dist_row<INTERLEAVED>(bu + (int64_t)min(1, nr - 1) * a.sr, be + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
-        load_dist_row<INTERLEAVED>(bu + (int64_t)min(2, nr - 1) * a.sr, be + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
-        load_dist_row<INTERLEAVED>(bu + (int64_t)min(3, nr - 1) * a.sr, be + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
+        load_dist_row<INTERLEAVED>(bu_, be_, lane_off, cu0, ce0);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr - 1) * a.sr, be_ + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr - 1) * a.sr, be_ + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr - 1) * a.sr, be_ + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
         for (int k = 0; k < nr; k += 4) {
             float nu0, ne0, nu1, ne1, nu2, ne2, nu3, ne3;
             const int64_t o4 = (int64_t)min(k + 4, nr - 1) * a.sr, o5 = (int64_t)min(k + 5, nr - 1) * a.sr;
             const int64_t o6 = (int64_t)min(k + 6, nr - 1) * a.sr, o7 = (int64_t)min(k + 7, nr - 1) * a.sr;
-            load_dist_row<INTERLEAVED>(bu + o4, be + o4, lane_off, nu0, ne0);
-            load_dist_row<INTERLEAVED>(bu + o5, be + o5, lane_off, nu1, ne1);
-            load_dist_row<INTERLEAVED>(bu + o6, be + o6, lane_off, nu2, ne2);
-            load_dist_row<INTERLEAVED>(bu + o7, be + o7, lane_off, nu3, ne3);
+            load_dist_row<INTERLEAVED>(bu_ + o4, be_ + o4, lane_off, nu0, ne0);
+            load_dist_row<INTERLEAVED>(bu_ + o5, be_ + o5, lane_off, nu1, ne1);
+            load_dist_row<INTERLEAVED>(bu_ + o6, be_ + o6, lane_off, nu2, ne2);
+            load_dist_row<INTERLEAVED>(bu_ + o7, be_ + o7, lane_off, nu3, ne3);
             trace_one(cu0, ce0);
             if (k + 1 < nr) trace_one(cu1, ce1);
             if (k + 2 < nr) trace_one(cu2, ce2);
