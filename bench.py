@@ -82,7 +82,7 @@ def cpu_baseline(args, cp_host, canting, transl, uv, orientation, incident, plan
 
     probe = max(threads, 1)
     t_probe = run(probe)
-    scale = max(1, min(int(seconds / max(t_probe, 1e-3)), 16))
+    scale = max(1, min(int(seconds / max(t_probe, 1e-3)), 64))      # <= 1024 heliostats = 8 GB of host distortions
     h_count = probe * scale
     t = run(h_count) if scale > 1 else t_probe
     return {"value": h_count * R * P / t, "unit": "rays/s", "cores": threads, "kind": "port",
