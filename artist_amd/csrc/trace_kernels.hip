@@ -835,6 +835,7 @@ struct FwdConfig {
     int p_block;        // target points per workgroup, forward
     int p_block_bwd;    // ... backward (gathers are cheaper than atomics when a ray strays: larger blocks pay)
     int multipass_ratio;
+    int min_rays;       // rays per workgroup worth a window build + flush
 };
 
 static int env_int(const char* name, int dflt)
@@ -856,6 +857,7 @@ static FwdConfig fwd_config()
     c.tile_cap = kb * 256;   // 4-byte fixed-point cells
     c.target_blocks = env_int("ARTIST_HIP_FWD_BLOCKS", 512);
     c.min_chunk = env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
+    c.min_rays = env_int("ARTIST_HIP_FWD_MINRAYS", 100000);
     c.multipass_ratio = env_int("ARTIST_HIP_FWD_MULTIPASS", 2);
     if (c.multipass_ratio < 1) c.multipass_ratio = 1;
     c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
@@ -871,6 +873,10 @@ static FwdConfig fwd_config()
 static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_target)
 {
     const int bs = cfg.block;
+    // a window build + flush costs about as much as 1e4 rays: keep >= ~1e5 rays per workgroup when the sun has
+    // few samples per point (R = 1 field-scale prediction: one workgroup per heliostat)
+    if ((int64_t)p_block_target * a.R < cfg.min_rays) p_block_target = (int)((cfg.min_rays + a.R - 1) / a.R);
+    if (p_block_target > a.P) p_block_target = a.P;
     const int nblk = (a.P + p_block_target - 1) / p_block_target;
     const int pb = ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
     a.p_block = pb;
