@@ -78,8 +78,17 @@ def _dist_args(dist_u, dist_e):
     return [_i64(s // it) for s in dist_u.strides]
 
 
+def _cyl_args(cyl, dt):
+    """Cylindrical target tables -> ctypes arguments (6 pointers + count); ``cyl`` is None or a dict with
+    centers/normals/axes [Tc,4] and radii/heights/opening [Tc]."""
+    if cyl is None or len(cyl["radii"]) == 0:
+        return [None] * 6 + [_i64(0)], []
+    keep = [_c(cyl[k], dt) for k in ("centers", "normals", "axes", "radii", "heights", "opening")]
+    return [_p(a) for a in keep] + [_i64(keep[3].shape[0])], keep
+
+
 def trace_fwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-              resolution, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, debug=False):
+              resolution, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, debug=False, cyl=None):
     """Returns (flux [H,Hh,W], factors [3,H]) and, with debug=True, a dict of per-stage arrays."""
     dt = origins.dtype
     o, n, inc = _c(origins, dt), _c(normals, dt), _c(incident, dt)
@@ -99,8 +108,9 @@ def trace_fwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, p
         dbg = dict(reflected=np.empty((H, P, 4), dt), scattered=np.empty((H, R, P, 4), dt),
                    e_px=np.empty((H, R, P), dt), u_px=np.empty((H, R, P), dt),
                    distances=np.empty((H, R, P), dt), intensities=np.empty((H, R, P), dt))
+    cargs, _keep = _cyl_args(cyl, dt)
     rc = getattr(lib(), "orc_trace_fwd" + _sfx(dt))(
-        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d),
+        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d), *cargs,
         _dbl(ray_magnitude), _dbl(extinction), _dbl(reflectivity),
         _i64(H), _i64(R), _i64(P), _i64(T), _i64(W), _i64(Hh), _p(flux), _p(factors), ctypes.c_int(nthreads),
         _p(dbg.get("reflected")), _p(dbg.get("scattered")), _p(dbg.get("e_px")), _p(dbg.get("u_px")),
@@ -110,7 +120,7 @@ def trace_fwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, p
 
 
 def trace_bwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-              resolution, grad_flux, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0):
+              resolution, grad_flux, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, cyl=None):
     dt = origins.dtype
     o, n, inc = _c(origins, dt), _c(normals, dt), _c(incident, dt)
     du = np.asarray(dist_u, dtype=dt)
@@ -124,8 +134,9 @@ def trace_bwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, p
     g = _c(grad_flux, dt)
     assert g.shape == (H, Hh, W)
     go, gn = np.empty_like(o), np.empty_like(n)
+    cargs, _keep = _cyl_args(cyl, dt)
     rc = getattr(lib(), "orc_trace_bwd" + _sfx(dt))(
-        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d),
+        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d), *cargs,
         _dbl(ray_magnitude), _dbl(extinction), _dbl(reflectivity),
         _i64(H), _i64(R), _i64(P), _i64(T), _i64(W), _i64(Hh), _p(g), _p(go), _p(gn), ctypes.c_int(nthreads))
     _check(rc, "trace_bwd")
@@ -255,3 +266,22 @@ def splat(e_px, u_px, inten, resolution):
     _check(getattr(lib(), "orc_splat" + _sfx(dt))(_p(e), _p(u), _p(i), _i64(e.shape[0]), _i64(W), _i64(Hh), _p(out)),
            "splat")
     return out
+
+
+def line_cylinder(dirs, mags, origins, cyl, target, resolution=(256, 256)):
+    dt = dirs.dtype
+    dirs, mags, origins = _c(dirs, dt).reshape(-1, 4), _c(mags, dt).reshape(-1), _c(origins, dt).reshape(-1, 4)
+    N = dirs.shape[0]
+    outs = [np.empty(N, dtype=dt) for _ in range(4)]
+    cargs, _keep = _cyl_args(cyl, dt)
+    rc = getattr(lib(), "orc_line_cylinder" + _sfx(dt))(
+        _p(dirs), _p(mags), _p(origins), _i64(N), *cargs[:6], _i64(target), _i64(int(resolution[0])),
+        _i64(int(resolution[1])), *[_p(o) for o in outs])
+    _check(rc, "line_cylinder")
+    return outs
+
+
+def cyl_tables(d):
+    """The cylinder tables of a golden fixture as the ``cyl=`` argument."""
+    return dict(centers=d["cyl_centers"], normals=d["cyl_normals"], axes=d["cyl_axes"], radii=d["cyl_radii"],
+                heights=d["cyl_heights"], opening=d["cyl_opening"])

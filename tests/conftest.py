@@ -39,6 +39,7 @@ def golden():
 
 
 STAGE_CASES = ["small_deg3", "small_deg2_tilted", "small_offtarget", "mid_256"]
+CYL_CASES = ["small_cyl_mixed", "mid_cyl"]   # cylindrical receivers (ill-conditioned in fp32: see test_oracle_golden.py)
 
 
 def sun_distortions(n_heliostats, n_rays, n_points, covariance=4.3681e-06, mean=0.0, seed=7):

@@ -181,14 +181,15 @@ def build(case, dtype=torch.float32):
         normals=torch.tensor(case["target_normals"], dtype=dtype),
         dimensions=torch.tensor(case["target_dims"], dtype=dtype),
     )
+    cc = case.get("cyl_centers", [])
     cyl = TowerTargetAreasCylindrical(
-        names=[],
-        centers=torch.zeros(0, 4, dtype=dtype),
-        normals=torch.zeros(0, 4, dtype=dtype),
-        axes=torch.zeros(0, 4, dtype=dtype),
-        radii=torch.zeros(0, dtype=dtype),
-        heights=torch.zeros(0, dtype=dtype),
-        opening_angles=torch.zeros(0, dtype=dtype),
+        names=[f"c{i}" for i in range(len(cc))],
+        centers=torch.tensor(cc, dtype=dtype).reshape(-1, 4),
+        normals=torch.tensor(case.get("cyl_normals", []), dtype=dtype).reshape(-1, 4),
+        axes=torch.tensor(case.get("cyl_axes", []), dtype=dtype).reshape(-1, 4),
+        radii=torch.tensor(case.get("cyl_radii", []), dtype=dtype),
+        heights=torch.tensor(case.get("cyl_heights", []), dtype=dtype),
+        opening_angles=torch.tensor(case.get("cyl_opening", []), dtype=dtype),
     )
     tower = SolarTower([planar, cyl], device=CPU)
     sun = Sun(
@@ -206,7 +207,7 @@ def build(case, dtype=torch.float32):
     )
     return dict(
         scenario=scenario, group=group, nurbs_inputs=(degrees, cp, uv_full, canting_h, transl_h),
-        planar=planar, sun=sun, P=P,
+        planar=planar, cyl=cyl, sun=sun, P=P,
     )
 
 
@@ -285,6 +286,8 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
         ray_magnitude=np.float64(float(rt.ray_magnitude)), extinction=np.float64(ext), reflectivity=np.float64(refl),
         resolution=npy(res), target_centers=npy(b["planar"].centers), target_normals=npy(b["planar"].normals),
         target_dims=npy(b["planar"].dimensions), n_rays=np.int64(case["n_rays"]), seed=np.int64(case.get("seed", 7)),
+        cyl_centers=npy(b["cyl"].centers), cyl_normals=npy(b["cyl"].normals), cyl_axes=npy(b["cyl"].axes),
+        cyl_radii=npy(b["cyl"].radii), cyl_heights=npy(b["cyl"].heights), cyl_opening=npy(b["cyl"].opening_angles),
         covariance=np.float64(case.get("covariance", 4.3681e-06)),
     )
     if store_rays:
@@ -296,9 +299,19 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
             refl_dirs = geometry.reflect(incident.unsqueeze(1), anrm)
             rays = rt.scatter_rays(distortion_u=du.contiguous(), distortion_e=de.contiguous(),
                                    original_ray_direction=refl_dirs, device=CPU)
-            e_px, u_px, t, inten = geometry.line_plane_intersections(
-                rays=rays, points_at_ray_origins=apts, target_areas=b["planar"],
-                target_area_indices=target_idx, bitmap_resolution=res, device=CPU)
+            n_planar = b["planar"].centers.shape[0]
+            e_px = torch.zeros(rays.ray_magnitudes.shape, dtype=dtype)
+            u_px, t, inten = torch.zeros_like(e_px), torch.zeros_like(e_px), torch.zeros_like(e_px)
+            pm = target_idx < n_planar
+            if pm.any():
+                e_px[pm], u_px[pm], t[pm], inten[pm] = geometry.line_plane_intersections(
+                    rays=Rays(rays.ray_directions[pm], rays.ray_magnitudes[pm]), points_at_ray_origins=apts[pm],
+                    target_areas=b["planar"], target_area_indices=target_idx[pm], bitmap_resolution=res, device=CPU)
+            if (~pm).any():
+                e_px[~pm], u_px[~pm], t[~pm], inten[~pm] = geometry.line_cylinder_intersections(
+                    rays=Rays(rays.ray_directions[~pm], rays.ray_magnitudes[~pm]), points_at_ray_origins=apts[~pm],
+                    target_areas=b["cyl"], target_area_indices=target_idx[~pm] - n_planar, bitmap_resolution=res,
+                    device=CPU)
             inten_abs = inten * (1 - 0.0) * (1 - ext) * refl
             bitmaps = rt.bilinear_splatting(e_px, u_px, inten_abs, device=CPU)
         out.update(reflected=npy(refl_dirs), scattered=npy(rays.ray_directions), e_px=npy(e_px), u_px=npy(u_px),
@@ -360,6 +373,23 @@ CASES = {
                     curvature=1e-3, **RECEIVER),
 }
 
+# Cylindrical receivers (artist/raytracing/geometry.py:207-445) mixed with a planar one: heliostat 0 -> planar,
+# 1 -> half cylinder facing north, 2 -> full cylinder (the -pi/2 seam of the unwrapped angle included), 3 -> a
+# narrow sector most rays miss.
+CASES["small_cyl_mixed"] = dict(
+    n_heliostats=4, n_cp=(6, 6), degrees=(3, 3), n_eval=7, n_rays=5, resolution=[64, 48], curvature=1e-3,
+    target_centers=[[0.0, 0.0, 55.0, 1.0]], target_normals=[[0.0, 1.0, 0.0, 0.0]], target_dims=[[8.0, 8.0]],
+    cyl_centers=[[0.0, 0.0, 55.0, 1.0], [0.0, 0.0, 50.0, 1.0], [1.0, 0.5, 52.0, 1.0]],
+    cyl_normals=[[0.0, 1.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0], [0.6, 0.8, 0.0, 0.0]],
+    cyl_axes=[[0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 0.0, 1.0, 0.0]],
+    cyl_radii=[3.0, 2.5, 4.0], cyl_heights=[8.0, 6.0, 5.0], cyl_opening=[3.141592653589793, 6.283185307179586, 0.6],
+    target_idx=[0, 1, 2, 3], extinction=0.05, reflectivity=0.9)
+CASES["mid_cyl"] = dict(
+    n_heliostats=2, n_cp=(6, 6), degrees=(3, 3), n_eval=20, n_rays=8, resolution=[256, 256], curvature=1e-3,
+    target_centers=[[0.0, 0.0, 55.0, 1.0]], target_normals=[[0.0, 1.0, 0.0, 0.0]], target_dims=[[8.0, 8.0]],
+    cyl_centers=[[0.0, 0.0, 55.0, 1.0]], cyl_normals=[[0.0, 1.0, 0.0, 0.0]], cyl_axes=[[0.0, 0.0, 1.0, 0.0]],
+    cyl_radii=[3.5], cyl_heights=[9.0], cyl_opening=[3.141592653589793], target_idx=[1, 1])
+
 # Config 1 of BASELINE.json: 1 heliostat, 4 planar facets, point sun, 10k rays.
 CONFIG1 = dict(n_heliostats=1, n_cp=(10, 10), degrees=(3, 3), n_eval=50, n_rays=1, z_noise=0.0, covariance=1e-12,
                resolution=[256, 256], **RECEIVER)
@@ -401,6 +431,23 @@ def known_answers():
             f"plane{i}_expected_e": npy(ee), f"plane{i}_expected_u": npy(eu), f"plane{i}_expected_t": npy(ed),
             f"plane{i}_expected_i": npy(ei), f"plane{i}_reference_e": npy(e_px), f"plane{i}_reference_u": npy(u_px),
             f"plane{i}_reference_t": npy(t), f"plane{i}_reference_i": npy(inten)})
+    # line-cylinder: tests/raytracing/test_geometry.py:411-551 (targets from fixtures :345-408)
+    import math
+    cyl_targets = {"target_area_1_cylindrical": 2 * math.pi, "target_area_2_cylindrical": math.pi / 2}
+    for i, (rays, tname, origins, ee, eu, ed, ei) in enumerate(tg.test_line_cylinder_intersection.pytestmark[0].args[1]):
+        ta = TowerTargetAreasCylindrical(
+            names=["c"], centers=torch.tensor([[0.0, 0.0, 0.0, 1.0]]), normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]]),
+            axes=torch.tensor([[0.0, 0.0, 1.0, 0.0]]), radii=torch.tensor([1.0]), heights=torch.tensor([2.0]),
+            opening_angles=torch.tensor([cyl_targets[tname]]))
+        r = Rays(ray_directions=rays[0], ray_magnitudes=rays[1])
+        e_px, u_px, t, inten = geometry.line_cylinder_intersections(r, origins, ta, torch.tensor([0]), device=CPU)
+        out.update({
+            f"cyl{i}_dirs": npy(rays[0]), f"cyl{i}_mags": npy(rays[1]), f"cyl{i}_origins": npy(origins),
+            f"cyl{i}_opening": np.float32(cyl_targets[tname]),
+            f"cyl{i}_expected_e": npy(ee), f"cyl{i}_expected_u": npy(eu), f"cyl{i}_expected_t": npy(ed),
+            f"cyl{i}_expected_i": npy(ei), f"cyl{i}_reference_e": npy(e_px), f"cyl{i}_reference_u": npy(u_px),
+            f"cyl{i}_reference_t": npy(t), f"cyl{i}_reference_i": npy(inten)})
+    out["cyl_count"] = np.int64(i + 1)
     # rotate_distortions: tests/geometry/test_transforms.py (test_distortion_rotations)
     tt = importlib.import_module("tests.geometry.test_transforms")
     k = 0

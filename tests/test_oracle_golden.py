@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import STAGE_CASES, rel_l2, sun_distortions
+from conftest import CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
 
 
 # ---- reference's own known answers -----------------------------------------------------------
@@ -167,7 +167,7 @@ def test_backward_vs_autograd(golden, name):
     assert rel_l2(g_cp, d["grad_control_points"]) < 2e-5, rel_l2(g_cp, d["grad_control_points"])
 
 
-@pytest.mark.parametrize("name", STAGE_CASES)
+@pytest.mark.parametrize("name", STAGE_CASES + CYL_CASES)
 def test_backward_f64_tight(golden, name):
     """In double precision the hand-derived backward must agree with autograd to ~1e-9: this is
     the check that the derivation (masks constant, gradient through weights/intensity/hit
@@ -187,26 +187,28 @@ def test_backward_f64_tight(golden, name):
     args = (ap, an, f("incident"), f("distortions_u"), f("distortions_e"), d["target_idx"], f("target_centers"),
             f("target_normals"), f("target_dims"), d["resolution"])
     sc = (float(d["ray_magnitude"]), float(d["extinction"]), float(d["reflectivity"]))
-    flux, fac, dbg = oracle.trace_fwd(*args, *sc, debug=True)
-    np.testing.assert_allclose(dbg["e_px"], d64["e_px"], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(dbg["u_px"], d64["u_px"], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(dbg["intensities"], d64["intensities"], rtol=1e-12, atol=1e-15)
-    np.testing.assert_allclose(flux, d64["flux"], rtol=1e-9, atol=1e-9)
-    go, gn = oracle.trace_bwd(*args, f("loss_weights"), *sc)
+    cyl = oracle.cyl_tables(d64)
+    flux, fac, dbg = oracle.trace_fwd(*args, *sc, debug=True, cyl=cyl)
+    loose = 1e3 if name in CYL_CASES else 1.0        # the cylinder quadratic amplifies rounding ~400x
+    np.testing.assert_allclose(dbg["e_px"], d64["e_px"], rtol=0, atol=1e-9 * loose)
+    np.testing.assert_allclose(dbg["u_px"], d64["u_px"], rtol=0, atol=1e-9 * loose)
+    np.testing.assert_allclose(dbg["intensities"], d64["intensities"], rtol=1e-12 * loose, atol=1e-15 * loose)
+    np.testing.assert_allclose(flux, d64["flux"], rtol=1e-9 * loose, atol=1e-9 * loose)
+    go, gn = oracle.trace_bwd(*args, f("loss_weights"), *sc, cyl=cyl)
     for got, key in ((go, "grad_aligned_points"), (gn, "grad_aligned_normals")):
         if np.linalg.norm(d64[key]) == 0:
             assert np.linalg.norm(got) == 0
         else:
-            assert rel_l2(got, d64[key]) < 1e-9, (key, rel_l2(got, d64[key]))
+            assert rel_l2(got, d64[key]) < 1e-9 * loose, (key, rel_l2(got, d64[key]))
     # chain to control points: d(aligned)/d(nurbs) = orientation
     g_pts = (go @ ori).reshape(pts.shape)
     g_nrm = (gn @ ori).reshape(nrm.shape)
     g_cp = oracle.nurbs_bwd(f("control_points"), f("eval_points"), d["degrees"], g_pts, g_nrm, f("canting"))
     if np.linalg.norm(d64["grad_control_points"]) > 0:
-        assert rel_l2(g_cp, d64["grad_control_points"]) < 1e-9, rel_l2(g_cp, d64["grad_control_points"])
+        assert rel_l2(g_cp, d64["grad_control_points"]) < 1e-9 * loose, rel_l2(g_cp, d64["grad_control_points"])
     g_ori = np.einsum("hpi,hpj->hij", go, pts.reshape(H, -1, 4)) + np.einsum("hpi,hpj->hij", gn, nrm.reshape(H, -1, 4))
     if np.linalg.norm(d64["grad_orientation"]) > 0:
-        assert rel_l2(g_ori, d64["grad_orientation"]) < 1e-9
+        assert rel_l2(g_ori, d64["grad_orientation"]) < 1e-9 * loose
 
 
 @pytest.mark.parametrize("name,tol", [("config1", 1e-6), ("config2", 1e-5)])
@@ -223,3 +225,44 @@ def test_baseline_configs(golden, name, tol):
     err = rel_l2(flux, d["flux"])
     assert err < tol, err
     assert np.array_equal(fac[0], d["intercept"]) and np.array_equal(fac[1], d["on_target"])
+
+
+# ---- cylindrical receivers (geometry.line_cylinder_intersections, next-row scope) ---------------------------
+def test_line_cylinder_known_answers(golden):
+    ka = golden("known_answers")
+    assert int(ka["cyl_count"]) == 5
+    for i in range(5):        # tests/raytracing/test_geometry.py:411-551
+        cyl = dict(centers=np.array([[0, 0, 0, 1.0]], np.float32), normals=np.array([[0, 1, 0, 0.0]], np.float32),
+                   axes=np.array([[0, 0, 1, 0.0]], np.float32), radii=np.array([1.0], np.float32),
+                   heights=np.array([2.0], np.float32), opening=np.array([ka[f"cyl{i}_opening"]], np.float32))
+        H, R, P = ka[f"cyl{i}_mags"].shape
+        o = np.broadcast_to(ka[f"cyl{i}_origins"][:, None], (H, R, P, 4))
+        got = oracle.line_cylinder(ka[f"cyl{i}_dirs"], ka[f"cyl{i}_mags"], o, cyl, 0)
+        for g, key in zip(got, "euti"):
+            np.testing.assert_allclose(g.reshape(H, R, P), ka[f"cyl{i}_expected_{key}"], rtol=1e-4, atol=1e-4)
+            np.testing.assert_allclose(g.reshape(H, R, P), ka[f"cyl{i}_reference_{key}"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", CYL_CASES)
+def test_cylinder_stages_fp32(golden, name):
+    """fp32 cylinder hits are ill-conditioned (b^2 - 4ac cancels ~400x at 60-150 m from a 3 m cylinder): the
+    reference's own fp32 pixel coordinates are ~1e-2 px (p99) from its fp64 run and its flux ~4e-3 in relative L2.
+    The restatement must reproduce most rays bit for bit and stay within that yardstick overall."""
+    d, d64 = golden(name), golden(name + "_f64")
+    flux, fac, dbg = oracle.trace_fwd(
+        d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"], d["distortions_e"],
+        d["target_idx"], d["target_centers"], d["target_normals"], d["target_dims"], d["resolution"],
+        float(d["ray_magnitude"]), float(d["extinction"]), float(d["reflectivity"]), debug=True, cyl=oracle.cyl_tables(d))
+    assert np.array_equal(fac[0], d["intercept"]) and np.array_equal(fac[1], d["on_target"])
+    for key in ("e_px", "u_px"):
+        assert (dbg[key] == d[key]).mean() > 0.85                       # sin/cos ULPs touch < 15 % of the rays
+        assert np.percentile(np.abs(dbg[key] - d[key]), 99) < 2e-2     # ... and move them by what fp32 itself does
+    yard = rel_l2(d["flux"], d64["flux"])
+    assert rel_l2(flux, d["flux"]) < max(yard, 2e-3), (rel_l2(flux, d["flux"]), yard)
+    go, gn = oracle.trace_bwd(
+        d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"], d["distortions_e"],
+        d["target_idx"], d["target_centers"], d["target_normals"], d["target_dims"], d["resolution"], d["loss_weights"],
+        float(d["ray_magnitude"]), float(d["extinction"]), float(d["reflectivity"]), cyl=oracle.cyl_tables(d))
+    for got, key in ((go, "grad_aligned_points"), (gn, "grad_aligned_normals")):
+        yard = rel_l2(d[key], d64[key])
+        assert rel_l2(got, d[key]) < max(yard, 1e-3), (key, rel_l2(got, d[key]), yard)
