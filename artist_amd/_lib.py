@@ -15,7 +15,7 @@ _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ArtistHipError(RuntimeError):
@@ -31,10 +31,12 @@ _ptr = ctypes.c_void_p
 # mirrors include/artist_hip.h one-to-one (tests/test_boundary.py checks every symbol).
 SIGNATURES = {
     "art_trace_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
-                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
+                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr],
     "art_trace_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
-                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
+                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr, _ptr],
     "art_per_target_sum": [_ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr],
     "art_nurbs_fwd": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_i64,

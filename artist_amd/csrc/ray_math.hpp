@@ -229,4 +229,149 @@ __device__ __forceinline__ RaySplat hit_and_weights(const Plane& pl, const float
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cylindrical receivers: artist/raytracing/geometry.py:207-445, in the reference's operation order.
+// Note that in fp32 this intersection is ill-conditioned (b^2 - 4ac cancels ~(distance/radius)^2
+// fold); the reference has the same property and parity is asserted against that yardstick.
+// ---------------------------------------------------------------------------------------------------
+struct Cyl {
+    float cx, cy, cz;                 // centre
+    float r00, r01, r02;              // rows of `rotations`: u = n x axis   (:299-300)
+    float r10, r11, r12;              //                      n
+    float r20, r21, r22;              //                      axis
+    float r2;                         // radius ** 2
+    float height, half_height, inv_height;
+    float opening, inv_opening;
+    float ang0;                       // atan2(n_y, n_x) - opening / 2 (world components, :399-405)
+    float wm1, hm1;
+    float mag, k_ext, k_refl;
+};
+
+__device__ __forceinline__ Cyl load_cyl(const float* __restrict__ centers, const float* __restrict__ normals,
+                                        const float* __restrict__ axes, const float* __restrict__ radii,
+                                        const float* __restrict__ heights, const float* __restrict__ opening, int t,
+                                        int W, int Hh, float mag, float k_ext, float k_refl)
+{
+    Cyl c;
+    c.cx = centers[4 * t]; c.cy = centers[4 * t + 1]; c.cz = centers[4 * t + 2];
+    const float nx = normals[4 * t], ny = normals[4 * t + 1], nz = normals[4 * t + 2];
+    const float ax = axes[4 * t], ay = axes[4 * t + 1], az = axes[4 * t + 2];
+    c.r00 = ny * az - nz * ay; c.r01 = nz * ax - nx * az; c.r02 = nx * ay - ny * ax;
+    c.r10 = nx; c.r11 = ny; c.r12 = nz;
+    c.r20 = ax; c.r21 = ay; c.r22 = az;
+    c.r2 = radii[t] * radii[t];
+    c.height = heights[t]; c.half_height = heights[t] / 2.0f; c.inv_height = 1.0f / heights[t];
+    c.opening = opening[t]; c.inv_opening = 1.0f / opening[t];
+    c.ang0 = atan2f(ny, nx) - opening[t] / 2.0f;
+    c.wm1 = (float)(W - 1); c.hm1 = (float)(Hh - 1);
+    c.mag = mag; c.k_ext = k_ext; c.k_refl = k_refl;
+    return c;
+}
+
+// v @ rotations^T, k sequential
+__device__ __forceinline__ void cyl_rot(const Cyl& c, float vx, float vy, float vz, float& ox, float& oy, float& oz)
+{
+    ox = (vx * c.r00 + vy * c.r01) + vz * c.r02;
+    oy = (vx * c.r10 + vy * c.r11) + vz * c.r12;
+    oz = (vx * c.r20 + vy * c.r21) + vz * c.r22;
+}
+
+struct CylPoint {        // per surface point (:303-305, :320)
+    float ox, oy, oz;    // origin in the cylinder frame
+    float c;             // ox^2 + oy^2 - r^2
+};
+
+__device__ __forceinline__ CylPoint cyl_point(const Cyl& cy, const float4 o)
+{
+    CylPoint p;
+    cyl_rot(cy, o.x - cy.cx, o.y - cy.cy, o.z - cy.cz, p.ox, p.oy, p.oz);
+    p.c = (p.ox * p.ox + p.oy * p.oy) - cy.r2;
+    return p;
+}
+
+struct CylHit {
+    float dx, dy, dz;        // ray direction in the cylinder frame
+    float a, b, sq, t;       // quadratic, sqrt(disc + 1e-12), selected root
+    float x, y, rho, nx, ny; // hit point (local xy), its radius, outward normal
+    float abi;               // clamp(-d.n, 0)
+    float be, bu, I0;        // outputs (masked like the reference: 0 when the ray misses)
+    bool near, ok;           // root choice; hit && inside the sector
+};
+
+__device__ __forceinline__ CylHit cyl_hit(const Cyl& cy, const CylPoint& p, float rx, float ry, float rz)
+{
+    CylHit h;
+    cyl_rot(cy, rx, ry, rz, h.dx, h.dy, h.dz);                                   // :306
+    h.a = h.dx * h.dx + h.dy * h.dy;                                             // :318
+    h.b = 2.0f * (p.ox * h.dx + p.oy * h.dy);                                    // :319
+    const float disc = h.b * h.b - (4.0f * h.a) * p.c;                           // :322
+    const bool mask = (disc >= 0.0f) && (fabsf(h.a) > 1e-8f);                    // :326
+    h.sq = sqrtf(disc * (mask ? 1.0f : 0.0f) + 1e-12f);                          // :336
+    const float two_a = 2.0f * h.a;
+    float tn = (-h.b - h.sq) / two_a, tf = (-h.b + h.sq) / two_a;                // :343-348
+    tn = tn > 0.0f ? tn : __builtin_inff();                                      // :351-355
+    tf = tf > 0.0f ? tf : __builtin_inff();
+    h.near = tn <= tf;
+    float t = h.near ? tn : tf;                                                  // :356
+    const bool hit = (fabsf(t) < __builtin_inff()) && mask;                      // :357-359 (isfinite)
+    t = hit ? t : 0.0f;                                                          // :360-364
+    h.t = t;
+    h.x = p.ox + t * h.dx; h.y = p.oy + t * h.dy;                                // :374-381
+    float z = p.oz + t * h.dz;
+    h.rho = sqrtf(h.x * h.x + h.y * h.y);                                        // :384-385
+    h.nx = h.x / h.rho; h.ny = h.y / h.rho;
+    const float dot = (-h.dx) * h.nx + (-h.dy) * h.ny;                           // :388-390 (z term is +-0)
+    h.abi = dot < 0.0f ? 0.0f : dot;                                             // clamp(min=0); NaN passes through
+    z = z + cy.half_height;                                                      // :397
+    const float ang = atan2f(h.y, h.x) - cy.ang0;                                // :399-405
+    const bool on = (z >= 0.0f) && (z <= cy.height) && (ang >= 0.0f) && (ang <= cy.opening);   // :407-412
+    h.ok = on && hit;
+    const float m = h.ok ? 1.0f : 0.0f;
+    h.bu = (div_const(z, cy.height, cy.inv_height) * cy.hm1) * m;                // :414-429
+    h.be = (div_const(ang, cy.opening, cy.inv_opening) * cy.wm1) * m;
+    h.I0 = (cy.mag * h.abi) * m;                                                 // :433-438
+    return h;
+}
+
+// Backward of cyl_hit: (g_be, g_bu, g_I0) -> gradient w.r.t. the local origin (gox, goy, goz) and the
+// WORLD ray direction (grx, gry, grz).  Only called for rays with h.ok.
+__device__ __forceinline__ void cyl_hit_bwd(const Cyl& cy, const CylPoint& p, const CylHit& h, float g_be, float g_bu,
+                                            float g_I0, float& gox, float& goy, float& goz, float& grx, float& gry,
+                                            float& grz)
+{
+#pragma clang fp contract(fast)
+    const float g_ang = g_be * cy.wm1 * cy.inv_opening;
+    const float g_z = g_bu * cy.hm1 * cy.inv_height;
+    const float irho2 = 1.0f / (h.x * h.x + h.y * h.y);
+    float g_x = -g_ang * h.y * irho2, g_y = g_ang * h.x * irho2;
+    float gdx = 0.0f, gdy = 0.0f;
+    if (h.abi > 0.0f) {
+        const float g_abi = g_I0 * cy.mag;
+        gdx = -g_abi * h.nx; gdy = -g_abi * h.ny;
+        const float gnx = -g_abi * h.dx, gny = -g_abi * h.dy;
+        const float dotn = h.nx * gnx + h.ny * gny;
+        const float irho = 1.0f / h.rho;
+        g_x += (gnx - h.nx * dotn) * irho; g_y += (gny - h.ny * dotn) * irho;
+    }
+    gox = g_x; goy = g_y; goz = g_z;
+    gdx += g_x * h.t; gdy += g_y * h.t;
+    const float gdz = g_z * h.t;
+    const float g_t = g_x * h.dx + g_y * h.dy + g_z * h.dz;
+    const float inv2a = 1.0f / (2.0f * h.a);
+    float g_b = -g_t * inv2a;
+    const float g_sq = (h.near ? -g_t : g_t) * inv2a;
+    float g_a = -g_t * h.t / h.a;
+    const float g_disc = g_sq / (2.0f * h.sq);
+    g_b += 2.0f * h.b * g_disc;
+    g_a -= 4.0f * p.c * g_disc;
+    const float g_c = -4.0f * h.a * g_disc;
+    gdx += 2.0f * h.dx * g_a + 2.0f * p.ox * g_b;
+    gdy += 2.0f * h.dy * g_a + 2.0f * p.oy * g_b;
+    gox += 2.0f * h.dx * g_b + 2.0f * p.ox * g_c;
+    goy += 2.0f * h.dy * g_b + 2.0f * p.oy * g_c;
+    grx = gdx * cy.r00 + gdy * cy.r10 + gdz * cy.r20;
+    gry = gdx * cy.r01 + gdy * cy.r11 + gdz * cy.r21;
+    grz = gdx * cy.r02 + gdy * cy.r12 + gdz * cy.r22;
+}
+
 }  // namespace art

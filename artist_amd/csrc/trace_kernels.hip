@@ -31,8 +31,14 @@ struct TraceArgs {
     const float* centers;
     const float* pnormals;
     const float* dims;
+    const float* cyl_centers;   // [Tc,4]  TowerTargetAreasCylindrical tensors (NULL when Tc == 0)
+    const float* cyl_normals;   // [Tc,4]
+    const float* cyl_axes;      // [Tc,4]
+    const float* cyl_radii;     // [Tc]
+    const float* cyl_heights;   // [Tc]
+    const float* cyl_opening;   // [Tc]
     float mag, k_ext, k_refl;
-    int H, R, P, T, W, Hh;
+    int H, R, P, T, Tc, W, Hh;  // target index t < T: planar area t; T <= t < T + Tc: cylinder t - T
     int mode;                 // 0: bitmap per heliostat, 1: bitmap per target
     int r_chunk;              // samples per block
     int n_rchunks;            // ceil(R / r_chunk)
@@ -90,6 +96,7 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
     const bool active = p < a.P;
 
     const int t = a.target_idx[h];
+    if (t >= a.T) return;             // planar receivers only (host refuses cylinders for this variant)
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
 
@@ -235,8 +242,8 @@ __device__ __forceinline__ void resolve_carries(const PendingSplat& ps, float* _
 // Phase 1 of the windowed kernels: bounding box (in un-flipped bitmap coordinates) of where the
 // workgroup's rays can land, clipped to `tile_cap` pixels, plus the fixed-point scale of the forward
 // accumulator.  Result is left in *s_win after a __syncthreads().
-template <bool INTERLEAVED>
-__device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& pl, const float4 inc,
+template <bool INTERLEAVED, bool CYL>
+__device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& pl, const Cyl& cy, const float4 inc,
                                                const float4* __restrict__ org, const float4* __restrict__ nrm,
                                                int p0, int p1, int64_t dbase, float (*s_red)[16], Window* s_win)
 {
@@ -251,16 +258,28 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
         float4 d; float s;
         reflect(inc, n, d, s);
         dmax2 = fmaxf(dmax2, d.x * d.x + d.y * d.y + d.z * d.z);
-        const float numer = plane_numer(pl, o);
-        const Hit hit = intersect(pl, o, numer, d.x, d.y, d.z);
-        if (hit.valid) {
-            emin = fminf(emin, hit.be); emax = fmaxf(emax, hit.be);
-            umin = fminf(umin, hit.bu); umax = fmaxf(umax, hit.bu);
-            esum += hit.be; usum += hit.bu; cnt += 1.0f;
-            esq += hit.be * hit.be; usq += hit.bu * hit.bu;
+        bool valid; float hbe, hbu, hke, hku;
+        if constexpr (CYL) {
+            // chief ray on the cylinder; hit-point travel per radian ~ t / cos(incidence) along both axes
+            const CylPoint cp = cyl_point(cy, o);
+            const CylHit ch = cyl_hit(cy, cp, d.x, d.y, d.z);
+            valid = ch.ok; hbe = ch.be; hbu = ch.bu;
+            hke = hku = ch.t / fmaxf(ch.abi, 0.1f);
+        } else {
+            const float numer = plane_numer(pl, o);
+            const Hit hit = intersect(pl, o, numer, d.x, d.y, d.z);
+            valid = hit.valid; hbe = hit.be; hbu = hit.bu;
             const float ia = 1.0f / hit.a, qe = d.x * ia, qu = d.z * ia;
-            ke = fmaxf(ke, hit.t * sqrtf(1.0f + qe * qe));
-            ku = fmaxf(ku, hit.t * sqrtf(1.0f + qu * qu));
+            hke = hit.t * sqrtf(1.0f + qe * qe);
+            hku = hit.t * sqrtf(1.0f + qu * qu);
+        }
+        if (valid) {
+            emin = fminf(emin, hbe); emax = fmaxf(emax, hbe);
+            umin = fminf(umin, hbu); umax = fmaxf(umax, hbu);
+            esum += hbe; usum += hbu; cnt += 1.0f;
+            esq += hbe * hbe; usq += hbu * hbu;
+            ke = fmaxf(ke, hke);
+            ku = fmaxf(ku, hku);
         }
         float u, e;
         load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e);
@@ -288,8 +307,11 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
         if (emax >= emin) {
             // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
             // worth keeping in the window (~4.2 sigma); +2 px for the bilinear footprint and rounding.
-            const float pad_e = fminf(1.15f * angmax * ke * (pl.wm1 / fabsf(pl.w)) + 2.0f, 32768.0f);
-            const float pad_u = fminf(1.15f * angmax * ku * (pl.hm1 / fabsf(pl.h)) + 2.0f, 32768.0f);
+            float ppm_e, ppm_u;   // pixels per metre on the receiver surface
+            if constexpr (CYL) { ppm_e = cy.wm1 / fabsf(cy.opening * sqrtf(cy.r2)); ppm_u = cy.hm1 / fabsf(cy.height); }
+            else { ppm_e = pl.wm1 / fabsf(pl.w); ppm_u = pl.hm1 / fabsf(pl.h); }
+            const float pad_e = fminf(1.15f * angmax * ke * ppm_e + 2.0f, 32768.0f);
+            const float pad_u = fminf(1.15f * angmax * ku * ppm_u + 2.0f, 32768.0f);
             int e0 = max((int)emin - (int)pad_e, 0), e1 = min((int)emax + 1 + (int)pad_e, a.W - 1);
             int u0 = max((int)umin - (int)pad_u, 0), u1 = min((int)umax + 1 + (int)pad_u, a.Hh - 1);
             int tw = e1 - e0 + 1, th = u1 - u0 + 1;
@@ -322,8 +344,16 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             win.npass = win.ths >= th ? 1 : (th - 1 + win.ths - 2) / (win.ths - 1);
             // |contribution| <= |I| = |mag k_ext k_refl| |r.m| <= |mag k_ext k_refl| |d| |m| (the scatter
             // matrix is a rotation); 2^ex > bound, so |v| * 2^(22-ex) < 2^22.
-            const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
-            const float mnorm = sqrtf(pl.mx * pl.mx + pl.my * pl.my + pl.mz * pl.mz);
+            // (cylinder: |I0| <= |mag| |(R d)_xy| <= |mag| |d| ||R_xy||_F)
+            float kI, mnorm;
+            if constexpr (CYL) {
+                kI = (cy.mag * cy.k_ext) * cy.k_refl;
+                mnorm = sqrtf(cy.r00 * cy.r00 + cy.r01 * cy.r01 + cy.r02 * cy.r02 + cy.r10 * cy.r10 + cy.r11 * cy.r11 +
+                              cy.r12 * cy.r12);
+            } else {
+                kI = (pl.mag * pl.k_ext) * pl.k_refl;
+                mnorm = sqrtf(pl.mx * pl.mx + pl.my * pl.my + pl.mz * pl.mz);
+            }
             const float bound = fabsf(kI) * sqrtf(dmax2) * mnorm * 1.001f;
             int ex = 0;
             if (bound > 0.0f && bound < 3.0e38f) (void)frexpf(bound, &ex);
@@ -338,7 +368,7 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
     __syncthreads();
 }
 
-template <bool INTERLEAVED>
+template <bool INTERLEAVED, bool CYL>
 __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float* __restrict__ flux,
                                                              unsigned int* __restrict__ counts)
 {
@@ -354,7 +384,12 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    if ((t >= a.T) != CYL) return;    // workgroup-uniform: the other instantiation's launch owns this heliostat
+    Plane pl; Cyl cy;
+    if constexpr (CYL) cy = load_cyl(a.cyl_centers, a.cyl_normals, a.cyl_axes, a.cyl_radii, a.cyl_heights, a.cyl_opening,
+                                     t - a.T, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    else pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    const float k_ext = a.k_ext, k_refl = a.k_refl;
     float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
     const float4 inc = a.incident[h];
     const int p0 = pblock * a.p_block;
@@ -367,14 +402,15 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
 
     // ---- phase 1: window ---------------------------------------------------------------------
     if (tid < 2) s_cnt[tid] = 0;
-    compute_window<INTERLEAVED>(a, pl, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
+    compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
     const unsigned twm1 = (unsigned)(win.tw - 1), uthm1 = (unsigned)(win.th - 1);
     const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     // lean mode needs I0 > 0 and I > 0 to be implied by `valid`: positive, sanely scaled intensity factors
-    const bool lean = pl.mag >= 1e-6f && pl.k_ext >= 1e-6f && pl.k_refl >= 1e-6f && pl.mag <= 1e6f && pl.k_ext <= 1e6f &&
-                      pl.k_refl <= 1e6f;
+    // (a cylinder's Lambert term is clamped at 0, so a valid ray can carry no intensity: never lean)
+    const bool lean = !CYL && a.mag >= 1e-6f && k_ext >= 1e-6f && k_refl >= 1e-6f && a.mag <= 1e6f && k_ext <= 1e6f &&
+                      k_refl <= 1e6f;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
     const int pth = min(win.ths, win.u0 + win.th - pu0);                 // rows held in LDS in this pass
@@ -395,7 +431,8 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         const float4 n = nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
-        const float numer = plane_numer(pl, o);
+        float numer = 0.0f; CylPoint cp;
+        if constexpr (CYL) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
         // One ray: scatter -> hit -> weights -> 4 pipelined LDS adds.  Ray arithmetic is the reference's
         // (ray_math.hpp); the masks are reduced to the one question the LDS path asks ("does this ray land inside
         // this pass's window?"), and everything rare - a scatter angle beyond the small-angle kernel, a valid ray
@@ -404,16 +441,23 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
-            const bool front = ah < 0.0f;
-            const float tt = numer / (front ? ah : 1.0f);                      // :130-131
-            const float hx = o.x + rx * tt, hz = o.z + rz * tt;                // :133-136
-            const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
-            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;    // :154-174
-            // :178-184.  0 <= x <= hi  <=>  x == med3(x, 0, hi)   (NaN compares false)
-            const bool valid = front && be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1) &&
-                               bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
-            const float be = pl.wm1 - be0;                                     // :195-197
+            float be, bu, I0; bool valid;
+            if constexpr (CYL) {
+                const CylHit ch = cyl_hit(cy, cp, rx, ry, rz);                     // geometry.py:287-445
+                valid = ch.ok; be = ch.be; bu = ch.bu; I0 = ch.I0;
+            } else {
+                const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
+                const bool front = ah < 0.0f;
+                const float tt = numer / (front ? ah : 1.0f);                      // :130-131
+                const float hx = o.x + rx * tt, hz = o.z + rz * tt;                // :133-136
+                const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
+                bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;                // :154-174
+                // :178-184.  0 <= x <= hi  <=>  x == med3(x, 0, hi)   (NaN compares false)
+                valid = front && be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1) &&
+                        bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
+                be = pl.wm1 - be0;                                                 // :195-197
+                I0 = pl.mag * (-ah);                                               // :139
+            }
             const float tbe = truncf(be), tbu = truncf(bu);                    // heliostat_ray_tracer.py:674-675
             const float cle = (tbe + 1.0f) - be, clu = (tbu + 1.0f) - bu, che = be - tbe, chu = bu - tbu;   // :694-700
             const int ie = (int)tbe, iu = (int)tbu;
@@ -421,8 +465,7 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             const bool inwin = valid && (unsigned)le < twm1 && (unsigned)lu < thm1;     // implies ie+1 < W, iu+1 < Hh
             const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;        // flat row iu
             const int cell_hi = inwin ? cell_lo + win.tw : dummy;                       // flat row iu + 1
-            const float I0 = pl.mag * (-ah);                                            // geometry.py:139
-            const float I = (I0 * pl.k_ext) * pl.k_refl;                                // heliostat_ray_tracer.py:482-487
+            const float I = (I0 * k_ext) * k_refl;                                      // heliostat_ray_tracer.py:482-487
             // S is a power of two, so (w I) S == w (I S) bit for bit: scale the intensity once
             const float Is = inwin ? fabsf(I) * win.scale : 0.0f;
             // ray counters live in SGPRs (v_cmp + s_bcnt1).  With positive, sanely scaled intensity factors
@@ -533,6 +576,7 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
     if (p >= a.P) return;
 
     const int t = a.target_idx[h];
+    if (t >= a.T) return;
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
 
@@ -607,8 +651,9 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
 // copied once into LDS (row-contiguous loads) and the four per-ray gathers become LDS reads; rays
 // outside the window read global memory.  Gradients are accumulated per point in registers.
 // --------------------------------------------------------------------------------------------
-template <bool INTERLEAVED, bool ATOMIC_OUT>
-__global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
+// (The cylinder instantiation keeps ~60 more live values per ray; it runs 512-thread workgroups = 256 VGPRs.)
+template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL>
+__global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
                                                              float4* __restrict__ grad_normals)
 {
@@ -623,7 +668,11 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    if ((t >= a.T) != CYL) return;    // workgroup-uniform: the other instantiation's launch owns this heliostat
+    Plane pl; Cyl cy;
+    if constexpr (CYL) cy = load_cyl(a.cyl_centers, a.cyl_normals, a.cyl_axes, a.cyl_radii, a.cyl_heights, a.cyl_opening,
+                                     t - a.T, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    else pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
     const float4 inc = a.incident[h];
     const int p0 = pblock * a.p_block;
@@ -634,7 +683,7 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
-    compute_window<INTERLEAVED>(a, pl, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
+    compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
@@ -649,8 +698,9 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
     if (tid < 2) gtile[a.tile_cap + tid] = 0.0f;
     __syncthreads();
 
-    const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
-    const float sx = pl.wm1 / pl.w, sz = pl.hm1 / pl.h;
+    const float kI = (a.mag * a.k_ext) * a.k_refl;
+    float sx = 0.0f, sz = 0.0f;
+    if constexpr (!CYL) { sx = pl.wm1 / pl.w; sz = pl.hm1 / pl.h; }
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     const unsigned twm1 = (unsigned)(win.tw - 1), thm1 = (unsigned)(pth - 1), uthm1 = (unsigned)(win.th - 1);
     const int dummy = a.tile_cap;                    // two spare cells holding 0
@@ -659,8 +709,9 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
         const float4 n = nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
-        const float numer = plane_numer(pl, o);
-        float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;
+        float numer = 0.0f; CylPoint cp;
+        if constexpr (CYL) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
+        float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // (cylinder: go in its local frame)
         // One ray.  The forward re-computation is the reference's arithmetic (it decides which cells the ray
         // touched); masks are reduced to "inside this pass's window?", strays and other bands' rays are handled by
         // a wave-uniform cold branch, and masked rays get zero gradient weights instead of an early exit.
@@ -668,15 +719,21 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
-            const bool front = ah < 0.0f;
-            const float tt = numer / (front ? ah : 1.0f);
-            const float hx = o.x + rx * tt, hz = o.z + rz * tt;
-            const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;
-            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;
-            const bool valid = front && be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1) &&
-                               bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
-            const float be = pl.wm1 - be0;
+            float be, bu, ah = 0.0f, tt = 0.0f; bool valid; CylHit ch;
+            if constexpr (CYL) {
+                ch = cyl_hit(cy, cp, rx, ry, rz);
+                valid = ch.ok; be = ch.be; bu = ch.bu;
+            } else {
+                ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
+                const bool front = ah < 0.0f;
+                tt = numer / (front ? ah : 1.0f);
+                const float hx = o.x + rx * tt, hz = o.z + rz * tt;
+                const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;
+                bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;
+                valid = front && be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1) &&
+                        bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
+                be = pl.wm1 - be0;
+            }
             const float tbe = truncf(be), tbu = truncf(bu);
             const float cle = (tbe + 1.0f) - be, clu = (tbu + 1.0f) - bu, che = be - tbe, chu = bu - tbu;
             const int ie = (int)tbe, iu = (int)tbu;
@@ -695,6 +752,22 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
                     g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
                     use = true;
                 }
+            }
+            if constexpr (CYL) {
+                if (use) {     // divergent, but a masked ray's intermediates are not finite: no zero-weight trick here
+#pragma clang fp contract(fast)
+                    const float I = (ch.I0 * a.k_ext) * a.k_refl;
+                    const float gI = (cle * (chu * g1 + clu * g4) + che * (chu * g2 + clu * g3)) * (a.k_ext * a.k_refl);
+                    const float g_be = (chu * (g2 - g1) + clu * (g3 - g4)) * I;
+                    const float g_bu = (cle * (g1 - g4) + che * (g2 - g3)) * I;
+                    float lx, ly, lz, grx, gry, grz;
+                    cyl_hit_bwd(cy, cp, ch, g_be, g_bu, gI, lx, ly, lz, grx, gry, grz);
+                    gox += lx; goy += ly; goz += lz;
+                    gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
+                    gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
+                    gdz += m.ce * grz - m.se * gry;
+                }
+                return;
             }
             const float I = use ? ((pl.mag * (-ah)) * pl.k_ext) * pl.k_refl : 0.0f;
             const float kIm = use ? kI : 0.0f;
@@ -744,6 +817,12 @@ __global__ __launch_bounds__(1024) void trace_bwd_lds_kernel(TraceArgs a, const 
             cu0 = nu0; ce0 = ne0; cu1 = nu1; ce1 = ne1; cu2 = nu2; ce2 = ne2; cu3 = nu3; ce3 = ne3;
         }
         const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
+        if constexpr (CYL) {   // local origin = R (o - c)  ->  dL/do = R^T dL/dlocal
+            const float wx = gox * cy.r00 + goy * cy.r10 + goz * cy.r20;
+            const float wy = gox * cy.r01 + goy * cy.r11 + goz * cy.r21;
+            const float wz = gox * cy.r02 + goy * cy.r12 + goz * cy.r22;
+            gox = wx; goy = wy; goz = wz;
+        }
         const float4 go = make_float4(gox, goy, goz, 0.0f);
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
@@ -783,12 +862,16 @@ __global__ void per_target_sum_kernel(const float* __restrict__ bitmaps, const i
 static bool fill_args(TraceArgs& a, const float* origins, const float* normals, const float* incident,
                       const float* dist_u, const float* dist_e, int64_t sh, int64_t sr, int64_t sp,
                       const int32_t* target_idx, const float* centers, const float* pnormals, const float* dims,
-                      double mag, double ext, double refl, int64_t H, int64_t R, int64_t P, int64_t T, int64_t W,
-                      int64_t Hh, int mode)
+                      const float* cyl_centers, const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
+                      const float* cyl_heights, const float* cyl_opening,
+                      double mag, double ext, double refl, int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc,
+                      int64_t W, int64_t Hh, int mode)
 {
-    if (!origins || !normals || !incident || !dist_u || !dist_e || !target_idx || !centers || !pnormals || !dims)
-        return false;
-    if (H < 0 || R <= 0 || P <= 0 || T <= 0 || W < 2 || Hh < 2 || (mode != 0 && mode != 1)) return false;
+    if (!origins || !normals || !incident || !dist_u || !dist_e || !target_idx) return false;
+    if (T < 0 || Tc < 0 || T + Tc <= 0 || T + Tc > (1 << 24)) return false;
+    if (T > 0 && (!centers || !pnormals || !dims)) return false;
+    if (Tc > 0 && (!cyl_centers || !cyl_normals || !cyl_axes || !cyl_radii || !cyl_heights || !cyl_opening)) return false;
+    if (H < 0 || R <= 0 || P <= 0 || W < 2 || Hh < 2 || (mode != 0 && mode != 1)) return false;
     if (H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || W > 32768 || Hh > 32768) return false;
     if ((double)R * (double)P >= 4294967296.0) return false;   // uint32 ray counters
     if (sp < 0 || (double)P * (double)sp >= 1073741824.0) return false;   // 32-bit per-lane distortion offsets
@@ -797,6 +880,8 @@ static bool fill_args(TraceArgs& a, const float* origins, const float* normals, 
     a.incident = reinterpret_cast<const float4*>(incident);
     a.dist_u = dist_u; a.dist_e = dist_e; a.sh = sh; a.sr = sr; a.sp = sp;
     a.target_idx = target_idx; a.centers = centers; a.pnormals = pnormals; a.dims = dims;
+    a.cyl_centers = cyl_centers; a.cyl_normals = cyl_normals; a.cyl_axes = cyl_axes; a.cyl_radii = cyl_radii;
+    a.cyl_heights = cyl_heights; a.cyl_opening = cyl_opening; a.Tc = (int)Tc;
     a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
     a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;
     a.n_ptiles = (int)((P + kBlock - 1) / kBlock);
@@ -900,22 +985,25 @@ using namespace art;
 extern "C" int art_trace_fwd(const float* origins, const float* normals, const float* incident,
                              const float* dist_u, const float* dist_e, int64_t dist_sh, int64_t dist_sr,
                              int64_t dist_sp, const int32_t* target_idx, const float* plane_centers,
-                             const float* plane_normals, const float* plane_dims, double ray_magnitude,
+                             const float* plane_normals, const float* plane_dims, const float* cyl_centers,
+                             const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
+                             const float* cyl_heights, const float* cyl_opening, double ray_magnitude,
                              double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
-                             int64_t W, int64_t Hh, int mode, float* flux, float* factors, void* stream_)
+                             int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux, float* factors, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
     if (H == 0) {   // empty field: nothing to trace; a per-target bitmap is still all zeros
-        if (mode == 1 && flux && T > 0 && W > 0 && Hh > 0) ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * T * Hh * W, stream));
+        if (mode == 1 && flux && T >= 0 && Tc >= 0 && T + Tc > 0 && W > 0 && Hh > 0)
+            ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * (T + Tc) * Hh * W, stream));
         return ART_OK;
     }
     if (!flux || !factors ||
         !fill_args(a, origins, normals, incident, dist_u, dist_e, dist_sh, dist_sr, dist_sp, target_idx,
-                   plane_centers, plane_normals, plane_dims, ray_magnitude, extinction, reflectivity, H, R, P, T, W,
-                   Hh, mode))
+                   plane_centers, plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights,
+                   cyl_opening, ray_magnitude, extinction, reflectivity, H, R, P, T, Tc, W, Hh, mode))
         return ART_EINVAL;
-    const int64_t n_maps = mode == 0 ? H : T;
+    const int64_t n_maps = mode == 0 ? H : T + Tc;
     ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * n_maps * Hh * W, stream));
     if (H == 0) return ART_OK;
     ART_HIP(hipMemsetAsync(factors, 0, sizeof(float) * 3 * H, stream));
@@ -927,16 +1015,21 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const int64_t blocks = base * a.n_rchunks;
         if (blocks > 2147483647LL) return ART_EINVAL;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
-        if (interleaved_layout(a)) {
-            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(trace_fwd_lds_kernel<true>, dim3((unsigned)blocks), dim3(cfg.block), lds, stream, a, flux, counts);
-        } else {
-            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(trace_fwd_lds_kernel<false>, dim3((unsigned)blocks), dim3(cfg.block), lds, stream, a, flux, counts);
-        }
+        // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
+        // exits at once (the type is only known on the device)
+#define ART_LAUNCH_FWD(IL, CY)                                                                                   \
+        do {                                                                                                     \
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY>),            \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY>), dim3((unsigned)blocks), dim3(cfg.block), lds,     \
+                               stream, a, flux, counts);                                                         \
+        } while (0)
+        const bool il = interleaved_layout(a);
+        if (T > 0) { if (il) ART_LAUNCH_FWD(true, false); else ART_LAUNCH_FWD(false, false); }
+        if (Tc > 0) { if (il) ART_LAUNCH_FWD(true, true); else ART_LAUNCH_FWD(false, true); }
+#undef ART_LAUNCH_FWD
     } else {
+        if (Tc > 0) return ART_EUNSUPPORTED;   // the global-atomic A/B variant knows planar receivers only
         choose_chunks(a, 4096, 8);
         const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
         if (blocks > 2147483647LL) return ART_EINVAL;
@@ -955,9 +1048,11 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
 extern "C" int art_trace_bwd(const float* origins, const float* normals, const float* incident,
                              const float* dist_u, const float* dist_e, int64_t dist_sh, int64_t dist_sr,
                              int64_t dist_sp, const int32_t* target_idx, const float* plane_centers,
-                             const float* plane_normals, const float* plane_dims, double ray_magnitude,
+                             const float* plane_normals, const float* plane_dims, const float* cyl_centers,
+                             const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
+                             const float* cyl_heights, const float* cyl_opening, double ray_magnitude,
                              double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
-                             int64_t W, int64_t Hh, int mode, const float* grad_flux, float* grad_origins,
+                             int64_t Tc, int64_t W, int64_t Hh, int mode, const float* grad_flux, float* grad_origins,
                              float* grad_normals, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -965,10 +1060,9 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     if (H == 0) return ART_OK;
     if (!grad_flux || !grad_origins || !grad_normals ||
         !fill_args(a, origins, normals, incident, dist_u, dist_e, dist_sh, dist_sr, dist_sp, target_idx,
-                   plane_centers, plane_normals, plane_dims, ray_magnitude, extinction, reflectivity, H, R, P, T, W,
-                   Hh, mode))
+                   plane_centers, plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights,
+                   cyl_opening, ray_magnitude, extinction, reflectivity, H, R, P, T, Tc, W, Hh, mode))
         return ART_EINVAL;
-    if (H == 0) return ART_OK;
     float4* go = reinterpret_cast<float4*>(grad_origins);
     float4* gn = reinterpret_cast<float4*>(grad_normals);
     const bool il = interleaved_layout(a);
@@ -983,21 +1077,28 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
             ART_HIP(hipMemsetAsync(grad_normals, 0, sizeof(float) * 4 * H * P, stream));
         }
-#define ART_LAUNCH_BWD(IL, AT)                                                                                   \
+#define ART_LAUNCH_BWD(IL, AT, CY)                                                                               \
         do {                                                                                                     \
-            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT>),            \
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY>),        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT>), dim3((unsigned)blocks), dim3(cfg.block), lds,     \
-                               stream, a, grad_flux, go, gn);                                                    \
+            hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY>), dim3((unsigned)blocks),                       \
+                               dim3(CY && cfg.block > 512 ? 512 : cfg.block), lds, stream, a, grad_flux, go, gn);  \
         } while (0)
-        if (il && atomic_out) ART_LAUNCH_BWD(true, true);
-        else if (il) ART_LAUNCH_BWD(true, false);
-        else if (atomic_out) ART_LAUNCH_BWD(false, true);
-        else ART_LAUNCH_BWD(false, false);
+#define ART_LAUNCH_BWD_TYPE(CY)                                                                                  \
+        do {                                                                                                     \
+            if (il && atomic_out) ART_LAUNCH_BWD(true, true, CY);                                                \
+            else if (il) ART_LAUNCH_BWD(true, false, CY);                                                        \
+            else if (atomic_out) ART_LAUNCH_BWD(false, true, CY);                                                \
+            else ART_LAUNCH_BWD(false, false, CY);                                                               \
+        } while (0)
+        if (T > 0) ART_LAUNCH_BWD_TYPE(false);
+        if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
+#undef ART_LAUNCH_BWD_TYPE
 #undef ART_LAUNCH_BWD
         ART_HIP(hipGetLastError());
         return ART_OK;
     }
+    if (Tc > 0) return ART_EUNSUPPORTED;
     choose_chunks(a, 2048, 16);
     const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
     if (blocks > 2147483647LL) return ART_EINVAL;

@@ -55,18 +55,40 @@ def _dist_views(dist_u: torch.Tensor, dist_e: torch.Tensor, shape):
     return dist_u, dist_e, dist_u.stride()
 
 
+def _cyl_tables(cyl, dev):
+    """(centers[Tc,4], normals[Tc,4], axes[Tc,4], radii[Tc], heights[Tc], opening[Tc]) -> fp32 contiguous
+    tensors on ``dev`` + their data pointers (NULL x 6 when there are no cylindrical target areas)."""
+    if cyl is None or cyl[0].shape[0] == 0:
+        return (), (None,) * 6, 0
+    if len(cyl) != 6:
+        raise ValueError("cylindrical target areas: (centers, normals, axes, radii, heights, opening_angles)")
+    tabs = tuple(_f32c(t.to(dev)) for t in cyl)
+    Tc = tabs[0].shape[0]
+    for t, shape in zip(tabs, ((Tc, 4), (Tc, 4), (Tc, 4), (Tc,), (Tc,), (Tc,))):
+        if tuple(t.shape) != shape:
+            raise ValueError(f"cylindrical target table has shape {tuple(t.shape)}, expected {shape}")
+    return tabs, tuple(t.data_ptr() for t in tabs), Tc
+
+
+def _planar_ptrs(centers, plane_normals, dims):
+    if centers.shape[0] == 0:
+        return (None, None, None)
+    return (centers.data_ptr(), plane_normals.data_ptr(), dims.data_ptr())
+
+
 class TraceRays(torch.autograd.Function):
-    """reflect -> scatter -> plane intersection -> bilinear splat (+ factors), fused.
+    """reflect -> scatter -> plane / cylinder intersection -> bilinear splat (+ factors), fused.
 
     Replaces the body of ``HeliostatRayTracer.trace_rays``
-    (artist/raytracing/heliostat_ray_tracer.py:285-506) for ``blocking_active=False`` and planar
-    target areas.  Differentiable w.r.t. ``origins`` and ``normals`` exactly like the eager chain
-    (indices and masks are constants).
+    (artist/raytracing/heliostat_ray_tracer.py:285-506) for ``blocking_active=False``.  Target index
+    ``t < T`` is planar area ``t``; ``t >= T`` is cylindrical area ``t - T`` of the ``cyl`` tables.
+    Differentiable w.r.t. ``origins`` and ``normals`` exactly like the eager chain (indices and masks
+    are constants).
     """
 
     @staticmethod
     def forward(ctx, origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-                ray_magnitude, extinction, reflectivity, width, height, per_target):
+                ray_magnitude, extinction, reflectivity, width, height, per_target, cyl=None):
         dev = _require_cuda(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims)
         origins, normals, incident = _f32c(origins), _f32c(normals), _f32c(incident)
         H, P = origins.shape[0], origins.shape[1]
@@ -77,17 +99,19 @@ class TraceRays(torch.autograd.Function):
         target_idx = target_idx.to(torch.int32).contiguous()
         centers, plane_normals, dims = _f32c(centers), _f32c(plane_normals), _f32c(dims)
         T = centers.shape[0]
-        n_maps = T if per_target else H
+        cyl_tabs, cyl_ptrs, Tc = _cyl_tables(cyl, dev)
+        n_maps = T + Tc if per_target else H
         flux = torch.empty((n_maps, height, width), dtype=torch.float32, device=dev)
         factors = torch.empty((3, H), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_fwd(
                 origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
-                sh, sr, sp, target_idx.data_ptr(), centers.data_ptr(), plane_normals.data_ptr(), dims.data_ptr(),
-                float(ray_magnitude), float(extinction), float(reflectivity), H, R, P, T, width, height,
+                sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,
+                float(ray_magnitude), float(extinction), float(reflectivity), H, R, P, T, Tc, width, height,
                 1 if per_target else 0, flux.data_ptr(), factors.data_ptr(), _stream(dev))
         _lib.check(rc, "art_trace_fwd")
-        ctx.save_for_backward(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims)
+        ctx.save_for_backward(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
+                              *cyl_tabs)
         ctx.scalars = (float(ray_magnitude), float(extinction), float(reflectivity), width, height, bool(per_target))
         ctx.mark_non_differentiable(factors)
         return flux, factors
@@ -95,7 +119,10 @@ class TraceRays(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_flux, _grad_factors):
-        origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims = ctx.saved_tensors
+        origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims = ctx.saved_tensors[:9]
+        cyl_tabs = ctx.saved_tensors[9:]
+        cyl_ptrs = tuple(t.data_ptr() for t in cyl_tabs) if cyl_tabs else (None,) * 6
+        Tc = cyl_tabs[0].shape[0] if cyl_tabs else 0
         mag, ext, refl, width, height, per_target = ctx.scalars
         dev = origins.device
         H, P = origins.shape[0], origins.shape[1]
@@ -107,20 +134,22 @@ class TraceRays(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_bwd(
                 origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
-                sh, sr, sp, target_idx.data_ptr(), centers.data_ptr(), plane_normals.data_ptr(), dims.data_ptr(),
-                mag, ext, refl, H, R, P, centers.shape[0], width, height, 1 if per_target else 0,
+                sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,
+                mag, ext, refl, H, R, P, centers.shape[0], Tc, width, height, 1 if per_target else 0,
                 grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(), _stream(dev))
         _lib.check(rc, "art_trace_bwd")
-        return (g_o, g_n) + (None,) * 13
+        return (g_o, g_n) + (None,) * 14
 
 
 def trace_rays(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-               ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, resolution=(256, 256), per_target=False):
-    """Functional form.  Returns ``(flux, factors)`` with ``flux`` ``[H,Hh,W]`` (or ``[T,Hh,W]`` when
-    ``per_target``) and ``factors`` ``[3,H]`` = intercept, on-target, blocking fractions."""
+               ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, resolution=(256, 256), per_target=False,
+               cyl=None):
+    """Functional form.  Returns ``(flux, factors)`` with ``flux`` ``[H,Hh,W]`` (or ``[T+Tc,Hh,W]`` when
+    ``per_target``) and ``factors`` ``[3,H]`` = intercept, on-target, blocking fractions.  ``cyl`` = the six
+    ``TowerTargetAreasCylindrical`` tensors (centers, normals, axes, radii, heights, opening_angles) or None."""
     return TraceRays.apply(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                            ray_magnitude, extinction, reflectivity, int(resolution[0]), int(resolution[1]),
-                           bool(per_target))
+                           bool(per_target), cyl)
 
 
 def per_target_sum(bitmaps: torch.Tensor, target_idx: torch.Tensor, n_targets: int) -> torch.Tensor:

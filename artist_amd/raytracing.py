@@ -30,6 +30,25 @@ def reflect(incident_ray_directions: torch.Tensor, reflection_surface_normals: t
             * reflection_surface_normals)
 
 
+def _planar_tables(tower, device):
+    """(centers [T,4], normals [T,4], dimensions [T,2]) of ``solar_tower.target_areas[planar]``; empty tables when
+    the tower has cylindrical receivers only."""
+    planar = tower.target_areas[0]
+    if int(tower.number_of_target_areas_per_type[0]) == 0 or not hasattr(planar, "centers"):
+        z = torch.zeros((0, 4), device=device)
+        return z, z, torch.zeros((0, 2), device=device)
+    return planar.centers, planar.normals, planar.dimensions
+
+
+def _cylinder_tables(tower):
+    """The six ``TowerTargetAreasCylindrical`` tensors (artist/field/tower_target_areas_cylindrical.py:52-102) or
+    None when the tower has none."""
+    if len(tower.target_areas) < 2 or int(tower.number_of_target_areas_per_type[1]) == 0:
+        return None
+    c = tower.target_areas[1]
+    return (c.centers, c.normals, c.axes, c.radii, c.heights, c.opening_angles)
+
+
 class HeliostatRayTracer:
     """See ``artist/raytracing/heliostat_ray_tracer.py:19-69`` for the attribute documentation."""
 
@@ -119,8 +138,6 @@ class HeliostatRayTracer:
                 group.preferred_reflection_directions = reflect(incident_ray_directions.unsqueeze(1), normals)
 
         tower = self.scenario.solar_tower
-        n_planar = int(tower.number_of_target_areas_per_type[0])
-        planar = tower.target_areas[0]
         idx, dist_u, dist_e = self._local_rows(device)
         if idx is not None:
             points, normals = points.index_select(0, idx), normals.index_select(0, idx)
@@ -130,45 +147,40 @@ class HeliostatRayTracer:
             lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
             if lo < 0 or hi >= int(tower.number_of_target_areas_per_type.sum()):
                 raise IndexError("target_area_indices out of range")
-            if hi >= n_planar:
-                raise NotImplementedError(
-                    "cylindrical target areas (geometry.line_cylinder_intersections) are not implemented in the "
-                    "MI355X path yet")
 
         ray_magnitude = float(self.ray_magnitude)
         width, height = self._resolution_host
+        planar = _planar_tables(tower, points.device)
         flux, factors = ops.TraceRays.apply(
-            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, planar.centers,
-            planar.normals, planar.dimensions, ray_magnitude, float(ray_extinction_factor), float(mirror_reflectivity),
-            width, height, False)
+            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
+            ray_magnitude, float(ray_extinction_factor), float(mirror_reflectivity), width, height, False,
+            _cylinder_tables(tower))
         return flux, factors[0], factors[1], factors[2]
 
     def trace_rays_per_target(self, incident_ray_directions, active_heliostats_mask, target_area_indices,
                               ray_extinction_factor: float = 0.0, mirror_reflectivity: float = 0.935,
                               device: torch.device | None = None):
         """``trace_rays`` + ``get_bitmaps_per_target`` without materialising ``[H,res,res]``: every
-        heliostat's rays are splatted straight into its target's bitmap (``[T,res_u,res_e]``).
-        Extension of the reference API for field-scale flux prediction (configs 3 and 5)."""
+        heliostat's rays are splatted straight into its target's bitmap (``[T,res_u,res_e]``, planar areas
+        first, cylindrical second).  Extension of the reference API for field-scale flux prediction
+        (configs 3 and 5)."""
         group = self.heliostat_group
         assert torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
             "Some heliostats were not aligned and cannot be raytraced."
         points, normals = group.active_surface_points, group.active_surface_normals
         device = points.device if device is None else torch.device(device)
         tower = self.scenario.solar_tower
-        planar = tower.target_areas[0]
         idx, dist_u, dist_e = self._local_rows(device)
         if idx is not None:
             points, normals = points.index_select(0, idx), normals.index_select(0, idx)
             incident_ray_directions = incident_ray_directions.index_select(0, idx)
             target_area_indices = target_area_indices.index_select(0, idx)
         width, height = self._resolution_host
+        planar = _planar_tables(tower, points.device)
         flux, factors = ops.TraceRays.apply(
-            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, planar.centers,
-            planar.normals, planar.dimensions, float(self.ray_magnitude), float(ray_extinction_factor),
-            float(mirror_reflectivity), width, height, True)
-        n_total = int(tower.number_of_target_areas_per_type.sum())
-        if n_total > flux.shape[0]:   # cylindrical slots stay zero, like get_bitmaps_per_target's zeros init
-            flux = torch.cat([flux, flux.new_zeros((n_total - flux.shape[0],) + tuple(flux.shape[1:]))])
+            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
+            float(self.ray_magnitude), float(ray_extinction_factor), float(mirror_reflectivity), width, height, True,
+            _cylinder_tables(tower))
         return flux, factors[0], factors[1], factors[2]
 
     def get_bitmaps_per_target(self, bitmaps_per_heliostat: torch.Tensor, target_area_indices: torch.Tensor,

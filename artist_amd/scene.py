@@ -57,6 +57,21 @@ class TowerTargetAreasPlanar:
         self.number_of_target_areas = len(names)
 
 
+class TowerTargetAreasCylindrical:
+    """artist/field/tower_target_areas_cylindrical.py:52-102 (centre = midpoint of the axis; ``normals`` points to
+    the middle of the opening sector)."""
+
+    def __init__(self, names, centers, normals, axes, radii, heights, opening_angles) -> None:
+        self.names = names
+        self.centers = centers
+        self.normals = normals
+        self.axes = axes
+        self.radii = radii
+        self.heights = heights
+        self.opening_angles = opening_angles
+        self.number_of_target_areas = len(names)
+
+
 class _NoCylinders:
     names: list = []
     number_of_target_areas = 0
@@ -76,7 +91,9 @@ class SolarTower:
         self.target_name_to_index = {n: i for i, n in enumerate(names)}
 
     def get_centers_of_target_areas(self, target_area_indices: torch.Tensor, device=None) -> torch.Tensor:
-        return self.target_areas[0].centers[target_area_indices]
+        """Centres by GLOBAL target index, planar first, cylindrical second (artist/field/solar_tower.py:133-185)."""
+        tables = [t.centers for t in self.target_areas if t.number_of_target_areas > 0]
+        return torch.cat(tables)[target_area_indices]
 
 
 def ideal_orientations(positions: torch.Tensor, aim_points: torch.Tensor, incident: torch.Tensor) -> torch.Tensor:

@@ -38,11 +38,12 @@ const char *art_strerror(int code);
 int art_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------
- * art_trace_fwd - HeliostatRayTracer.trace_rays with blocking off and planar targets:
+ * art_trace_fwd - HeliostatRayTracer.trace_rays with blocking off, planar and cylindrical targets:
  *   artist/raytracing/heliostat_ray_tracer.py:220-508 =
  *     geometry.reflect                (artist/raytracing/geometry.py:11-41)
  *   + scatter_rays/rotate_distortions (heliostat_ray_tracer.py:510-561, artist/geometry/transforms.py:7-83)
- *   + line_plane_intersections        (artist/raytracing/geometry.py:44-204)
+ *   + line_plane_intersections        (artist/raytracing/geometry.py:44-204)      planar target areas
+ *   + line_cylinder_intersections     (artist/raytracing/geometry.py:207-445)     cylindrical target areas
  *   + intensity product               (heliostat_ray_tracer.py:482-487)
  *   + bilinear_splatting              (heliostat_ray_tracer.py:610-778)
  *   + the three diagnostic factors    (heliostat_ray_tracer.py:498-506)
@@ -53,36 +54,45 @@ int art_last_hip_error(void);
  *   dist_u, dist_e    distortion angles; element (h,r,p) at base[h*dist_sh + r*dist_sr + p*dist_sp]
  *                     (element strides: Sun.get_distortions returns stride-2 views of one
  *                     interleaved [H,R,P,2] buffer, artist/scene/sun.py:227-234)
- *   target_idx        [H] int32, each in [0,T)
- *   plane_centers / plane_normals [T,4], plane_dims [T,2]  TowerTargetAreasPlanar tensors
+ *   target_idx        [H] int32 in [0, T + Tc): t < T is planar area t, t >= T is cylinder t - T
+ *                     (the reference keeps two index lists, indices.planar_target_areas /
+ *                     indices.cylindrical_target_areas, heliostat_ray_tracer.py:337-429; the binding
+ *                     concatenates them in that order)
+ *   plane_centers / plane_normals [T,4], plane_dims [T,2]  TowerTargetAreasPlanar tensors (NULL if T == 0)
+ *   cyl_centers / cyl_normals / cyl_axes [Tc,4], cyl_radii / cyl_heights / cyl_opening [Tc]
+ *                     TowerTargetAreasCylindrical tensors (NULL if Tc == 0)
  *   ray_magnitude     Rays.ray_magnitudes fill value (heliostat_ray_tracer.py:185-203)
  *   extinction, reflectivity  trace_rays(ray_extinction_factor, mirror_reflectivity)
- *   W, Hh             bitmap_resolution[0] (east), bitmap_resolution[1] (up)
+ *   W, Hh             bitmap_resolution[0] (east / angle), bitmap_resolution[1] (up)
  *   mode              0: flux is [H,Hh,W] (one bitmap per active heliostat)
- *                     1: flux is [T,Hh,W] (summed per target area)
+ *                     1: flux is [T+Tc,Hh,W] (summed per target area)
  *   flux              output, zero-filled then accumulated; rows already up-down flipped
  *   factors           output [3,H]: intercept, on_target, blocking fractions
  * ------------------------------------------------------------------------------------------- */
 int art_trace_fwd(const float *origins, const float *normals, const float *incident,
                   const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
                   const int32_t *target_idx, const float *plane_centers, const float *plane_normals,
-                  const float *plane_dims, double ray_magnitude, double extinction, double reflectivity,
-                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t W, int64_t Hh, int mode,
+                  const float *plane_dims, const float *cyl_centers, const float *cyl_normals,
+                  const float *cyl_axes, const float *cyl_radii, const float *cyl_heights,
+                  const float *cyl_opening, double ray_magnitude, double extinction, double reflectivity,
+                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
                   float *flux, float *factors, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * art_trace_bwd - what torch.autograd derives for the op chain of art_trace_fwd (mode 0 or 1):
  * indices and masks are constants, gradients flow through the bilinear weights, the Lambert
- * intensity and the hit point (heliostat_ray_tracer.py:285-290, 328-335, 390-409, 482-494,
- * 610-778).  Same inputs as the forward plus
- *   grad_flux     [H,Hh,W] (mode 0) or [T,Hh,W] (mode 1)
+ * intensity and the hit point (heliostat_ray_tracer.py:285-290, 328-335, 390-429, 482-494,
+ * 610-778; geometry.py:287-445 for cylinders).  Same inputs as the forward plus
+ *   grad_flux     [H,Hh,W] (mode 0) or [T+Tc,Hh,W] (mode 1)
  *   grad_origins, grad_normals   outputs [H,P,4] (w components 0 / as autograd gives them)
  * ------------------------------------------------------------------------------------------- */
 int art_trace_bwd(const float *origins, const float *normals, const float *incident,
                   const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
                   const int32_t *target_idx, const float *plane_centers, const float *plane_normals,
-                  const float *plane_dims, double ray_magnitude, double extinction, double reflectivity,
-                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t W, int64_t Hh, int mode,
+                  const float *plane_dims, const float *cyl_centers, const float *cyl_normals,
+                  const float *cyl_axes, const float *cyl_radii, const float *cyl_heights,
+                  const float *cyl_opening, double ray_magnitude, double extinction, double reflectivity,
+                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
                   const float *grad_flux, float *grad_origins, float *grad_normals, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

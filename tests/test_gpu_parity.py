@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import STAGE_CASES, rel_l2, sun_distortions
+from conftest import CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
 
 pytestmark = pytest.mark.gpu
 
@@ -481,3 +481,161 @@ def test_nurbs_nonuniform_knots_and_many_points():
     o_g = oracle.nurbs_bwd(cp.numpy(), uv.numpy(), [3, 2], gp.numpy(), gn.numpy(), knots_u=ku.numpy(), knots_v=kv.numpy(),
                            uniform=False)
     assert rel_l2(n(surf.control_points.grad), o_g) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# Cylindrical receivers (geometry.line_cylinder_intersections, artist/raytracing/geometry.py:207-445).
+# In fp32 the hit is ill-conditioned at the fixtures' geometry (b^2 - 4ac cancels ~400x): the yardstick
+# is the reference's own fp32-vs-fp64 error, as in tests/test_oracle_golden.py::test_cylinder_stages_fp32.
+# ---------------------------------------------------------------------------------------------
+def cyl_inputs(d):
+    return tuple(t(d[k]) for k in ("cyl_centers", "cyl_normals", "cyl_axes", "cyl_radii", "cyl_heights", "cyl_opening"))
+
+
+@pytest.mark.parametrize("name", CYL_CASES)
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_trace_forward_cylinders(golden, name, interleaved):
+    from artist_amd import trace_rays
+    d, d64 = golden(name), golden(name + "_f64")
+    flux, fac = trace_rays(**trace_inputs(d, interleaved), cyl=cyl_inputs(d))
+    o_flux, o_fac = oracle_fwd(d, cyl=oracle.cyl_tables(d))
+    yard = rel_l2(d["flux"], d64["flux"])                 # what fp32 does to the reference itself
+    assert rel_l2(n(flux), o_flux) < max(yard, 2e-3), (rel_l2(n(flux), o_flux), yard)
+    assert rel_l2(n(flux), d["flux"]) < max(yard, 2e-3), (rel_l2(n(flux), d["flux"]), yard)
+    assert rel_l2(n(flux), d64["flux"]) < 2 * max(yard, 2e-3)
+    # planar heliostats of the mixed case are untouched by the cylinder launch: same bar as test_trace_forward
+    planar = d["target_idx"] < d["target_centers"].shape[0]
+    if planar.any():
+        assert rel_l2(n(flux)[planar], o_flux[planar]) < 2e-4
+        np.testing.assert_array_equal(n(fac)[:, planar], o_fac[:, planar])
+    # ray counts: a sin/cos ULP can move a ray across the sector edge; <= 1e-3 of the rays do
+    np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=1e-3)
+    np.testing.assert_allclose(n(fac[0]), d["intercept"], rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", CYL_CASES)
+def test_trace_backward_cylinders(golden, name):
+    from artist_amd import trace_rays
+    d, d64 = golden(name), golden(name + "_f64")
+    inp = trace_inputs(d)
+    inp["origins"].requires_grad_(True)
+    inp["normals"].requires_grad_(True)
+    flux, _ = trace_rays(**inp, cyl=cyl_inputs(d))
+    (flux * t(d["loss_weights"])).sum().backward()
+    go, gn = oracle.trace_bwd(d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"],
+                              d["distortions_e"], d["target_idx"], d["target_centers"], d["target_normals"],
+                              d["target_dims"], d["resolution"], d["loss_weights"], float(d["ray_magnitude"]),
+                              float(d["extinction"]), float(d["reflectivity"]), cyl=oracle.cyl_tables(d))
+    for got, orc, key in ((inp["origins"].grad, go, "grad_aligned_points"), (inp["normals"].grad, gn, "grad_aligned_normals")):
+        yard = rel_l2(d[key], d64[key])
+        assert rel_l2(n(got), orc) < max(yard, 1e-3), (key, rel_l2(n(got), orc), yard)
+        assert rel_l2(n(got), d[key]) < max(2 * yard, 1e-3), (key, rel_l2(n(got), d[key]), yard)
+        assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)
+
+
+def test_cylinder_per_target_mode(golden):
+    from artist_amd import per_target_sum, trace_rays
+    d = golden("small_cyl_mixed")
+    T, Tc = d["target_centers"].shape[0], d["cyl_centers"].shape[0]
+    inp = trace_inputs(d)
+    flux_h, _ = trace_rays(**inp, cyl=cyl_inputs(d))
+    flux_t, _ = trace_rays(**inp, cyl=cyl_inputs(d), per_target=True)
+    assert flux_t.shape[0] == T + Tc
+    summed = per_target_sum(flux_h, inp["target_idx"], T + Tc)
+    np.testing.assert_allclose(n(flux_t), n(summed), rtol=0, atol=2e-6 * float(summed.max()))
+    assert rel_l2(n(summed), d["per_target"]) < 5e-3
+
+
+def _wide_cylinder_case(seed=3, H=3, P=640, R=24, res=(192, 64)):
+    """Well-conditioned cylinder geometry (radius 25 m, mirrors 60-80 m away: cancellation ~10x, not 400x), where
+    fp32 must agree with the fp64 oracle tightly - this is the test that pins the HIP cylinder arithmetic."""
+    g = torch.Generator().manual_seed(seed)
+    centre = torch.tensor([0.0, 0.0, 40.0])
+    pos = torch.tensor([[-30.0, 60.0, 2.0], [5.0, 75.0, 2.0], [40.0, 55.0, 2.0]])[:H]
+    sun = torch.tensor([0.2, -0.5, -0.84]); sun = sun / sun.norm()
+    hdir = (pos - centre) * torch.tensor([1.0, 1.0, 0.0])
+    to_t = centre + 25.0 * hdir / hdir.norm(dim=1, keepdim=True) - pos        # aim at the mantle, mid height
+    to_t = to_t / to_t.norm(dim=1, keepdim=True)
+    nrm0 = to_t - sun
+    nrm0 = nrm0 / nrm0.norm(dim=1, keepdim=True)
+    local = (torch.rand((H, P, 3), generator=g) - 0.5) * torch.tensor([3.0, 3.0, 0.0])
+    ex = torch.linalg.cross(nrm0, torch.tensor([[0.0, 0.0, 1.0]]).expand(H, 3))
+    ex = ex / ex.norm(dim=1, keepdim=True)
+    ey = torch.linalg.cross(nrm0, ex)
+    pts = pos[:, None] + local[..., :1] * ex[:, None] + local[..., 1:2] * ey[:, None]
+    nrm = nrm0[:, None] + 2e-3 * torch.randn((H, P, 3), generator=g)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    origins = torch.cat([pts, torch.ones(H, P, 1)], -1)
+    normals = torch.cat([nrm, torch.zeros(H, P, 1)], -1)
+    incident = torch.cat([sun, torch.zeros(1)]).expand(H, 4).contiguous()
+    both = 2e-3 * torch.randn((H, R, P, 2), generator=g)
+    cyl = dict(centers=torch.tensor([[0.0, 0.0, 40.0, 1.0]]), normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]]),
+               axes=torch.tensor([[0.0, 0.0, 1.0, 0.0]]), radii=torch.tensor([25.0]), heights=torch.tensor([12.0]),
+               opening=torch.tensor([2.6]))
+    return origins, normals, incident, both, cyl, res
+
+
+def test_cylinder_well_conditioned_vs_fp64_oracle():
+    from artist_amd import trace_rays
+    origins, normals, incident, both, cyl, res = _wide_cylinder_case()
+    H = origins.shape[0]
+    tix = torch.zeros(H, dtype=torch.int32)                     # T == 0: index 0 is cylinder 0
+    dev_both = both.to(DEV)
+    empty4, empty2 = torch.zeros((0, 4), device=DEV), torch.zeros((0, 2), device=DEV)
+    o, nn = origins.to(DEV).requires_grad_(True), normals.to(DEV).requires_grad_(True)
+    cyl_dev = tuple(v.to(DEV) for v in (cyl["centers"], cyl["normals"], cyl["axes"], cyl["radii"], cyl["heights"], cyl["opening"]))
+    flux, fac = trace_rays(o, nn, incident.to(DEV), dev_both[..., 0], dev_both[..., 1], tix.to(DEV), empty4, empty4, empty2,
+                           ray_magnitude=1.0, extinction=0.1, reflectivity=0.9, resolution=res, cyl=cyl_dev)
+    f64 = lambda x: x.double().numpy()
+    cyl64 = {k: f64(v) for k, v in cyl.items()}
+    z4, z2 = np.zeros((0, 4)), np.zeros((0, 2))
+    o_flux, o_fac = oracle.trace_fwd(f64(origins), f64(normals), f64(incident), f64(both[..., 0]), f64(both[..., 1]),
+                                     tix.numpy(), z4, z4, z2, res, 1.0, 0.1, 0.9, cyl=cyl64)
+    assert o_flux.sum() > 0.5 * both.shape[1] * origins.shape[1] * H * 0.3      # the beam is on the receiver
+    assert rel_l2(n(flux), o_flux) < 5e-5, rel_l2(n(flux), o_flux)      # the fp32 oracle sits at 7e-6 here
+    np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=2e-4)
+    w = torch.linspace(0.5, 1.5, res[0] * res[1]).reshape(res[1], res[0]).expand(H, -1, -1).contiguous()
+    (flux * w.to(DEV)).sum().backward()
+    go, gn = oracle.trace_bwd(f64(origins), f64(normals), f64(incident), f64(both[..., 0]), f64(both[..., 1]),
+                              tix.numpy(), z4, z4, z2, res, f64(w), 1.0, 0.1, 0.9, cyl=cyl64)
+    # smooth loss weights: cell flips cost little and the fp32 oracle sits at 1e-6 here
+    assert rel_l2(n(o.grad), go) < 2e-4, rel_l2(n(o.grad), go)
+    assert rel_l2(n(nn.grad), gn) < 2e-4, rel_l2(n(nn.grad), gn)
+
+
+def test_cylinder_through_ray_tracer_mirror():
+    """``HeliostatRayTracer`` with a tower that has planar AND cylindrical areas: global target indices, planar
+    first (heliostat_ray_tracer.py:337-429), against the oracle."""
+    from artist_amd import HeliostatRayTracer
+    from artist_amd.scene import SolarTower, TowerTargetAreasCylindrical, build_synthetic_scenario
+    H = 6
+    scenario, _ = build_synthetic_scenario(H, 20, n_eval=16, device=DEV)
+    planar = scenario.solar_tower.target_areas[0]
+    cyl = TowerTargetAreasCylindrical(
+        names=["cyl"], centers=torch.tensor([[0.0, -12.0, 55.0, 1.0]], device=DEV),
+        normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=DEV), axes=torch.tensor([[0.0, 0.0, 1.0, 0.0]], device=DEV),
+        radii=torch.tensor([12.0], device=DEV), heights=torch.tensor([30.0], device=DEV),
+        opening_angles=torch.tensor([2.0], device=DEV))
+    scenario.solar_tower = SolarTower([planar, cyl], device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    tix = torch.tensor([0, 1, 1, 0, 1, 0], device=DEV)
+    inc = torch.tensor([0.0, 1.0, -1.0, 0.0], device=DEV)
+    inc = (inc / inc.norm()).expand(H, 4).contiguous()
+    group.activate_heliostats(mask, DEV)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask, DEV)
+    rt = HeliostatRayTracer(scenario, group, blocking_active=False, bitmap_resolution=torch.tensor([64, 64]))
+    flux, intercept, on_target, blocking = rt.trace_rays(inc, mask, tix)
+    assert flux.shape == (H, 64, 64) and bool((intercept[tix == 1] > 0.5).all())
+    c = scenario.solar_tower.target_areas[1]
+    cyl_np = dict(centers=n(c.centers), normals=n(c.normals), axes=n(c.axes), radii=n(c.radii), heights=n(c.heights),
+                  opening=n(c.opening_angles))
+    o_flux, o_fac = oracle.trace_fwd(n(group.active_surface_points), n(group.active_surface_normals), n(inc),
+                                     n(rt.distortions_dataset.distortions_u), n(rt.distortions_dataset.distortions_e),
+                                     n(tix), n(planar.centers), n(planar.normals), n(planar.dimensions), (64, 64),
+                                     cyl=cyl_np)
+    assert rel_l2(n(flux), o_flux) < 1e-3, rel_l2(n(flux), o_flux)
+    np.testing.assert_allclose(n(intercept), o_fac[0], rtol=0, atol=1e-3)
+    pt, *_ = rt.trace_rays_per_target(inc, mask, tix)
+    assert pt.shape[0] == 2
+    assert rel_l2(n(pt), n(rt.get_bitmaps_per_target(flux, tix))) < 1e-6
