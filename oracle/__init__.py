@@ -87,9 +87,24 @@ def _cyl_args(cyl, dt):
     return [_p(a) for a in keep] + [_i64(keep[3].shape[0])], keep
 
 
+def _blocking_args(blocking, dt, H):
+    """``blocking`` = None or dict(corners [N,4,4], spans [N,2,4], normals [N,4], owner [H][, lbvh_compat]): the
+    tables of ALL blocking primitives and, per traced heliostat, the index of its own rectangle.  ``lbvh_compat``
+    (default True) restricts the filter to the primitives that are reachable in the reference's tree."""
+    if blocking is None:
+        return [None] * 4 + [_i64(0), ctypes.c_int(1)], [], 0
+    keep = [_c(blocking["corners"], dt), _c(blocking["spans"], dt), _c(blocking["normals"], dt),
+            _c(blocking["owner"], np.int32)]
+    N = keep[0].shape[0]
+    assert keep[0].shape == (N, 4, 4) and keep[1].shape == (N, 2, 4) and keep[2].shape == (N, 4) and keep[3].shape == (H,)
+    return [_p(a) for a in keep] + [_i64(N), ctypes.c_int(1 if blocking.get("lbvh_compat", True) else 0)], keep, N
+
+
 def trace_fwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-              resolution, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, debug=False, cyl=None):
-    """Returns (flux [H,Hh,W], factors [3,H]) and, with debug=True, a dict of per-stage arrays."""
+              resolution, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, debug=False, cyl=None,
+              blocking=None):
+    """Returns (flux [H,Hh,W], factors [3,H]) and, with debug=True, a dict of per-stage arrays (with blocking:
+    also ``blocked`` [H,R,P] and ``filter_flags`` [N])."""
     dt = origins.dtype
     o, n, inc = _c(origins, dt), _c(normals, dt), _c(incident, dt)
     du = np.asarray(dist_u, dtype=dt)
@@ -109,18 +124,25 @@ def trace_fwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, p
                    e_px=np.empty((H, R, P), dt), u_px=np.empty((H, R, P), dt),
                    distances=np.empty((H, R, P), dt), intensities=np.empty((H, R, P), dt))
     cargs, _keep = _cyl_args(cyl, dt)
+    bargs, _keepb, N = _blocking_args(blocking, dt, H)
+    if debug and N:
+        dbg.update(blocked=np.empty((H, R, P), dt), filter_flags=np.empty((N,), np.int32))
     rc = getattr(lib(), "orc_trace_fwd" + _sfx(dt))(
         _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d), *cargs,
+        *bargs, _p(dbg.get("filter_flags")),
         _dbl(ray_magnitude), _dbl(extinction), _dbl(reflectivity),
         _i64(H), _i64(R), _i64(P), _i64(T), _i64(W), _i64(Hh), _p(flux), _p(factors), ctypes.c_int(nthreads),
         _p(dbg.get("reflected")), _p(dbg.get("scattered")), _p(dbg.get("e_px")), _p(dbg.get("u_px")),
-        _p(dbg.get("distances")), _p(dbg.get("intensities")))
+        _p(dbg.get("distances")), _p(dbg.get("intensities")), _p(dbg.get("blocked")))
     _check(rc, "trace_fwd")
     return (flux, factors, dbg) if debug else (flux, factors)
 
 
 def trace_bwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-              resolution, grad_flux, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, cyl=None):
+              resolution, grad_flux, ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, nthreads=0, cyl=None,
+              blocking=None):
+    """(grad_origins, grad_normals); with ``blocking`` also the DIRECT gradients w.r.t. the primitive tables
+    (grad_corners [N,4,4] - corner 0 only -, grad_spans [N,2,4], grad_normals [N,4])."""
     dt = origins.dtype
     o, n, inc = _c(origins, dt), _c(normals, dt), _c(incident, dt)
     du = np.asarray(dist_u, dtype=dt)
@@ -135,12 +157,68 @@ def trace_bwd(origins, normals, incident, dist_u, dist_e, target_idx, centers, p
     assert g.shape == (H, Hh, W)
     go, gn = np.empty_like(o), np.empty_like(n)
     cargs, _keep = _cyl_args(cyl, dt)
+    bargs, _keepb, N = _blocking_args(blocking, dt, H)
+    gpc = np.zeros((N, 4, 4), dt) if N else None
+    gps = np.zeros((N, 2, 4), dt) if N else None
+    gpn = np.zeros((N, 4), dt) if N else None
     rc = getattr(lib(), "orc_trace_bwd" + _sfx(dt))(
-        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d), *cargs,
+        _p(o), _p(n), _p(inc), _p(du), _p(de), *_dist_args(du, de), _p(tix), _p(c), _p(m), _p(d), *cargs, *bargs,
         _dbl(ray_magnitude), _dbl(extinction), _dbl(reflectivity),
-        _i64(H), _i64(R), _i64(P), _i64(T), _i64(W), _i64(Hh), _p(g), _p(go), _p(gn), ctypes.c_int(nthreads))
+        _i64(H), _i64(R), _i64(P), _i64(T), _i64(W), _i64(Hh), _p(g), _p(go), _p(gn), _p(gpc), _p(gps), _p(gpn),
+        ctypes.c_int(nthreads))
     _check(rc, "trace_bwd")
-    return go, gn
+    return (go, gn, gpc, gps, gpn) if N else (go, gn)
+
+
+def blocking_primitives(surfaces):
+    """create_blocking_primitives_rectangles_by_index (artist/raytracing/blocking.py:123-209)."""
+    dt = surfaces.dtype
+    sfc = _c(surfaces, dt)
+    N, P = sfc.shape[0], sfc.shape[1]
+    corners, spans, normals = np.zeros((N, 4, 4), dt), np.zeros((N, 2, 4), dt), np.zeros((N, 4), dt)
+    _check(getattr(lib(), "orc_blocking_primitives" + _sfx(dt))(_p(sfc), _i64(N), _i64(P), _p(corners), _p(spans),
+                                                                _p(normals)), "blocking_primitives")
+    return corners, spans, normals
+
+
+def lbvh_live(corners):
+    """Which primitives the reference's LBVH (blocking.py:514-749) can reach from its root (1 = reachable)."""
+    dt = corners.dtype
+    cc = _c(corners, dt)
+    live = np.zeros((cc.shape[0],), np.int32)
+    _check(getattr(lib(), "orc_lbvh_live" + _sfx(dt))(_p(cc), _i64(cc.shape[0]), _p(live)), "lbvh_live")
+    return live
+
+
+def blocking_filter(origins3, dirs3, t_target, owner, corners, lbvh_compat=True):
+    """lbvh_filter_blocking_planes (:832-995) for independent rays -> indices of the primitives that are hit."""
+    dt = origins3.dtype
+    o, dd, tt, cc = _c(origins3, dt), _c(dirs3, dt), _c(t_target, dt), _c(corners, dt)
+    ow = _c(owner, np.int32)
+    flags = np.zeros((cc.shape[0],), np.int32)
+    _check(getattr(lib(), "orc_blocking_filter" + _sfx(dt))(_p(o), _p(dd), _p(tt), _p(ow), _i64(o.shape[0]), _p(cc),
+                                                            _i64(cc.shape[0]), ctypes.c_int(int(lbvh_compat)),
+                                                            _p(flags)), "blocking_filter")
+    return np.nonzero(flags)[0]
+
+
+def soft_blocking(origins3, dirs3, corners, spans, normals):
+    """soft_ray_blocking_mask (:212-354) for independent rays against all given primitives."""
+    dt = origins3.dtype
+    o, dd = _c(origins3, dt), _c(dirs3, dt)
+    cc, ss, nn = _c(corners, dt), _c(spans, dt), _c(normals, dt)
+    out = np.empty((o.shape[0],), dt)
+    _check(getattr(lib(), "orc_soft_blocking" + _sfx(dt))(_p(o), _p(dd), _i64(o.shape[0]), _p(cc), _p(ss), _p(nn),
+                                                          _i64(cc.shape[0]), _p(out)), "soft_blocking")
+    return out
+
+
+def blocking_tables(d, H=None):
+    """The blocking tables of a golden fixture as the ``blocking=`` argument (one group, every heliostat active:
+    heliostat h owns primitive h)."""
+    H = d["aligned_points"].shape[0] if H is None else H
+    return dict(corners=d["prim_corners"], spans=d["prim_spans"], normals=d["prim_normals"],
+                owner=np.arange(H, dtype=np.int32))
 
 
 def per_target(bitmaps, target_idx, n_targets):

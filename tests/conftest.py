@@ -39,6 +39,7 @@ def golden():
 
 
 STAGE_CASES = ["small_deg3", "small_deg2_tilted", "small_offtarget", "mid_256"]
+BLOCKING_CASES = ["small_blocking", "mid_blocking"]   # blocking_active=True (artist/raytracing/blocking.py)
 CYL_CASES = ["small_cyl_mixed", "mid_cyl"]   # cylindrical receivers (ill-conditioned in fp32: see test_oracle_golden.py)
 
 

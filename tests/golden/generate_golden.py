@@ -81,6 +81,7 @@ from artist.nurbs.utils import (  # noqa: E402
     create_nurbs_evaluation_grid,
     create_planar_nurbs_control_points,
 )
+from artist.raytracing import blocking as ref_blocking  # noqa: E402
 from artist.raytracing import geometry  # noqa: E402
 from artist.raytracing.heliostat_ray_tracer import HeliostatRayTracer  # noqa: E402
 from artist.raytracing.sampling import RestrictedDistributedSampler  # noqa: E402
@@ -268,8 +269,24 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
                aligned_points=npy(apts), aligned_normals=npy(anrm),
                active_mask=npy(mask), target_idx=npy(target_idx))
 
+    use_blocking = bool(case.get("blocking", False))
+    captured_prims = []
+    if use_blocking:
+        # trace_rays builds the primitives internally: wrap the builder so that the tensors it returned can be
+        # stored and their gradients retained (they are non-leaf tensors of the autograd graph)
+        _orig_builder = ref_blocking.create_blocking_primitives_rectangles_by_index
+
+        def _capturing_builder(*a, **k):
+            prims = _orig_builder(*a, **k)
+            if with_grads and prims[0].requires_grad:
+                for t_ in prims:
+                    t_.retain_grad()
+            captured_prims.append(prims)
+            return prims
+
+        ref_blocking.create_blocking_primitives_rectangles_by_index = _capturing_builder
     rt = HeliostatRayTracer(
-        scenario=scenario, heliostat_group=group, blocking_active=False,
+        scenario=scenario, heliostat_group=group, blocking_active=use_blocking,
         batch_size=case.get("batch_size", 100), random_seed=case.get("seed", 7),
         bitmap_resolution=res, dni=case.get("dni", None),
     )
@@ -312,7 +329,25 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
                     rays=Rays(rays.ray_directions[~pm], rays.ray_magnitudes[~pm]), points_at_ray_origins=apts[~pm],
                     target_areas=b["cyl"], target_area_indices=target_idx[~pm] - n_planar, bitmap_resolution=res,
                     device=CPU)
-            inten_abs = inten * (1 - 0.0) * (1 - ext) * refl
+            blocked = torch.zeros_like(inten)
+            if use_blocking:
+                # the calls of heliostat_ray_tracer.py:444-480 for ONE batch holding every heliostat
+                corners, spans, pnormals = _orig_builder(
+                    blocking_heliostats_active_surface_points=rt.blocking_heliostat_surfaces_active, device=CPU)
+                owner = torch.nonzero(mask, as_tuple=True)[0].repeat_interleave(e_px.shape[1] * e_px.shape[2])
+                filt = ref_blocking.lbvh_filter_blocking_planes(
+                    points_at_ray_origins=apts, ray_directions=rays.ray_directions,
+                    blocking_primitives_corners=corners, ray_to_heliostat_mapping=owner,
+                    intersection_distances_target=t, device=CPU)
+                if filt.numel() > 0:
+                    blocked = ref_blocking.soft_ray_blocking_mask(
+                        ray_origins=apts, ray_directions=rays.ray_directions,
+                        blocking_primitives_corners=corners[filt], blocking_primitives_spans=spans[filt],
+                        blocking_primitives_normals=pnormals[filt], epsilon=1e-12, softness=1000.0)
+                out.update(prim_corners=npy(corners), prim_spans=npy(spans), prim_normals=npy(pnormals),
+                           filter_indices=npy(filt), blocked=npy(blocked),
+                           blocking_surfaces=npy(rt.blocking_heliostat_surfaces_active))
+            inten_abs = inten * (1 - blocked) * (1 - ext) * refl
             bitmaps = rt.bilinear_splatting(e_px, u_px, inten_abs, device=CPU)
         out.update(reflected=npy(refl_dirs), scattered=npy(rays.ray_directions), e_px=npy(e_px), u_px=npy(u_px),
                    distances=npy(t), intensities=npy(inten), stage_bitmaps=npy(bitmaps))
@@ -334,6 +369,11 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
                    grad_aligned_points=npy(apts.grad), grad_aligned_normals=npy(anrm.grad),
                    grad_nurbs_points=npy(sp.grad), grad_nurbs_normals=npy(sn.grad),
                    grad_orientation=npy(orientation.grad), grad_control_points=npy(cp_active.grad))
+        if use_blocking and captured_prims and captured_prims[-1][0].grad is not None:
+            c_, s_, n_ = captured_prims[-1]
+            out.update(grad_prim_corners=npy(c_.grad), grad_prim_spans=npy(s_.grad), grad_prim_normals=npy(n_.grad))
+    if use_blocking:
+        ref_blocking.create_blocking_primitives_rectangles_by_index = _orig_builder
     torch.set_default_dtype(torch.float32)
     return out, (du32, de32)
 
@@ -389,6 +429,19 @@ CASES["mid_cyl"] = dict(
     target_centers=[[0.0, 0.0, 55.0, 1.0]], target_normals=[[0.0, 1.0, 0.0, 0.0]], target_dims=[[8.0, 8.0]],
     cyl_centers=[[0.0, 0.0, 55.0, 1.0]], cyl_normals=[[0.0, 1.0, 0.0, 0.0]], cyl_axes=[[0.0, 0.0, 1.0, 0.0]],
     cyl_radii=[3.5], cyl_heights=[9.0], cyl_opening=[3.141592653589793], target_idx=[1, 1])
+
+# Blocking (artist/raytracing/blocking.py): a column of heliostats far north of the tower with the sun low in the
+# south, so that the nearly vertical mirrors in front cut into the beams of the ones behind them; the third one
+# is shifted east (partial overlap -> rays inside the sigmoid edge band), the fourth stands clear of the others.
+CASES["small_blocking"] = dict(
+    n_heliostats=4, n_cp=(6, 6), degrees=(3, 3), n_eval=8, n_rays=6, resolution=[64, 64], curvature=1e-3, blocking=True,
+    positions=[[0.0, 140.0, 0.0, 1.0], [0.0, 137.0, 0.0, 1.0], [1.2, 134.0, 0.0, 1.0], [30.0, 120.0, 0.0, 1.0]],
+    extinction=0.02, reflectivity=0.9, **RECEIVER)
+CASES["mid_blocking"] = dict(
+    n_heliostats=5, n_cp=(6, 6), degrees=(3, 3), n_eval=16, n_rays=8, resolution=[128, 128], curvature=1e-3,
+    blocking=True, incident=[[0.1, 0.95, -0.1, 0.0]] * 5,
+    positions=[[0.0, 150.0, 0.0, 1.0], [0.3, 147.2, 0.0, 1.0], [-0.8, 144.0, 0.0, 1.0], [2.0, 141.0, 0.0, 1.0],
+               [-25.0, 100.0, 0.0, 1.0]], **RECEIVER)
 
 # Config 1 of BASELINE.json: 1 heliostat, 4 planar facets, point sun, 10k rays.
 CONFIG1 = dict(n_heliostats=1, n_cp=(10, 10), degrees=(3, 3), n_eval=50, n_rays=1, z_noise=0.0, covariance=1e-12,
@@ -448,6 +501,93 @@ def known_answers():
             f"cyl{i}_expected_i": npy(ei), f"cyl{i}_reference_e": npy(e_px), f"cyl{i}_reference_u": npy(u_px),
             f"cyl{i}_reference_t": npy(t), f"cyl{i}_reference_i": npy(inten)})
     out["cyl_count"] = np.int64(i + 1)
+
+    # tests/raytracing/test_blocking.py:170-333 create_blocking_primitives_rectangles_by_index known answers:
+    # four 5x5-point facets (origins (0,0), (2,0), (2,1), (0,2), size 2x2), flat and rotated/translated.
+    facets = []
+    for x, y in [(0.0, 0.0), (2.0, 0.0), (2.0, 1.0), (0.0, 2.0)]:
+        gx, gy = torch.meshgrid(torch.linspace(x, x + 2.0, 5), torch.linspace(y, y + 2.0, 5), indexing="ij")
+        facets.append(torch.stack([gx.flatten(), gy.flatten(), torch.zeros(25)], dim=-1))
+    flat = torch.cat(facets, dim=0)
+    flat = torch.cat([flat, torch.ones(flat.shape[0], 1)], dim=-1)[None]
+    translation = torch.tensor([[1.0, 0.0, 0.0, 2.0], [0.0, 1.0, 0.0, 3.0], [0.0, 0.0, 1.0, 1.5], [0.0, 0.0, 0.0, 1.0]])
+    moved = flat @ (translation.T @ transforms.rotate_n(n=torch.tensor([0.2]), device=CPU)
+                    @ transforms.rotate_e(e=torch.tensor([0.5]), device=CPU))
+    expected = [
+        ([[[2.0, 1.0, 0.0, 1.0], [0.0, 2.0, 0.0, 1.0], [4.0, 2.0, 0.0, 1.0], [2.0, 2.0, 0.0, 1.0]]],
+         [[[-2.0, 1.0, 0.0, 0.0], [0.0, 1.0, 0.0, 0.0]]], [[0.0, 0.0, -1.0, 0.0]]),
+        ([[[4.2183, 3.8341, -1.3250, 1.0], [2.2581, 4.9022, -1.4557, 1.0], [6.1784, 4.5212, -2.1531, 1.0],
+           [4.2183, 4.7117, -1.8044, 1.0]]],
+         [[[-1.9601, 1.0681, -0.1307, 0.0], [0.0, 0.8776, -0.4794, 0.0]]], [[-0.1987, -0.4699, -0.8601, 0.0]]),
+    ]
+    for i, (surf, exp) in enumerate(zip((flat, moved.reshape(1, -1, 4)), expected)):
+        c_, s_, n_ = ref_blocking.create_blocking_primitives_rectangles_by_index(surf, device=CPU)
+        out.update({f"prim{i}_surface": npy(surf), f"prim{i}_expected_corners": np.asarray(exp[0], np.float32),
+                    f"prim{i}_expected_spans": np.asarray(exp[1], np.float32),
+                    f"prim{i}_expected_normals": np.asarray(exp[2], np.float32),
+                    f"prim{i}_reference_corners": npy(c_), f"prim{i}_reference_spans": npy(s_),
+                    f"prim{i}_reference_normals": npy(n_)})
+
+    # lbvh_filter_blocking_planes (blocking.py:832-995) on random rectangles and rays: the output of the reference's
+    # tree build + traversal, which the brute-force box test of the restatement has to reproduce exactly.
+    # Also soft_ray_blocking_mask (:212-354) of the same rays against ALL rectangles.
+    g = torch.Generator().manual_seed(99)
+    for i, (n_prim, n_ray) in enumerate([(1, 60), (7, 400), (40, 1500)]):
+        centre = (torch.rand((n_prim, 1, 3), generator=g) - 0.5) * torch.tensor([40.0, 40.0, 6.0])
+        a = torch.nn.functional.normalize(torch.randn((n_prim, 3), generator=g), dim=-1)
+        b = torch.nn.functional.normalize(torch.linalg.cross(a, torch.randn((n_prim, 3), generator=g)), dim=-1)
+        ha, hb = 1.0 + torch.rand((n_prim, 1), generator=g), 0.8 + torch.rand((n_prim, 1), generator=g)
+        c0 = centre[:, 0] - ha * a - hb * b
+        corners = torch.stack([c0, c0 + 2 * ha * a, c0 + 2 * ha * a + 2 * hb * b, c0 + 2 * hb * b], dim=1)
+        corners = torch.cat([corners, torch.ones(n_prim, 4, 1)], dim=-1)
+        spans = torch.zeros(n_prim, 2, 4)
+        spans[:, 0], spans[:, 1] = corners[:, 1] - corners[:, 0], corners[:, 3] - corners[:, 0]
+        pn = torch.cat([torch.nn.functional.normalize(torch.linalg.cross(spans[:, 0, :3], spans[:, 1, :3]), dim=-1),
+                        torch.zeros(n_prim, 1)], dim=-1)
+        ro = (torch.rand((1, 1, n_ray, 3), generator=g) - 0.5) * torch.tensor([50.0, 50.0, 8.0])
+        aim = centre[torch.randint(0, n_prim, (n_ray,), generator=g), 0] + 1.5 * torch.randn((n_ray, 3), generator=g)
+        rd = torch.nn.functional.normalize(aim[None, None] - ro, dim=-1)
+        rd[0, 0, ::7, 2] = 0.0                                   # axis-parallel components (1 / (0 + 1e-12))
+        tt = torch.rand((1, 1, n_ray), generator=g) * 60.0
+        tt[0, 0, ::5] = 0.0                                      # rays that missed the target carry distance 0
+        ro4 = torch.cat([ro, torch.ones(1, 1, n_ray, 1)], -1)
+        rd4 = torch.cat([rd, torch.zeros(1, 1, n_ray, 1)], -1)
+        owner = torch.randint(0, n_prim, (n_ray,), generator=g)
+        filt = ref_blocking.lbvh_filter_blocking_planes(
+            points_at_ray_origins=ro4[0], ray_directions=rd4, blocking_primitives_corners=corners,
+            ray_to_heliostat_mapping=owner, intersection_distances_target=tt, device=CPU)
+        soft = ref_blocking.soft_ray_blocking_mask(ro4[0], rd4, corners, spans, pn)
+        out.update({f"lbvh{i}_corners": npy(corners), f"lbvh{i}_spans": npy(spans), f"lbvh{i}_normals": npy(pn),
+                    f"lbvh{i}_origins": npy(ro[0, 0]), f"lbvh{i}_dirs": npy(rd[0, 0]), f"lbvh{i}_t": npy(tt[0, 0]),
+                    f"lbvh{i}_owner": npy(owner), f"lbvh{i}_filtered": npy(filt), f"lbvh{i}_soft": npy(soft[0, 0])})
+    out["lbvh_count"] = np.int64(i + 1)
+
+    # Structure of the reference's tree on field-like layouts (rows of near-vertical rectangles at similar height):
+    # which primitives hang off a path from the root (build_linear_bounding_volume_hierarchies, blocking.py:514-749).
+    for i, (rows, cols) in enumerate([(2, 3), (5, 9), (17, 23), (40, 50)]):
+        n_prim = rows * cols
+        gy, gx = torch.meshgrid(torch.arange(rows, dtype=torch.float32), torch.arange(cols, dtype=torch.float32), indexing="ij")
+        centre = torch.stack([(gx.flatten() - cols / 2) * 6.3 + 0.7 * torch.randn(n_prim, generator=g),
+                              60.0 + gy.flatten() * 7.1 + 0.7 * torch.randn(n_prim, generator=g),
+                              1.5 + 0.2 * torch.randn(n_prim, generator=g)], dim=-1)
+        a = torch.tensor([[1.0, 0.0, 0.0]]).repeat(n_prim, 1)
+        b = torch.nn.functional.normalize(torch.tensor([[0.0, 0.3, 1.0]]) + 0.05 * torch.randn((n_prim, 3), generator=g), dim=-1)
+        c0 = centre - 1.6 * a - 1.3 * b
+        corners = torch.stack([c0, c0 + 2.6 * b, c0 + 3.2 * a + 2.6 * b, c0 + 3.2 * a], dim=1)
+        corners = torch.cat([corners, torch.ones(n_prim, 4, 1)], dim=-1)
+        tree = ref_blocking.build_linear_bounding_volume_hierarchies(corners, device=CPU)
+        left, right, prim = tree["left"].tolist(), tree["right"].tolist(), tree["primitive_index"].tolist()
+        seen, stack, reachable = set(), [0], []
+        while stack:
+            node = stack.pop()
+            if node < 0 or node in seen:
+                continue
+            seen.add(node)
+            if prim[node] >= 0:
+                reachable.append(prim[node])
+            stack += [left[node], right[node]]
+        out.update({f"tree{i}_corners": npy(corners), f"tree{i}_reachable": np.asarray(sorted(reachable), np.int64)})
+    out["tree_count"] = np.int64(i + 1)
     # rotate_distortions: tests/geometry/test_transforms.py (test_distortion_rotations)
     tt = importlib.import_module("tests.geometry.test_transforms")
     k = 0
@@ -508,8 +648,14 @@ def known_answers():
 
 
 def main():
-    save("known_answers", known_answers())
+    only = None
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":     # regenerate a subset (every case is deterministic)
+        only = set(sys.argv[2].split(","))
+    if only is None or "known_answers" in only:
+        save("known_answers", known_answers())
     for name, case in CASES.items():
+        if only is not None and name not in only:
+            continue
         arrs32, dist = run_case(name, case, dtype=torch.float32)
         save(name, arrs32)
         arrs64, _ = run_case(name, case, dtype=torch.float64, distortions_f32=dist)
@@ -522,6 +668,8 @@ def main():
             "target_dims", "resolution", "ray_magnitude", "extinction", "reflectivity", "n_rays", "seed", "covariance",
             "degrees", "eval_points_grid", "canting", "facet_translations", "nurbs_points", "nurbs_normals"}
     for name, case in (("config1", CONFIG1), ("config2", CONFIG2)):
+        if only is not None and name not in only:
+            continue
         arrs32, dist = run_case(name, case, with_grads=False, store_rays=False, dtype=torch.float32)
         a = summarize_large(arrs32, keep)
         a["eval_points_grid"] = arrs32["eval_points"][0, 0]

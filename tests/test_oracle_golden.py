@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
+from conftest import BLOCKING_CASES, CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
 
 
 # ---- reference's own known answers -----------------------------------------------------------
@@ -266,3 +266,125 @@ def test_cylinder_stages_fp32(golden, name):
     for got, key in ((go, "grad_aligned_points"), (gn, "grad_aligned_normals")):
         yard = rel_l2(d[key], d64[key])
         assert rel_l2(got, d[key]) < max(yard, 1e-3), (key, rel_l2(got, d[key]), yard)
+
+
+# ---------------------------------------------------------------------------------------------
+# Blocking (artist/raytracing/blocking.py)
+# ---------------------------------------------------------------------------------------------
+def test_blocking_primitives_known_answers(golden):
+    """tests/raytracing/test_blocking.py:253-333 (values quoted to 4 decimals there: atol = rtol = 5e-4)."""
+    ka = golden("known_answers")
+    for i in range(2):
+        c, s, nrm = oracle.blocking_primitives(ka[f"prim{i}_surface"])
+        np.testing.assert_allclose(c, ka[f"prim{i}_expected_corners"], rtol=5e-4, atol=5e-4)
+        np.testing.assert_allclose(s, ka[f"prim{i}_expected_spans"], rtol=5e-4, atol=5e-4)
+        np.testing.assert_allclose(nrm, ka[f"prim{i}_expected_normals"], rtol=5e-4, atol=5e-4)
+        np.testing.assert_array_equal(c, ka[f"prim{i}_reference_corners"])          # gathers and subtractions: exact
+        np.testing.assert_array_equal(s, ka[f"prim{i}_reference_spans"])
+        np.testing.assert_allclose(nrm, ka[f"prim{i}_reference_normals"], rtol=0, atol=2e-7)
+
+
+def test_blocking_filter_equals_reference_lbvh(golden):
+    """The brute-force box test must return exactly the set the reference's LBVH build + traversal returns."""
+    ka = golden("known_answers")
+    for i in range(int(ka["lbvh_count"])):
+        got = oracle.blocking_filter(ka[f"lbvh{i}_origins"], ka[f"lbvh{i}_dirs"], ka[f"lbvh{i}_t"], ka[f"lbvh{i}_owner"],
+                                     ka[f"lbvh{i}_corners"])
+        np.testing.assert_array_equal(got, ka[f"lbvh{i}_filtered"])
+        assert 0 < len(got) or i == 0
+        soft = oracle.soft_blocking(ka[f"lbvh{i}_origins"], ka[f"lbvh{i}_dirs"], ka[f"lbvh{i}_corners"],
+                                    ka[f"lbvh{i}_spans"], ka[f"lbvh{i}_normals"])
+        # fp32 sigmoid(1000 x) amplifies a 1-ULP difference of x near an edge: compare in the mask's own units
+        np.testing.assert_allclose(soft, ka[f"lbvh{i}_soft"], rtol=0, atol=2e-3)
+        assert np.mean(np.abs(soft - ka[f"lbvh{i}_soft"]) > 1e-5) < 0.01
+
+
+def _blocking_case_args(d, a, an):
+    return (a, an, d["incident"], d["distortions_u"], d["distortions_e"], d["target_idx"], d["target_centers"],
+            d["target_normals"], d["target_dims"], d["resolution"])
+
+
+def _chain_primitive_grads(surfaces, gpc, gps, gpn):
+    """Direct primitive-table gradients -> total gradients of corners / spans / normals and of the surface points
+    they were gathered from, through the builder of the product (torch ops on CPU, autograd)."""
+    import torch
+
+    from artist_amd.blocking import create_blocking_primitives_rectangles_by_index
+    sfc = torch.from_numpy(np.ascontiguousarray(surfaces)).requires_grad_(True)
+    corners, spans, normals = create_blocking_primitives_rectangles_by_index(sfc)
+    for x in (corners, spans, normals):
+        x.retain_grad()
+    torch.autograd.backward([corners, spans, normals], [torch.from_numpy(gpc), torch.from_numpy(gps), torch.from_numpy(gpn)])
+    return corners.grad.numpy(), spans.grad.numpy(), normals.grad.numpy(), sfc.grad.numpy()
+
+
+@pytest.mark.parametrize("name", BLOCKING_CASES)
+def test_blocking_stages_fp64_tight(golden, name):
+    d = golden(name + "_f64")
+    H = d["orientation"].shape[0]
+    ori = d["orientation"]
+    a = d["nurbs_points"].reshape(H, -1, 4) @ ori.transpose(0, 2, 1)
+    an = d["nurbs_normals"].reshape(H, -1, 4) @ ori.transpose(0, 2, 1)
+    np.testing.assert_array_equal(a, d["blocking_surfaces"])            # one group, all active: surfaces = aligned points
+    c, s, nrm = oracle.blocking_primitives(d["blocking_surfaces"])
+    np.testing.assert_allclose(c, d["prim_corners"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(s, d["prim_spans"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(nrm, d["prim_normals"], rtol=0, atol=1e-14)
+    sc = (float(d["ray_magnitude"]), float(d["extinction"]), float(d["reflectivity"]))
+    blk = oracle.blocking_tables(d, H)
+    flux, fac, dbg = oracle.trace_fwd(*_blocking_case_args(d, a, an), *sc, debug=True, blocking=blk)
+    np.testing.assert_array_equal(np.nonzero(dbg["filter_flags"])[0], d["filter_indices"])
+    np.testing.assert_allclose(dbg["blocked"], d["blocked"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(flux, d["flux"], rtol=1e-9, atol=1e-9)
+    for row, key in enumerate(("intercept", "on_target", "blocking")):
+        np.testing.assert_array_equal(fac[row], d[key])
+    assert (d["blocking"] < 0.9).any() and ((d["blocked"] > 1e-3) & (d["blocked"] < 0.999)).any()   # the case blocks
+    go, gn, gpc, gps, gpn = oracle.trace_bwd(*_blocking_case_args(d, a, an), d["loss_weights"], *sc, blocking=blk)
+    assert rel_l2(gn, d["grad_aligned_normals"]) < 1e-9
+    assert rel_l2(gpn, d["grad_prim_normals"]) < 1e-9
+    tc, ts, tn, g_sfc = _chain_primitive_grads(d["blocking_surfaces"], gpc, gps, gpn)
+    assert rel_l2(ts, d["grad_prim_spans"]) < 1e-9 and rel_l2(tc, d["grad_prim_corners"]) < 1e-9
+    # the aligned points are ray origins AND the source of the rectangle corners
+    assert rel_l2(go + g_sfc, d["grad_aligned_points"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", BLOCKING_CASES)
+def test_blocking_stages_fp32(golden, name):
+    d, d64 = golden(name), golden(name + "_f64")
+    H = d["aligned_points"].shape[0]
+    sc = (float(d["ray_magnitude"]), float(d["extinction"]), float(d["reflectivity"]))
+    blk = oracle.blocking_tables(d, H)
+    args = _blocking_case_args(d, d["aligned_points"], d["aligned_normals"])
+    flux, fac, dbg = oracle.trace_fwd(*args, *sc, debug=True, blocking=blk)
+    np.testing.assert_array_equal(np.nonzero(dbg["filter_flags"])[0], d["filter_indices"])
+    # sigmoid(1000 x): one ULP of the hit coordinate is ~1e-4 of the mask inside the edge band
+    np.testing.assert_allclose(dbg["blocked"], d["blocked"], rtol=0, atol=2e-3)
+    assert np.mean(np.abs(dbg["blocked"] - d["blocked"]) > 1e-6) < 0.02
+    yard = rel_l2(d["flux"], d64["flux"])
+    assert rel_l2(flux, d["flux"]) < max(yard, 2e-4), (rel_l2(flux, d["flux"]), yard)
+    for row, key in enumerate(("intercept", "on_target", "blocking")):
+        np.testing.assert_allclose(fac[row], d[key], rtol=0, atol=1.5 / (d["blocked"][0].size))     # <= 1 ray
+    go, gn, gpc, gps, gpn = oracle.trace_bwd(*args, d["loss_weights"], *sc, blocking=blk)
+    tc, ts, tn, g_sfc = _chain_primitive_grads(d["blocking_surfaces"], gpc, gps, gpn)
+    for got, key in ((go + g_sfc, "grad_aligned_points"), (gn, "grad_aligned_normals"), (tc, "grad_prim_corners"),
+                     (ts, "grad_prim_spans"), (gpn, "grad_prim_normals")):
+        yard = rel_l2(d[key], d64[key])
+        assert rel_l2(got, d[key]) < max(yard, 1e-3), (key, rel_l2(got, d[key]), yard)
+
+
+def test_lbvh_reachability_equals_reference_tree(golden):
+    """The reference's split search halves its step by floor division (blocking.py:640-650), which leaves most
+    leaves of a larger tree unreachable from the root; the filter can only ever return reachable primitives, so
+    the restatement has to reproduce exactly that set (here: 3 of 6, 34 of 45, 26 of 391, 3 of 2000)."""
+    ka = golden("known_answers")
+    sizes = []
+    for i in range(int(ka["tree_count"])):
+        live = oracle.lbvh_live(ka[f"tree{i}_corners"])
+        np.testing.assert_array_equal(np.nonzero(live)[0], ka[f"tree{i}_reachable"])
+        sizes.append((live.size, int(live.sum())))
+    assert sizes[-1][1] < sizes[-1][0] // 100          # the defect is real: keep it documented by a failing-if-fixed check
+    # and with compatibility off every primitive can be returned
+    i = 1
+    full = oracle.blocking_filter(ka[f"lbvh{i}_origins"], ka[f"lbvh{i}_dirs"], ka[f"lbvh{i}_t"], ka[f"lbvh{i}_owner"],
+                                  ka[f"lbvh{i}_corners"], lbvh_compat=False)
+    assert set(ka[f"lbvh{i}_filtered"].tolist()) < set(full.tolist())
