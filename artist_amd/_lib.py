@@ -15,7 +15,7 @@ _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ArtistHipError(RuntimeError):
@@ -32,12 +32,19 @@ _ptr = ctypes.c_void_p
 SIGNATURES = {
     "art_trace_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                      _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64,
                       _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr],
     "art_trace_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
+                      _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64,
                       _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
-                      _ptr, _ptr, _ptr, _ptr],
+                      _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "art_blocking_workspace_bytes": [_c_i64, _c_i64],
+    "art_blocking_filter": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
+                            _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_dbl,
+                            _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
+                            _ptr, _ptr, _c_i64, _c_dbl, _c_int, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_per_target_sum": [_ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr],
     "art_nurbs_fwd": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_i64,
                       _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr],
@@ -87,7 +94,8 @@ def lib() -> ctypes.CDLL:
         except AttributeError as exc:
             raise ArtistHipError(f"{LIB_PATH} does not export {name}") from exc
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "art_strerror" else ctypes.c_int
+        fn.restype = (ctypes.c_char_p if name == "art_strerror"
+                      else ctypes.c_int64 if name == "art_blocking_workspace_bytes" else ctypes.c_int)
     if handle.art_abi_version() != ABI_VERSION:
         raise ArtistHipError(f"ABI mismatch: library {handle.art_abi_version()} vs binding {ABI_VERSION}")
     _LIB = handle

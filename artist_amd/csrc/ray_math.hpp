@@ -374,4 +374,153 @@ __device__ __forceinline__ void cyl_hit_bwd(const Cyl& cy, const CylPoint& p, co
     grz = gdx * cy.r02 + gdy * cy.r12 + gdz * cy.r22;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Blocking: soft_ray_blocking_mask (artist/raytracing/blocking.py:212-354) for one ray and one rectangle.
+// The reference evaluates every ray against every filtered primitive; here a ray first passes two
+// exact-arithmetic rejection tests whose thresholds put the skipped contribution below 1e-11 (the mask is
+// 1 - exp(-100 sum sigma), so a skipped term cannot change an fp32 result), and only rays near or inside a
+// rectangle pay for the five sigmoids.
+// ---------------------------------------------------------------------------------------------------
+constexpr float kBlockSoftness = 1000.0f;     // blocking.py:218
+constexpr float kBlockAlpha = 100.0f;         // :219
+constexpr float kBlockOffset = 0.05f;         // :220
+constexpr float kBlockEps = 1e-12f;           // :217
+constexpr float kBlockMargin = 0.026f;        // sigmoid(-1000 * 0.026) = 5e-12
+
+struct Prim {            // one blocking rectangle, 16 floats in LDS
+    float c0x, c0y, c0z;     // corner 0
+    float sux, suy, suz;     // span u = corner 1 - corner 0
+    float svx, svy, svz;     // span v = corner 3 - corner 0
+    float nx, ny, nz;        // plane normal
+    float suu, svv, suv;     // :333-335
+    float det_safe;          // :338-339
+};
+
+__device__ __forceinline__ Prim make_prim(const float* __restrict__ corners, const float* __restrict__ spans,
+                                          const float* __restrict__ normals, int k)
+{
+    Prim q;
+    q.c0x = corners[16 * k]; q.c0y = corners[16 * k + 1]; q.c0z = corners[16 * k + 2];
+    q.sux = spans[8 * k]; q.suy = spans[8 * k + 1]; q.suz = spans[8 * k + 2];
+    q.svx = spans[8 * k + 4]; q.svy = spans[8 * k + 5]; q.svz = spans[8 * k + 6];
+    q.nx = normals[4 * k]; q.ny = normals[4 * k + 1]; q.nz = normals[4 * k + 2];
+    q.suu = (q.sux * q.sux + q.suy * q.suy) + q.suz * q.suz;
+    q.svv = (q.svx * q.svx + q.svy * q.svy) + q.svz * q.svz;
+    q.suv = (q.sux * q.svx + q.suy * q.svy) + q.suz * q.svz;
+    const float det = q.suu * q.svv - q.suv * q.suv;
+    const float sgn = det > 0.0f ? 1.0f : (det < 0.0f ? -1.0f : 0.0f);
+    q.det_safe = fabsf(det) < kBlockEps ? sgn * kBlockEps : det;
+    return q;
+}
+
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+struct SoftHit {
+    float den, den_safe, d;
+    float offx, offy, offz, pu, pv, u, v;
+    bool near;               // passes both rejection tests
+};
+
+// Plane hit (:315-324) and local coordinates (:328-345), reference operation order, in two steps so that a wave
+// whose rays all pass behind / too close to the rectangle's plane skips the second one.
+__device__ __forceinline__ bool soft_plane(const Prim& q, float ox, float oy, float oz, float rx, float ry, float rz,
+                                           SoftHit& s)
+{
+    s.den = (rx * q.nx + ry * q.ny) + rz * q.nz;
+    s.den_safe = fabsf(s.den) < kBlockEps ? (s.den >= 0.0f ? kBlockEps : -kBlockEps) : s.den;
+    const float num = ((q.c0x - ox) * q.nx + (q.c0y - oy) * q.ny) + (q.c0z - oz) * q.nz;
+    s.d = num / s.den_safe;
+    return s.d > kBlockOffset - kBlockMargin;
+}
+
+__device__ __forceinline__ void soft_uv(const Prim& q, float ox, float oy, float oz, float rx, float ry, float rz,
+                                        bool in_front, SoftHit& s)
+{
+    s.offx = (ox + s.d * rx) - q.c0x; s.offy = (oy + s.d * ry) - q.c0y; s.offz = (oz + s.d * rz) - q.c0z;
+    s.pu = (s.offx * q.sux + s.offy * q.suy) + s.offz * q.suz;
+    s.pv = (s.offx * q.svx + s.offy * q.svy) + s.offz * q.svz;
+    s.u = (s.pu * q.svv - s.pv * q.suv) / q.det_safe;
+    s.v = (s.pv * q.suu - s.pu * q.suv) / q.det_safe;
+    // NaN coordinates (degenerate rectangle) fail the comparisons and are skipped; the reference would carry NaN
+    s.near = in_front && s.u > -kBlockMargin && s.u < 1.0f + kBlockMargin && s.v > -kBlockMargin &&
+             s.v < 1.0f + kBlockMargin;
+}
+
+// sum of sigma over the heliostat's candidate rectangles -> 1 - blocked = exp(-alpha sum)  (:362-365)
+__device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
+                                                    float rx, float ry, float rz);
+
+struct SoftSig { float f, Au, Bu, Av, Bv, sigma_raw; };
+
+__device__ __forceinline__ float soft_sigma(const SoftHit& s, SoftSig& g)     // :325-327, :353-361
+{
+    g.f = sigmoid_fast(kBlockSoftness * (s.d - kBlockOffset));
+    g.Au = sigmoid_fast(kBlockSoftness * s.u); g.Bu = sigmoid_fast(kBlockSoftness * (1.0f - s.u));
+    g.Av = sigmoid_fast(kBlockSoftness * s.v); g.Bv = sigmoid_fast(kBlockSoftness * (1.0f - s.v));
+    g.sigma_raw = ((g.Au * g.Bu) * (g.Av * g.Bv)) * g.f;
+    return __builtin_amdgcn_fmed3f(g.sigma_raw, 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
+                                                    float rx, float ry, float rz)
+{
+    float sum = 0.0f;
+    for (int k = 0; k < n; ++k) {
+        const Prim q = prims[k];                       // wave-uniform LDS address: broadcast reads
+        SoftHit s;
+        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s);
+        if (!wave_any(in_front)) continue;
+        soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, s);
+        if (!wave_any(s.near)) continue;
+        SoftSig g;
+        const float sg = soft_sigma(s, g);
+        sum += s.near ? sg : 0.0f;
+    }
+    return __expf(-(kBlockAlpha * sum));
+}
+
+// Adjoint of sigma w.r.t. the ray (origin, direction) and the rectangle (corner 0, spans, normal).
+struct SoftGrad { float ox, oy, oz, rx, ry, rz, c0[3], su[3], sv[3], n[3]; };
+
+__device__ __forceinline__ void soft_sigma_bwd(const Prim& q, float ox, float oy, float oz, float rx, float ry, float rz,
+                                               const SoftHit& s, const SoftSig& g, float g_sigma, SoftGrad& out)
+{
+#pragma clang fp contract(fast)
+    const float k = kBlockSoftness;
+    const float iu = g.Au * g.Bu, iv = g.Av * g.Bv;
+    const float g_u = g_sigma * iv * g.f * (k * iu * (g.Bu - g.Au));
+    const float g_v = g_sigma * iu * g.f * (k * iv * (g.Bv - g.Av));
+    float g_d = g_sigma * iu * iv * (g.f * (1.0f - g.f) * k);
+    const float idet = 1.0f / q.det_safe;
+    const float g_pu = (g_u * q.svv - g_v * q.suv) * idet;
+    const float g_pv = (g_v * q.suu - g_u * q.suv) * idet;
+    float g_svv = g_u * s.pu * idet, g_suu = g_v * s.pv * idet, g_suv = -(g_u * s.pv + g_v * s.pu) * idet;
+    if (fabsf(q.det_safe) > kBlockEps) {           // det itself was used (:339)
+        const float g_det = -(g_u * s.u + g_v * s.v) * idet;
+        g_suu += g_det * q.svv; g_svv += g_det * q.suu; g_suv -= 2.0f * q.suv * g_det;
+    }
+    const float su[3] = {q.sux, q.suy, q.suz}, sv[3] = {q.svx, q.svy, q.svz}, nn[3] = {q.nx, q.ny, q.nz};
+    const float off[3] = {s.offx, s.offy, s.offz}, dir[3] = {rx, ry, rz};
+    const float rel[3] = {q.c0x - ox, q.c0y - oy, q.c0z - oz};
+    float g_off[3], go[3], gr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        g_off[c] = g_pu * su[c] + g_pv * sv[c];
+        out.su[c] = g_pu * off[c] + 2.0f * g_suu * su[c] + g_suv * sv[c];
+        out.sv[c] = g_pv * off[c] + 2.0f * g_svv * sv[c] + g_suv * su[c];
+        g_d += g_off[c] * dir[c];
+    }
+    const float g_num = g_d / s.den_safe;
+    const float g_den = fabsf(s.den) < kBlockEps ? 0.0f : -g_d * s.d / s.den_safe;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        go[c] = g_off[c] - g_num * nn[c];
+        gr[c] = s.d * g_off[c] + g_den * nn[c];
+        out.c0[c] = g_num * nn[c] - g_off[c];
+        out.n[c] = g_num * rel[c] + g_den * dir[c];
+    }
+    out.ox = go[0]; out.oy = go[1]; out.oz = go[2];
+    out.rx = gr[0]; out.ry = gr[1]; out.rz = gr[2];
+}
+
 }  // namespace art

@@ -1,0 +1,125 @@
+// trace_common.hpp - argument block and distortion fetch shared by the trace and blocking kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "ray_math.hpp"
+#include "launch_common.hpp"
+
+namespace art {
+
+constexpr int kBlock = 256;     // 4 waves; one wave per SIMD, several blocks per CU
+constexpr int kMaxCand = 32;    // upper bound of Cmax: candidate tables live in LDS (116 B per rectangle)
+
+struct TraceArgs {
+    const float4* origins;    // [H,P]
+    const float4* normals;    // [H,P]
+    const float4* incident;   // [H]
+    const float* dist_u;
+    const float* dist_e;
+    int64_t sh, sr, sp;       // element strides of the distortion views
+    const int32_t* target_idx;
+    const float* centers;
+    const float* pnormals;
+    const float* dims;
+    const float* cyl_centers;   // [Tc,4]  TowerTargetAreasCylindrical tensors (NULL when Tc == 0)
+    const float* cyl_normals;   // [Tc,4]
+    const float* cyl_axes;      // [Tc,4]
+    const float* cyl_radii;     // [Tc]
+    const float* cyl_heights;   // [Tc]
+    const float* cyl_opening;   // [Tc]
+    const float* prim_corners;  // [N,4,4] blocking rectangles (NULL: blocking off), artist/raytracing/blocking.py:123-209
+    const float* prim_spans;    // [N,2,4]
+    const float* prim_normals;  // [N,4]
+    const int32_t* cand;        // [H,Cmax] rectangles each heliostat's rays are tested against (art_blocking_filter)
+    const int32_t* cand_count;  // [H]
+    int Cmax;
+    float mag, k_ext, k_refl;
+    int H, R, P, T, Tc, W, Hh;  // target index t < T: planar area t; T <= t < T + Tc: cylinder t - T
+    int mode;                 // 0: bitmap per heliostat, 1: bitmap per target
+    int r_chunk;              // samples per block
+    int n_rchunks;            // ceil(R / r_chunk)
+    int n_ptiles;             // ceil(P / kBlock)
+    int p_block;              // points per workgroup (LDS-window kernel)
+    int n_pblocks;            // ceil(P / p_block)
+    int tile_cap;             // LDS bitmap-window capacity in pixels
+    int multipass_ratio;      // footprints above ratio x capacity are swept in several passes
+};
+
+// Distortion fetch.  INTERLEAVED: (u,e) adjacent floats of one [H,R,P,2] buffer -> one 8-byte load.
+template <bool INTERLEAVED>
+__device__ __forceinline__ void load_dist(const TraceArgs& a, int64_t off, float& u, float& e)
+{
+    if constexpr (INTERLEAVED) {
+        const float2 v = *reinterpret_cast<const float2*>(a.dist_u + off);
+        u = v.x; e = v.y;
+    } else {
+        u = a.dist_u[off]; e = a.dist_e[off];
+    }
+}
+
+// Same fetch with the address split into a wave-uniform row pointer (heliostat, sample -> SGPRs) and a 32-bit
+// per-lane offset (point): compiles to global_load ... v_off, s[base:base+1] with no per-ray VALU address math.
+template <bool INTERLEAVED>
+__device__ __forceinline__ void load_dist_row(const float* __restrict__ row_u, const float* __restrict__ row_e,
+                                              int lane_off, float& u, float& e)
+{
+#ifdef ART_ABLATE_NO_LOADS   // diagnostic build: synthesise angles in registers, no HBM stream
+    u = 1e-6f * (float)(lane_off & 1023); e = -1e-6f * (float)((lane_off >> 3) & 1023);
+    return;
+#endif
+    if constexpr (INTERLEAVED) {
+        const float2 v = *reinterpret_cast<const float2*>(row_u + lane_off);
+        u = v.x; e = v.y;
+    } else {
+        u = row_u[lane_off]; e = row_e[lane_off];
+    }
+}
+
+static inline bool fill_args(TraceArgs& a, const float* origins, const float* normals, const float* incident,
+                      const float* dist_u, const float* dist_e, int64_t sh, int64_t sr, int64_t sp,
+                      const int32_t* target_idx, const float* centers, const float* pnormals, const float* dims,
+                      const float* cyl_centers, const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
+                      const float* cyl_heights, const float* cyl_opening,
+                      double mag, double ext, double refl, int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc,
+                      int64_t W, int64_t Hh, int mode)
+{
+    if (!origins || !normals || !incident || !dist_u || !dist_e || !target_idx) return false;
+    if (T < 0 || Tc < 0 || T + Tc <= 0 || T + Tc > (1 << 24)) return false;
+    if (T > 0 && (!centers || !pnormals || !dims)) return false;
+    if (Tc > 0 && (!cyl_centers || !cyl_normals || !cyl_axes || !cyl_radii || !cyl_heights || !cyl_opening)) return false;
+    if (H < 0 || R <= 0 || P <= 0 || W < 2 || Hh < 2 || (mode != 0 && mode != 1)) return false;
+    if (H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || W > 32768 || Hh > 32768) return false;
+    if ((double)R * (double)P >= 4294967296.0) return false;   // uint32 ray counters
+    if (sp < 0 || (double)P * (double)sp >= 1073741824.0) return false;   // 32-bit per-lane distortion offsets
+    a.origins = reinterpret_cast<const float4*>(origins);
+    a.normals = reinterpret_cast<const float4*>(normals);
+    a.incident = reinterpret_cast<const float4*>(incident);
+    a.dist_u = dist_u; a.dist_e = dist_e; a.sh = sh; a.sr = sr; a.sp = sp;
+    a.target_idx = target_idx; a.centers = centers; a.pnormals = pnormals; a.dims = dims;
+    a.cyl_centers = cyl_centers; a.cyl_normals = cyl_normals; a.cyl_axes = cyl_axes; a.cyl_radii = cyl_radii;
+    a.cyl_heights = cyl_heights; a.cyl_opening = cyl_opening; a.Tc = (int)Tc;
+    a.prim_corners = a.prim_spans = a.prim_normals = nullptr; a.cand = a.cand_count = nullptr; a.Cmax = 0;
+    a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
+    a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;
+    a.n_ptiles = (int)((P + kBlock - 1) / kBlock);
+    return true;
+}
+
+
+static inline bool interleaved_layout(const TraceArgs& a)
+{
+    return a.dist_e == a.dist_u + 1 && a.sp == 2 && (a.sr % 2) == 0 && (a.sh % 2) == 0 &&
+           (reinterpret_cast<uintptr_t>(a.dist_u) % 8) == 0;
+}
+
+
+static inline int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+
+}  // namespace art

@@ -13,71 +13,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "ray_math.hpp"
-#include "launch_common.hpp"
+#include "trace_common.hpp"
 
 namespace art {
-
-constexpr int kBlock = 256;   // 4 waves; one wave per SIMD, several blocks per CU
-
-struct TraceArgs {
-    const float4* origins;    // [H,P]
-    const float4* normals;    // [H,P]
-    const float4* incident;   // [H]
-    const float* dist_u;
-    const float* dist_e;
-    int64_t sh, sr, sp;       // element strides of the distortion views
-    const int32_t* target_idx;
-    const float* centers;
-    const float* pnormals;
-    const float* dims;
-    const float* cyl_centers;   // [Tc,4]  TowerTargetAreasCylindrical tensors (NULL when Tc == 0)
-    const float* cyl_normals;   // [Tc,4]
-    const float* cyl_axes;      // [Tc,4]
-    const float* cyl_radii;     // [Tc]
-    const float* cyl_heights;   // [Tc]
-    const float* cyl_opening;   // [Tc]
-    float mag, k_ext, k_refl;
-    int H, R, P, T, Tc, W, Hh;  // target index t < T: planar area t; T <= t < T + Tc: cylinder t - T
-    int mode;                 // 0: bitmap per heliostat, 1: bitmap per target
-    int r_chunk;              // samples per block
-    int n_rchunks;            // ceil(R / r_chunk)
-    int n_ptiles;             // ceil(P / kBlock)
-    int p_block;              // points per workgroup (LDS-window kernel)
-    int n_pblocks;            // ceil(P / p_block)
-    int tile_cap;             // LDS bitmap-window capacity in pixels
-    int multipass_ratio;      // footprints above ratio x capacity are swept in several passes
-};
-
-// Distortion fetch.  INTERLEAVED: (u,e) adjacent floats of one [H,R,P,2] buffer -> one 8-byte load.
-template <bool INTERLEAVED>
-__device__ __forceinline__ void load_dist(const TraceArgs& a, int64_t off, float& u, float& e)
-{
-    if constexpr (INTERLEAVED) {
-        const float2 v = *reinterpret_cast<const float2*>(a.dist_u + off);
-        u = v.x; e = v.y;
-    } else {
-        u = a.dist_u[off]; e = a.dist_e[off];
-    }
-}
-
-// Same fetch with the address split into a wave-uniform row pointer (heliostat, sample -> SGPRs) and a 32-bit
-// per-lane offset (point): compiles to global_load ... v_off, s[base:base+1] with no per-ray VALU address math.
-template <bool INTERLEAVED>
-__device__ __forceinline__ void load_dist_row(const float* __restrict__ row_u, const float* __restrict__ row_e,
-                                              int lane_off, float& u, float& e)
-{
-#ifdef ART_ABLATE_NO_LOADS   // diagnostic build: synthesise angles in registers, no HBM stream
-    u = 1e-6f * (float)(lane_off & 1023); e = -1e-6f * (float)((lane_off >> 3) & 1023);
-    return;
-#endif
-    if constexpr (INTERLEAVED) {
-        const float2 v = *reinterpret_cast<const float2*>(row_u + lane_off);
-        u = v.x; e = v.y;
-    } else {
-        u = row_u[lane_off]; e = row_e[lane_off];
-    }
-}
 
 // --------------------------------------------------------------------------------------------
 // Forward, global-atomic splat.
@@ -368,14 +306,35 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
     __syncthreads();
 }
 
-template <bool INTERLEAVED, bool CYL>
+// Blocking rectangles of one heliostat in LDS (empty when the kernel is instantiated without blocking).
+template <bool BLOCKING> struct PrimTable { Prim prim[kMaxCand]; int id[kMaxCand]; float grad[kMaxCand * 12]; };
+template <> struct PrimTable<false> { Prim prim[1]; int id[1]; float grad[1]; };
+
+// candidates of heliostat h -> LDS; returns their number (workgroup-uniform).  Ends with a barrier.
+template <bool BLOCKING>
+__device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<BLOCKING>& tab)
+{
+    if constexpr (!BLOCKING) return 0;
+    const int n = min(a.cand_count[h], a.Cmax);
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        const int k = a.cand[(int64_t)h * a.Cmax + c];
+        tab.id[c] = k;
+        tab.prim[c] = make_prim(a.prim_corners, a.prim_spans, a.prim_normals, k);
+    }
+    for (int c = threadIdx.x; c < n * 12; c += blockDim.x) tab.grad[c] = 0.0f;
+    __syncthreads();
+    return n;
+}
+
+template <bool INTERLEAVED, bool CYL, bool BLOCKING>
 __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float* __restrict__ flux,
                                                              unsigned int* __restrict__ counts)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned tile[];
     __shared__ float s_red[13][16];    // per-wave partials: emin, emax, umin, umax, ke, ku, angmax, dmax2, sums
     __shared__ Window s_win;
-    __shared__ unsigned s_cnt[2];
+    __shared__ unsigned s_cnt[3];
+    __shared__ PrimTable<BLOCKING> s_tab;
 
     const int bid = blockIdx.x;
     const int rchunk = bid % a.n_rchunks;
@@ -401,7 +360,8 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
     // ---- phase 1: window ---------------------------------------------------------------------
-    if (tid < 2) s_cnt[tid] = 0;
+    if (tid < 3) s_cnt[tid] = 0;
+    const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
     const unsigned twm1 = (unsigned)(win.tw - 1), uthm1 = (unsigned)(win.th - 1);
@@ -409,7 +369,8 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     // lean mode needs I0 > 0 and I > 0 to be implied by `valid`: positive, sanely scaled intensity factors
     // (a cylinder's Lambert term is clamped at 0, so a valid ray can carry no intensity: never lean)
-    const bool lean = !CYL && a.mag >= 1e-6f && k_ext >= 1e-6f && k_refl >= 1e-6f && a.mag <= 1e6f && k_ext <= 1e6f &&
+    // (blocking: an intensity can be attenuated to 0 as well)
+    const bool lean = !CYL && !BLOCKING && a.mag >= 1e-6f && k_ext >= 1e-6f && k_refl >= 1e-6f && a.mag <= 1e6f && k_ext <= 1e6f &&
                       k_refl <= 1e6f;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
@@ -417,6 +378,7 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     const unsigned thm1 = (unsigned)(pth - 1);
     const bool first = pass == 0;
     unsigned n_valid = 0, n_int = 0;     // rays with I0 > 0 / I > 0 among the valid ones (wave totals)
+    unsigned n_free = 0;                 // rays with blocked < 1e-3 (heliostat_ray_tracer.py:501-503)
     const int npx = win.tw * pth;
     for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
     __syncthreads();
@@ -465,7 +427,18 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             const bool inwin = valid && (unsigned)le < twm1 && (unsigned)lu < thm1;     // implies ie+1 < W, iu+1 < Hh
             const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;        // flat row iu
             const int cell_hi = inwin ? cell_lo + win.tw : dummy;                       // flat row iu + 1
-            const float I = (I0 * k_ext) * k_refl;                                      // heliostat_ray_tracer.py:482-487
+            float keep = 1.0f;                                                          // 1 - blocked
+            if constexpr (BLOCKING) {
+                // soft mask over this heliostat's rectangles, for every ray - also those that miss the target
+                // (blocking.py:212-354; heliostat_ray_tracer.py:462-480)
+                float blocked = 0.0f;
+                if (n_prims > 0) {
+                    blocked = 1.0f - soft_transmittance(s_tab.prim, n_prims, o.x, o.y, o.z, rx, ry, rz);   // :364-365
+                    keep = 1.0f - blocked;       // exactly 0 once the transmittance drops below 2^-25, as in the reference
+                }
+                n_free += __popcll(__builtin_amdgcn_ballot_w64(blocked < 1e-3f));
+            }
+            const float I = ((I0 * keep) * k_ext) * k_refl;                             // heliostat_ray_tracer.py:482-487
             // S is a power of two, so (w I) S == w (I S) bit for bit: scale the intensity once
             const float Is = inwin ? fabsf(I) * win.scale : 0.0f;
             // ray counters live in SGPRs (v_cmp + s_bcnt1).  With positive, sanely scaled intensity factors
@@ -530,7 +503,10 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         }
     }
     resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
-    if (first && lane == 0) { atomicAdd(&s_cnt[0], lean ? n_valid : n_int); atomicAdd(&s_cnt[1], n_valid); }   // wave totals
+    if (first && lane == 0) {                                                           // wave totals
+        atomicAdd(&s_cnt[0], lean ? n_valid : n_int); atomicAdd(&s_cnt[1], n_valid);
+        if constexpr (BLOCKING) atomicAdd(&s_cnt[2], n_free);
+    }
     __syncthreads();
 
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
@@ -544,19 +520,20 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     }
     __syncthreads();   // the band is flushed before the next pass re-zeroes the tile
   }
-    if (tid < 2 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
+    if (tid < 3 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
 // counts (uint32, rows 0,1 of factors) -> fractions (heliostat_ray_tracer.py:498-506).
-__global__ void finalize_factors_kernel(float* factors, int H, float rays_per_heliostat)
+__global__ void finalize_factors_kernel(float* factors, int H, float rays_per_heliostat, int blocking)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
     const unsigned* c = reinterpret_cast<const unsigned*>(factors);
-    const unsigned n_int = c[h], n_on = c[H + h];
+    const unsigned n_int = c[h], n_on = c[H + h], n_free = c[2 * H + h];
     factors[h] = (float)n_int / rays_per_heliostat;
     factors[H + h] = (float)n_on / rays_per_heliostat;
-    factors[2 * H + h] = rays_per_heliostat / rays_per_heliostat;   // blocked == 0 everywhere (blocking off)
+    // blocking off: blocked == 0 everywhere
+    factors[2 * H + h] = (blocking ? (float)n_free : rays_per_heliostat) / rays_per_heliostat;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -651,15 +628,53 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
 // copied once into LDS (row-contiguous loads) and the four per-ray gathers become LDS reads; rays
 // outside the window read global memory.  Gradients are accumulated per point in registers.
 // --------------------------------------------------------------------------------------------
-// (The cylinder instantiation keeps ~60 more live values per ray; it runs 512-thread workgroups = 256 VGPRs.)
-template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL>
-__global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
+// Adjoint of the blocking mask for one ray of every lane: g_sigma = dL/dsigma of the lanes in `adj` (0 elsewhere).
+// Ray-side gradients come back per lane; the rectangles' gradients are accumulated in LDS (12 floats per
+// candidate: corner 0, span u, span v, normal) and flushed once per workgroup - few rays sit in the soft edge of
+// a rectangle, so the LDS float atomics are off the common path.
+__device__ __forceinline__ void block_adjoint(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
+                                              float rx, float ry, float rz, bool adj, float g_sigma, float& g_ox,
+                                              float& g_oy, float& g_oz, float& g_rx, float& g_ry, float& g_rz,
+                                              float* __restrict__ s_gprim)
+{
+    for (int k = 0; k < n; ++k) {
+        const Prim q = prims[k];
+        SoftHit sh;
+        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, sh);
+        if (!wave_any(adj && in_front)) continue;
+        soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, sh);
+        const bool on = adj && sh.near;
+        if (!wave_any(on)) continue;
+        SoftSig sg;
+        (void)soft_sigma(sh, sg);
+        SoftGrad g;
+        soft_sigma_bwd(q, ox, oy, oz, rx, ry, rz, sh, sg, on ? g_sigma : 0.0f, g);
+        if (on) {     // lanes outside the edge band may hold non-finite intermediates: branch, do not multiply
+            g_ox += g.ox; g_oy += g.oy; g_oz += g.oz;
+            g_rx += g.rx; g_ry += g.ry; g_rz += g.rz;
+            float* acc = s_gprim + 12 * k;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                atomicAdd(acc + c, g.c0[c]); atomicAdd(acc + 3 + c, g.su[c]);
+                atomicAdd(acc + 6 + c, g.sv[c]); atomicAdd(acc + 9 + c, g.n[c]);
+            }
+        }
+    }
+}
+
+// (The cylinder and blocking instantiations keep ~60 more live values per ray; they run 512-thread workgroups =
+// 256 VGPRs.)
+template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
+__global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
-                                                             float4* __restrict__ grad_normals)
+                                                             float4* __restrict__ grad_normals,
+                                                             float* __restrict__ g_corners, float* __restrict__ g_spans,
+                                                             float* __restrict__ g_pnormals)
 {
     extern __shared__ __attribute__((aligned(16))) float gtile[];
     __shared__ float s_red[13][16];
     __shared__ Window s_win;
+    __shared__ PrimTable<BLOCKING> s_tab;
 
     const int bid = blockIdx.x;
     const int rchunk = bid % a.n_rchunks;
@@ -683,6 +698,7 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
+    const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
   for (int pass = 0; pass < win.npass; ++pass) {
@@ -712,6 +728,7 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
         float numer = 0.0f; CylPoint cp;
         if constexpr (CYL) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
         float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // (cylinder: go in its local frame)
+        float bgx = 0.f, bgy = 0.f, bgz = 0.f;                                     // dL/do through the blocking mask (world)
         // One ray.  The forward re-computation is the reference's arithmetic (it decides which cells the ray
         // touched); masks are reduced to "inside this pass's window?", strays and other bands' rays are handled by
         // a wave-uniform cold branch, and masked rays get zero gradient weights instead of an early exit.
@@ -719,6 +736,28 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
             const Rot m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
+            float keep = 1.0f, trans = 1.0f, g_keep = 0.0f;        // 1 - blocked, exp(-alpha sum), dL/d(1 - blocked)
+            if constexpr (BLOCKING) {
+                if (n_prims > 0) {
+                    trans = soft_transmittance(s_tab.prim, n_prims, o.x, o.y, o.z, rx, ry, rz);
+                    keep = 1.0f - (1.0f - trans);                  // the reference's rounding (blocked = 1 - trans)
+                }
+            }
+            // the mask's adjoint: ray side into this thread's accumulators, rectangle side into the tables
+            auto mask_adjoint = [&]() {
+                if constexpr (BLOCKING) {
+                    const bool adj = g_keep != 0.0f && trans > 0.0f && n_prims > 0;
+                    if (wave_any(adj)) {
+                        float ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+                        block_adjoint(s_tab.prim, n_prims, o.x, o.y, o.z, rx, ry, rz, adj,
+                                      adj ? -kBlockAlpha * trans * g_keep : 0.0f, ax, ay, az, bx, by, bz, s_tab.grad);
+                        bgx += ax; bgy += ay; bgz += az;
+                        gdx += m.cu * bx + m.m10 * by + m.m20 * bz;
+                        gdy += m.m11 * by + m.m21 * bz - m.su * bx;
+                        gdz += m.ce * bz - m.se * by;
+                    }
+                }
+            };
             float be, bu, ah = 0.0f, tt = 0.0f; bool valid; CylHit ch;
             if constexpr (CYL) {
                 ch = cyl_hit(cy, cp, rx, ry, rz);
@@ -756,8 +795,10 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
             if constexpr (CYL) {
                 if (use) {     // divergent, but a masked ray's intermediates are not finite: no zero-weight trick here
 #pragma clang fp contract(fast)
-                    const float I = (ch.I0 * a.k_ext) * a.k_refl;
-                    const float gI = (cle * (chu * g1 + clu * g4) + che * (chu * g2 + clu * g3)) * (a.k_ext * a.k_refl);
+                    const float I = ((ch.I0 * keep) * a.k_ext) * a.k_refl;
+                    const float g_abs = cle * (chu * g1 + clu * g4) + che * (chu * g2 + clu * g3);     // dL/dI
+                    const float gI = g_abs * (a.k_ext * a.k_refl) * keep;                                // dL/dI0
+                    g_keep = g_abs * (a.k_ext * a.k_refl) * ch.I0;
                     const float g_be = (chu * (g2 - g1) + clu * (g3 - g4)) * I;
                     const float g_bu = (cle * (g1 - g4) + che * (g2 - g3)) * I;
                     float lx, ly, lz, grx, gry, grz;
@@ -767,13 +808,15 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
                     gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
                     gdz += m.ce * grz - m.se * gry;
                 }
+                mask_adjoint();
                 return;
             }
-            const float I = use ? ((pl.mag * (-ah)) * pl.k_ext) * pl.k_refl : 0.0f;
-            const float kIm = use ? kI : 0.0f;
+            const float I = use ? (((pl.mag * (-ah)) * keep) * pl.k_ext) * pl.k_refl : 0.0f;
+            const float kIm = use ? kI * keep : 0.0f;
             {
 #pragma clang fp contract(fast)
                 const float gI = cle * (chu * g1 + clu * g4) + che * (chu * g2 + clu * g3);
+                if constexpr (BLOCKING) g_keep = use ? gI * (kI * (-ah)) : 0.0f;       // I = mag (-a) keep k_ext k_refl
                 const float g_be = (chu * (g2 - g1) + clu * (g3 - g4)) * I;
                 const float g_bu = (cle * (g1 - g4) + che * (g2 - g3)) * I;
                 const float g_hx = -g_be * sx;
@@ -791,6 +834,7 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
                 gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
                 gdz += m.ce * grz - m.se * gry;
             }
+            mask_adjoint();
         };
         // distortion stream prefetched in groups of four samples (see the forward kernel)
         const int lane_off = p * (int)a.sp;
@@ -823,6 +867,7 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
             const float wz = gox * cy.r02 + goy * cy.r12 + goz * cy.r22;
             gox = wx; goy = wy; goz = wz;
         }
+        if constexpr (BLOCKING) { gox += bgx; goy += bgy; goz += bgz; }
         const float4 go = make_float4(gox, goy, goz, 0.0f);
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
@@ -843,6 +888,19 @@ __global__ __launch_bounds__(CYL ? 512 : 1024) void trace_bwd_lds_kernel(TraceAr
     }
     __syncthreads();   // every wave is done with this band before it is overwritten
   }
+    if constexpr (BLOCKING) {      // rectangle gradients of this workgroup -> the primitive tables
+        for (int c = tid; c < n_prims * 12; c += blockDim.x) {
+            const float v = s_tab.grad[c];
+            if (v == 0.0f) continue;
+            const int64_t id = s_tab.id[c / 12];
+            const int part = (c % 12) / 3, comp = c % 3;
+            float* dst = part == 0 ? g_corners + 16 * id + comp                 // corner 0
+                       : part == 1 ? g_spans + 8 * id + comp                    // span u
+                       : part == 2 ? g_spans + 8 * id + 4 + comp                // span v
+                                   : g_pnormals + 4 * id + comp;
+            atomicAdd(dst, v);
+        }
+    }
 }
 
 // out[t] = sum_h [target_idx[h] == t] bitmaps[h]   (heliostat_ray_tracer.py:593-608)
@@ -859,35 +917,6 @@ __global__ void per_target_sum_kernel(const float* __restrict__ bitmaps, const i
     out[(int64_t)t * npix + i] = acc;
 }
 
-static bool fill_args(TraceArgs& a, const float* origins, const float* normals, const float* incident,
-                      const float* dist_u, const float* dist_e, int64_t sh, int64_t sr, int64_t sp,
-                      const int32_t* target_idx, const float* centers, const float* pnormals, const float* dims,
-                      const float* cyl_centers, const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
-                      const float* cyl_heights, const float* cyl_opening,
-                      double mag, double ext, double refl, int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc,
-                      int64_t W, int64_t Hh, int mode)
-{
-    if (!origins || !normals || !incident || !dist_u || !dist_e || !target_idx) return false;
-    if (T < 0 || Tc < 0 || T + Tc <= 0 || T + Tc > (1 << 24)) return false;
-    if (T > 0 && (!centers || !pnormals || !dims)) return false;
-    if (Tc > 0 && (!cyl_centers || !cyl_normals || !cyl_axes || !cyl_radii || !cyl_heights || !cyl_opening)) return false;
-    if (H < 0 || R <= 0 || P <= 0 || W < 2 || Hh < 2 || (mode != 0 && mode != 1)) return false;
-    if (H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || W > 32768 || Hh > 32768) return false;
-    if ((double)R * (double)P >= 4294967296.0) return false;   // uint32 ray counters
-    if (sp < 0 || (double)P * (double)sp >= 1073741824.0) return false;   // 32-bit per-lane distortion offsets
-    a.origins = reinterpret_cast<const float4*>(origins);
-    a.normals = reinterpret_cast<const float4*>(normals);
-    a.incident = reinterpret_cast<const float4*>(incident);
-    a.dist_u = dist_u; a.dist_e = dist_e; a.sh = sh; a.sr = sr; a.sp = sp;
-    a.target_idx = target_idx; a.centers = centers; a.pnormals = pnormals; a.dims = dims;
-    a.cyl_centers = cyl_centers; a.cyl_normals = cyl_normals; a.cyl_axes = cyl_axes; a.cyl_radii = cyl_radii;
-    a.cyl_heights = cyl_heights; a.cyl_opening = cyl_opening; a.Tc = (int)Tc;
-    a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
-    a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;
-    a.n_ptiles = (int)((P + kBlock - 1) / kBlock);
-    return true;
-}
-
 // Pick the sample-chunk so that the grid has a few thousand blocks (>> 256 CUs) without
 // shrinking chunks below what amortises the per-point prologue.
 static void choose_chunks(TraceArgs& a, int target_blocks, int min_chunk)
@@ -900,12 +929,6 @@ static void choose_chunks(TraceArgs& a, int target_blocks, int min_chunk)
     if (chunk > a.R) chunk = a.R;
     a.r_chunk = chunk;
     a.n_rchunks = (a.R + chunk - 1) / chunk;
-}
-
-static bool interleaved_layout(const TraceArgs& a)
-{
-    return a.dist_e == a.dist_u + 1 && a.sp == 2 && (a.sr % 2) == 0 && (a.sh % 2) == 0 &&
-           (reinterpret_cast<uintptr_t>(a.dist_u) % 8) == 0;
 }
 
 // Launch geometry of the forward kernel.  Defaults are the tuned MI355X values; the environment
@@ -922,12 +945,6 @@ struct FwdConfig {
     int multipass_ratio;
     int min_rays;       // rays per workgroup worth a window build + flush
 };
-
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 static FwdConfig fwd_config()
 {
@@ -987,7 +1004,9 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                              int64_t dist_sp, const int32_t* target_idx, const float* plane_centers,
                              const float* plane_normals, const float* plane_dims, const float* cyl_centers,
                              const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
-                             const float* cyl_heights, const float* cyl_opening, double ray_magnitude,
+                             const float* cyl_heights, const float* cyl_opening, const float* prim_corners,
+                             const float* prim_spans, const float* prim_normals, const int32_t* cand,
+                             const int32_t* cand_count, int64_t Cmax, double ray_magnitude,
                              double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
                              int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux, float* factors, void* stream_)
 {
@@ -1003,12 +1022,19 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                    plane_centers, plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights,
                    cyl_opening, ray_magnitude, extinction, reflectivity, H, R, P, T, Tc, W, Hh, mode))
         return ART_EINVAL;
+    const bool blocking = prim_corners != nullptr;
+    if (blocking) {
+        if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > kMaxCand) return ART_EINVAL;
+        a.prim_corners = prim_corners; a.prim_spans = prim_spans; a.prim_normals = prim_normals;
+        a.cand = cand; a.cand_count = cand_count; a.Cmax = (int)Cmax;
+    }
     const int64_t n_maps = mode == 0 ? H : T + Tc;
     ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * n_maps * Hh * W, stream));
     if (H == 0) return ART_OK;
     ART_HIP(hipMemsetAsync(factors, 0, sizeof(float) * 3 * H, stream));
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
-    const FwdConfig cfg = fwd_config();
+    FwdConfig cfg = fwd_config();
+    if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
         window_geometry(a, cfg, cfg.p_block);
         const int64_t base = (int64_t)a.H * a.n_pblocks;
@@ -1017,19 +1043,27 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
         // exits at once (the type is only known on the device)
-#define ART_LAUNCH_FWD(IL, CY)                                                                                   \
+#define ART_LAUNCH_FWD(IL, CY, BL)                                                                               \
         do {                                                                                                     \
-            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY>),            \
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL>),        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY>), dim3((unsigned)blocks), dim3(cfg.block), lds,     \
+            hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL>), dim3((unsigned)blocks), dim3(cfg.block), lds, \
                                stream, a, flux, counts);                                                         \
         } while (0)
+#define ART_LAUNCH_FWD_TYPE(CY)                                                                                  \
+        do {                                                                                                     \
+            if (il && blocking) ART_LAUNCH_FWD(true, CY, true);                                                  \
+            else if (il) ART_LAUNCH_FWD(true, CY, false);                                                        \
+            else if (blocking) ART_LAUNCH_FWD(false, CY, true);                                                  \
+            else ART_LAUNCH_FWD(false, CY, false);                                                               \
+        } while (0)
         const bool il = interleaved_layout(a);
-        if (T > 0) { if (il) ART_LAUNCH_FWD(true, false); else ART_LAUNCH_FWD(false, false); }
-        if (Tc > 0) { if (il) ART_LAUNCH_FWD(true, true); else ART_LAUNCH_FWD(false, true); }
+        if (T > 0) ART_LAUNCH_FWD_TYPE(false);
+        if (Tc > 0) ART_LAUNCH_FWD_TYPE(true);
+#undef ART_LAUNCH_FWD_TYPE
 #undef ART_LAUNCH_FWD
     } else {
-        if (Tc > 0) return ART_EUNSUPPORTED;   // the global-atomic A/B variant knows planar receivers only
+        if (Tc > 0 || blocking) return ART_EUNSUPPORTED;   // the global-atomic A/B variant: planar, no blocking
         choose_chunks(a, 4096, 8);
         const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
         if (blocks > 2147483647LL) return ART_EINVAL;
@@ -1040,7 +1074,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     }
     ART_HIP(hipGetLastError());
     hipLaunchKernelGGL(finalize_factors_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, factors,
-                       (int)H, (float)(R * P));
+                       (int)H, (float)(R * P), blocking ? 1 : 0);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }
@@ -1050,10 +1084,13 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                              int64_t dist_sp, const int32_t* target_idx, const float* plane_centers,
                              const float* plane_normals, const float* plane_dims, const float* cyl_centers,
                              const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
-                             const float* cyl_heights, const float* cyl_opening, double ray_magnitude,
+                             const float* cyl_heights, const float* cyl_opening, const float* prim_corners,
+                             const float* prim_spans, const float* prim_normals, const int32_t* cand,
+                             const int32_t* cand_count, int64_t Cmax, int64_t N, double ray_magnitude,
                              double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
                              int64_t Tc, int64_t W, int64_t Hh, int mode, const float* grad_flux, float* grad_origins,
-                             float* grad_normals, void* stream_)
+                             float* grad_normals, float* grad_prim_corners, float* grad_prim_spans,
+                             float* grad_prim_normals, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
@@ -1063,10 +1100,22 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                    plane_centers, plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights,
                    cyl_opening, ray_magnitude, extinction, reflectivity, H, R, P, T, Tc, W, Hh, mode))
         return ART_EINVAL;
+    const bool blocking = prim_corners != nullptr;
+    if (blocking) {
+        if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > kMaxCand || N <= 0 ||
+            !grad_prim_corners || !grad_prim_spans || !grad_prim_normals)
+            return ART_EINVAL;
+        a.prim_corners = prim_corners; a.prim_spans = prim_spans; a.prim_normals = prim_normals;
+        a.cand = cand; a.cand_count = cand_count; a.Cmax = (int)Cmax;
+        ART_HIP(hipMemsetAsync(grad_prim_corners, 0, sizeof(float) * 16 * N, stream));
+        ART_HIP(hipMemsetAsync(grad_prim_spans, 0, sizeof(float) * 8 * N, stream));
+        ART_HIP(hipMemsetAsync(grad_prim_normals, 0, sizeof(float) * 4 * N, stream));
+    }
     float4* go = reinterpret_cast<float4*>(grad_origins);
     float4* gn = reinterpret_cast<float4*>(grad_normals);
     const bool il = interleaved_layout(a);
-    const FwdConfig cfg = fwd_config();
+    FwdConfig cfg = fwd_config();
+    if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
         window_geometry(a, cfg, cfg.p_block_bwd);
         const int64_t blocks = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
@@ -1077,28 +1126,35 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
             ART_HIP(hipMemsetAsync(grad_normals, 0, sizeof(float) * 4 * H * P, stream));
         }
-#define ART_LAUNCH_BWD(IL, AT, CY)                                                                               \
+#define ART_LAUNCH_BWD(IL, AT, CY, BL)                                                                           \
         do {                                                                                                     \
-            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY>),        \
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY>), dim3((unsigned)blocks),                       \
-                               dim3(CY && cfg.block > 512 ? 512 : cfg.block), lds, stream, a, grad_flux, go, gn);  \
+            hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL>), dim3((unsigned)blocks),                   \
+                               dim3((CY || BL) && cfg.block > 512 ? 512 : cfg.block), lds, stream, a, grad_flux, \
+                               go, gn,                                                                           \
+                               grad_prim_corners, grad_prim_spans, grad_prim_normals);                           \
+        } while (0)
+#define ART_LAUNCH_BWD_BL(CY, BL)                                                                                \
+        do {                                                                                                     \
+            if (il && atomic_out) ART_LAUNCH_BWD(true, true, CY, BL);                                            \
+            else if (il) ART_LAUNCH_BWD(true, false, CY, BL);                                                    \
+            else if (atomic_out) ART_LAUNCH_BWD(false, true, CY, BL);                                            \
+            else ART_LAUNCH_BWD(false, false, CY, BL);                                                           \
         } while (0)
 #define ART_LAUNCH_BWD_TYPE(CY)                                                                                  \
         do {                                                                                                     \
-            if (il && atomic_out) ART_LAUNCH_BWD(true, true, CY);                                                \
-            else if (il) ART_LAUNCH_BWD(true, false, CY);                                                        \
-            else if (atomic_out) ART_LAUNCH_BWD(false, true, CY);                                                \
-            else ART_LAUNCH_BWD(false, false, CY);                                                               \
+            if (blocking) ART_LAUNCH_BWD_BL(CY, true); else ART_LAUNCH_BWD_BL(CY, false);                        \
         } while (0)
         if (T > 0) ART_LAUNCH_BWD_TYPE(false);
         if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
 #undef ART_LAUNCH_BWD_TYPE
+#undef ART_LAUNCH_BWD_BL
 #undef ART_LAUNCH_BWD
         ART_HIP(hipGetLastError());
         return ART_OK;
     }
-    if (Tc > 0) return ART_EUNSUPPORTED;
+    if (Tc > 0 || blocking) return ART_EUNSUPPORTED;
     choose_chunks(a, 2048, 16);
     const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
     if (blocks > 2147483647LL) return ART_EINVAL;

@@ -76,19 +76,27 @@ def _planar_ptrs(centers, plane_normals, dims):
     return (centers.data_ptr(), plane_normals.data_ptr(), dims.data_ptr())
 
 
+#: capacity of a heliostat's list of candidate blocking rectangles (``Cmax`` of art_blocking_filter, <= 32)
+BLOCKING_CANDIDATES = 32
+
+
 class TraceRays(torch.autograd.Function):
-    """reflect -> scatter -> plane / cylinder intersection -> bilinear splat (+ factors), fused.
+    """reflect -> scatter -> plane / cylinder intersection -> (blocking mask) -> bilinear splat (+ factors), fused.
 
     Replaces the body of ``HeliostatRayTracer.trace_rays``
-    (artist/raytracing/heliostat_ray_tracer.py:285-506) for ``blocking_active=False``.  Target index
-    ``t < T`` is planar area ``t``; ``t >= T`` is cylindrical area ``t - T`` of the ``cyl`` tables.
-    Differentiable w.r.t. ``origins`` and ``normals`` exactly like the eager chain (indices and masks
-    are constants).
+    (artist/raytracing/heliostat_ray_tracer.py:285-506).  Target index ``t < T`` is planar area ``t``; ``t >= T``
+    is cylindrical area ``t - T`` of the ``cyl`` tables.  With ``prim_corners/spans/normals`` (the rectangles of
+    ``create_blocking_primitives_rectangles_by_index``) blocking is on: ``art_blocking_filter`` picks the
+    rectangles (``lbvh_filter_blocking_planes``) and the kernels evaluate ``soft_ray_blocking_mask`` per ray.
+    Differentiable w.r.t. ``origins``, ``normals`` and the three rectangle tables exactly like the eager chain
+    (indices, masks and the filter are constants).  Returns ``(flux, factors, filter_flags)``.
     """
 
     @staticmethod
     def forward(ctx, origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-                ray_magnitude, extinction, reflectivity, width, height, per_target, cyl=None):
+                ray_magnitude, extinction, reflectivity, width, height, per_target, cyl=None,
+                prim_corners=None, prim_spans=None, prim_normals=None, owner=None, max_scatter_angle=-1.0,
+                lbvh_compat=True):
         dev = _require_cuda(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims)
         origins, normals, incident = _f32c(origins), _f32c(normals), _f32c(incident)
         H, P = origins.shape[0], origins.shape[1]
@@ -101,29 +109,65 @@ class TraceRays(torch.autograd.Function):
         T = centers.shape[0]
         cyl_tabs, cyl_ptrs, Tc = _cyl_tables(cyl, dev)
         n_maps = T + Tc if per_target else H
+        geometry = (origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
+                    sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs)
+
+        blocking = prim_corners is not None
+        block_tabs, block_ptrs, Cmax, N = (), (None,) * 5, 0, 0
+        flags = torch.empty((0,), dtype=torch.int32, device=dev)
+        if blocking and H > 0:
+            _require_cuda(prim_corners, prim_spans, prim_normals, owner)
+            prim_corners, prim_spans, prim_normals = _f32c(prim_corners), _f32c(prim_spans), _f32c(prim_normals)
+            N = prim_corners.shape[0]
+            if prim_corners.shape != (N, 4, 4) or prim_spans.shape != (N, 2, 4) or prim_normals.shape != (N, 4):
+                raise ValueError("blocking primitives must be corners [N,4,4], spans [N,2,4], normals [N,4]")
+            owner = owner.to(torch.int32).contiguous()
+            if owner.shape != (H,):
+                raise ValueError("owner must hold one primitive index per traced heliostat")
+            Cmax = BLOCKING_CANDIDATES
+            flags = torch.empty((N,), dtype=torch.int32, device=dev)
+            cand = torch.empty((H, Cmax), dtype=torch.int32, device=dev)
+            cand_count = torch.empty((H,), dtype=torch.int32, device=dev)
+            workspace = torch.empty((int(_lib.lib().art_blocking_workspace_bytes(H, N)),), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().art_blocking_filter(
+                    *geometry, float(ray_magnitude), H, R, P, T, Tc, width, height, prim_corners.data_ptr(),
+                    owner.data_ptr(), N, float(max_scatter_angle), 1 if lbvh_compat else 0, Cmax, flags.data_ptr(),
+                    cand.data_ptr(), cand_count.data_ptr(), workspace.data_ptr(), _stream(dev))
+            _lib.check(rc, "art_blocking_filter")
+            most = int(cand_count.max())
+            if most > Cmax:
+                raise _lib.ArtistHipError(
+                    f"a heliostat has {most} blocking rectangles inside its ray cone; the kernels hold {Cmax}")
+            block_tabs = (prim_corners, prim_spans, prim_normals, cand, cand_count)
+            block_ptrs = tuple(t.data_ptr() for t in block_tabs)
+
         flux = torch.empty((n_maps, height, width), dtype=torch.float32, device=dev)
         factors = torch.empty((3, H), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_fwd(
-                origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
-                sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,
-                float(ray_magnitude), float(extinction), float(reflectivity), H, R, P, T, Tc, width, height,
-                1 if per_target else 0, flux.data_ptr(), factors.data_ptr(), _stream(dev))
+                *geometry, *block_ptrs, Cmax, float(ray_magnitude), float(extinction), float(reflectivity),
+                H, R, P, T, Tc, width, height, 1 if per_target else 0, flux.data_ptr(), factors.data_ptr(),
+                _stream(dev))
         _lib.check(rc, "art_trace_fwd")
         ctx.save_for_backward(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
-                              *cyl_tabs)
-        ctx.scalars = (float(ray_magnitude), float(extinction), float(reflectivity), width, height, bool(per_target))
-        ctx.mark_non_differentiable(factors)
-        return flux, factors
+                              *cyl_tabs, *block_tabs)
+        ctx.n_cyl = len(cyl_tabs)
+        ctx.scalars = (float(ray_magnitude), float(extinction), float(reflectivity), width, height, bool(per_target),
+                       Cmax, N)
+        ctx.mark_non_differentiable(factors, flags)
+        return flux, factors, flags
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_flux, _grad_factors):
+    def backward(ctx, grad_flux, _grad_factors, _grad_flags):
         origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims = ctx.saved_tensors[:9]
-        cyl_tabs = ctx.saved_tensors[9:]
+        cyl_tabs = ctx.saved_tensors[9:9 + ctx.n_cyl]
+        block_tabs = ctx.saved_tensors[9 + ctx.n_cyl:]
         cyl_ptrs = tuple(t.data_ptr() for t in cyl_tabs) if cyl_tabs else (None,) * 6
+        block_ptrs = tuple(t.data_ptr() for t in block_tabs) if block_tabs else (None,) * 5
         Tc = cyl_tabs[0].shape[0] if cyl_tabs else 0
-        mag, ext, refl, width, height, per_target = ctx.scalars
+        mag, ext, refl, width, height, per_target, Cmax, N = ctx.scalars
         dev = origins.device
         H, P = origins.shape[0], origins.shape[1]
         R = dist_u.shape[1]
@@ -131,25 +175,38 @@ class TraceRays(torch.autograd.Function):
         grad_flux = _f32c(grad_flux)
         g_o = torch.empty_like(origins)
         g_n = torch.empty_like(normals)
+        g_pc = g_ps = g_pn = None
+        if block_tabs:
+            g_pc, g_ps, g_pn = (torch.empty_like(t) for t in block_tabs[:3])
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_bwd(
                 origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
                 sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,
-                mag, ext, refl, H, R, P, centers.shape[0], Tc, width, height, 1 if per_target else 0,
-                grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(), _stream(dev))
+                *block_ptrs, Cmax, N, mag, ext, refl, H, R, P, centers.shape[0], Tc, width, height,
+                1 if per_target else 0, grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(),
+                *(t.data_ptr() if t is not None else None for t in (g_pc, g_ps, g_pn)), _stream(dev))
         _lib.check(rc, "art_trace_bwd")
-        return (g_o, g_n) + (None,) * 14
+        return (g_o, g_n) + (None,) * 14 + (g_pc, g_ps, g_pn, None, None, None)
 
 
 def trace_rays(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, resolution=(256, 256), per_target=False,
-               cyl=None):
+               cyl=None, blocking=None):
     """Functional form.  Returns ``(flux, factors)`` with ``flux`` ``[H,Hh,W]`` (or ``[T+Tc,Hh,W]`` when
     ``per_target``) and ``factors`` ``[3,H]`` = intercept, on-target, blocking fractions.  ``cyl`` = the six
-    ``TowerTargetAreasCylindrical`` tensors (centers, normals, axes, radii, heights, opening_angles) or None."""
+    ``TowerTargetAreasCylindrical`` tensors (centers, normals, axes, radii, heights, opening_angles) or None.
+    ``blocking`` = None or a dict with ``corners [N,4,4]``, ``spans [N,2,4]``, ``normals [N,4]``, ``owner [H]`` and
+    optionally ``max_scatter_angle`` / ``lbvh_compat``; the filtered set is then returned as a third value."""
+    if blocking is None:
+        flux, factors, _ = TraceRays.apply(origins, normals, incident, dist_u, dist_e, target_idx, centers,
+                                           plane_normals, dims, ray_magnitude, extinction, reflectivity,
+                                           int(resolution[0]), int(resolution[1]), bool(per_target), cyl)
+        return flux, factors
     return TraceRays.apply(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                            ray_magnitude, extinction, reflectivity, int(resolution[0]), int(resolution[1]),
-                           bool(per_target), cyl)
+                           bool(per_target), cyl, blocking["corners"], blocking["spans"], blocking["normals"],
+                           blocking["owner"], float(blocking.get("max_scatter_angle", -1.0)),
+                           bool(blocking.get("lbvh_compat", True)))
 
 
 def per_target_sum(bitmaps: torch.Tensor, target_idx: torch.Tensor, n_targets: int) -> torch.Tensor:

@@ -14,10 +14,15 @@ the sum over ranks equals the single-rank result.
 """
 from __future__ import annotations
 
+import logging
+
 import torch
 
 from . import ops
+from .blocking import create_blocking_primitives_rectangles_by_index
 from .sampling import DistortionsDataset, RestrictedDistributedSampler
+
+log = logging.getLogger(__name__)
 
 _DEFAULT_RESOLUTION = torch.tensor([256, 256])   # artist/util/indices.py:307
 
@@ -61,10 +66,6 @@ class HeliostatRayTracer:
         self.scenario = scenario
         self.heliostat_group = heliostat_group
         self.blocking_active = blocking_active
-        if blocking_active:
-            raise NotImplementedError(
-                "blocking_active=True (artist/raytracing/blocking.py) is not implemented in the MI355X path yet; "
-                "construct the ray tracer with blocking_active=False")
         self.world_size = world_size
         self.rank = rank
         self.batch_size = batch_size   # accepted for API parity; the fused kernel has no per-ray intermediates
@@ -84,6 +85,31 @@ class HeliostatRayTracer:
         )
         self.bitmap_resolution = bitmap_resolution
         self._resolution_host = (int(bitmap_resolution[0]), int(bitmap_resolution[1]))
+
+        if self.blocking_active:
+            # heliostat_ray_tracer.py:159-183: every heliostat of every group can block; aligned surfaces where a
+            # group has been aligned, horizontal ones at their positions otherwise
+            surfaces = []
+            for group in self.scenario.heliostat_field.heliostat_groups:
+                points = group.surface_points + group.positions.unsqueeze(1)
+                mask = group.active_heliostats_mask.bool()
+                if mask.any():
+                    points = points.index_put((torch.nonzero(mask, as_tuple=True)[0],), group.active_surface_points)
+                else:
+                    log.warning("Not all heliostat groups have been aligned yet. "
+                                "Using horizontal heliostats as blocking planes.")
+                surfaces.append(points)
+            self.blocking_heliostat_surfaces = torch.cat(
+                [group.surface_points for group in self.scenario.heliostat_field.heliostat_groups])
+            self.blocking_heliostat_surfaces_active = torch.cat(surfaces)
+            # largest scatter angle of the (fixed) distortion dataset: bounds every heliostat's ray cone
+            ds = self.distortions_dataset
+            self._max_scatter_angle = float(torch.maximum(ds.distortions_u.abs().max(), ds.distortions_e.abs().max()))
+        #: reproduce which rectangles the reference's LBVH can reach (see artist_amd/blocking.py); False = every
+        #: rectangle whose box is hit, as ``lbvh_filter_blocking_planes`` documents
+        self.lbvh_compat = True
+        #: indices of the rectangles the last ``trace_rays`` call filtered (blocking only)
+        self.filtered_blocking_primitive_indices = None
 
         if dni is not None:
             # heliostat_ray_tracer.py:185-201
@@ -151,11 +177,23 @@ class HeliostatRayTracer:
         ray_magnitude = float(self.ray_magnitude)
         width, height = self._resolution_host
         planar = _planar_tables(tower, points.device)
-        flux, factors = ops.TraceRays.apply(
+        flux, factors, flags = ops.TraceRays.apply(
             points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
             ray_magnitude, float(ray_extinction_factor), float(mirror_reflectivity), width, height, False,
-            _cylinder_tables(tower))
+            _cylinder_tables(tower), *self._blocking_arguments(idx, active_heliostats_mask))
+        if self.blocking_active:
+            self.filtered_blocking_primitive_indices = torch.nonzero(flags, as_tuple=True)[0]
         return flux, factors[0], factors[1], factors[2]
+
+    def _blocking_arguments(self, idx, active_heliostats_mask):
+        """Rectangles of all heliostats (:291-301) + the rectangle index of each traced heliostat (:445-448)."""
+        if not self.blocking_active:
+            return ()
+        corners, spans, normals = create_blocking_primitives_rectangles_by_index(self.blocking_heliostat_surfaces_active)
+        owner = torch.nonzero(active_heliostats_mask, as_tuple=True)[0]
+        if idx is not None:
+            owner = owner.index_select(0, idx.to(owner.device))
+        return corners, spans, normals, owner, self._max_scatter_angle, self.lbvh_compat
 
     def trace_rays_per_target(self, incident_ray_directions, active_heliostats_mask, target_area_indices,
                               ray_extinction_factor: float = 0.0, mirror_reflectivity: float = 0.935,
@@ -177,10 +215,12 @@ class HeliostatRayTracer:
             target_area_indices = target_area_indices.index_select(0, idx)
         width, height = self._resolution_host
         planar = _planar_tables(tower, points.device)
-        flux, factors = ops.TraceRays.apply(
+        flux, factors, flags = ops.TraceRays.apply(
             points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
             float(self.ray_magnitude), float(ray_extinction_factor), float(mirror_reflectivity), width, height, True,
-            _cylinder_tables(tower))
+            _cylinder_tables(tower), *self._blocking_arguments(idx, active_heliostats_mask))
+        if self.blocking_active:
+            self.filtered_blocking_primitive_indices = torch.nonzero(flags, as_tuple=True)[0]
         return flux, factors[0], factors[1], factors[2]
 
     def get_bitmaps_per_target(self, bitmaps_per_heliostat: torch.Tensor, target_area_indices: torch.Tensor,

@@ -38,7 +38,7 @@ const char *art_strerror(int code);
 int art_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------
- * art_trace_fwd - HeliostatRayTracer.trace_rays with blocking off, planar and cylindrical targets:
+ * art_trace_fwd - HeliostatRayTracer.trace_rays, planar and cylindrical targets, blocking on or off:
  *   artist/raytracing/heliostat_ray_tracer.py:220-508 =
  *     geometry.reflect                (artist/raytracing/geometry.py:11-41)
  *   + scatter_rays/rotate_distortions (heliostat_ray_tracer.py:510-561, artist/geometry/transforms.py:7-83)
@@ -61,6 +61,12 @@ int art_last_hip_error(void);
  *   plane_centers / plane_normals [T,4], plane_dims [T,2]  TowerTargetAreasPlanar tensors (NULL if T == 0)
  *   cyl_centers / cyl_normals / cyl_axes [Tc,4], cyl_radii / cyl_heights / cyl_opening [Tc]
  *                     TowerTargetAreasCylindrical tensors (NULL if Tc == 0)
+ *   prim_corners [N,4,4], prim_spans [N,2,4], prim_normals [N,4]   blocking rectangles of ALL heliostats
+ *                     (create_blocking_primitives_rectangles_by_index, artist/raytracing/blocking.py:123-209);
+ *                     prim_corners == NULL <=> blocking_active=False
+ *   cand [H,Cmax], cand_count [H]   per heliostat the rectangles its rays are tested against, as written by
+ *                     art_blocking_filter (the filtered set of lbvh_filter_blocking_planes, :832-995); the soft
+ *                     mask (soft_ray_blocking_mask, :212-354) is evaluated in the kernel for every ray
  *   ray_magnitude     Rays.ray_magnitudes fill value (heliostat_ray_tracer.py:185-203)
  *   extinction, reflectivity  trace_rays(ray_extinction_factor, mirror_reflectivity)
  *   W, Hh             bitmap_resolution[0] (east / angle), bitmap_resolution[1] (up)
@@ -74,7 +80,9 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
                   const int32_t *target_idx, const float *plane_centers, const float *plane_normals,
                   const float *plane_dims, const float *cyl_centers, const float *cyl_normals,
                   const float *cyl_axes, const float *cyl_radii, const float *cyl_heights,
-                  const float *cyl_opening, double ray_magnitude, double extinction, double reflectivity,
+                  const float *cyl_opening, const float *prim_corners, const float *prim_spans,
+                  const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax,
+                  double ray_magnitude, double extinction, double reflectivity,
                   int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
                   float *flux, float *factors, void *stream);
 
@@ -85,15 +93,49 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
  * 610-778; geometry.py:287-445 for cylinders).  Same inputs as the forward plus
  *   grad_flux     [H,Hh,W] (mode 0) or [T+Tc,Hh,W] (mode 1)
  *   grad_origins, grad_normals   outputs [H,P,4] (w components 0 / as autograd gives them)
+ *   grad_prim_corners [N,4,4], grad_prim_spans [N,2,4], grad_prim_normals [N,4]   (blocking only; fully
+ *                 written) DIRECT gradients of the soft mask w.r.t. the rectangle tables - corner 0, both spans,
+ *                 the normal; the caller chains them through whatever built the tables (blocking.py:170-207)
  * ------------------------------------------------------------------------------------------- */
 int art_trace_bwd(const float *origins, const float *normals, const float *incident,
                   const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
                   const int32_t *target_idx, const float *plane_centers, const float *plane_normals,
                   const float *plane_dims, const float *cyl_centers, const float *cyl_normals,
                   const float *cyl_axes, const float *cyl_radii, const float *cyl_heights,
-                  const float *cyl_opening, double ray_magnitude, double extinction, double reflectivity,
+                  const float *cyl_opening, const float *prim_corners, const float *prim_spans,
+                  const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax, int64_t N,
+                  double ray_magnitude, double extinction, double reflectivity,
                   int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
-                  const float *grad_flux, float *grad_origins, float *grad_normals, void *stream);
+                  const float *grad_flux, float *grad_origins, float *grad_normals, float *grad_prim_corners,
+                  float *grad_prim_spans, float *grad_prim_normals, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_blocking_filter - lbvh_filter_blocking_planes (artist/raytracing/blocking.py:832-995, with the tree of
+ * :514-749) for ONE batch holding every traced heliostat (heliostat_ray_tracer.py:444-461): which rectangles can
+ * block at all, and which of them each heliostat's rays have to be tested against.
+ *   geometry arguments as art_trace_fwd (the rays and their target distances are recomputed, not stored);
+ *   prim_corners [N,4,4]; owner [H] = index of heliostat h's own rectangle (self hits are ignored, :944-947);
+ *   max_scatter_angle  bound on |distortion angle| of the dataset in radians (< 0: measured here);
+ *   lbvh_compat != 0   reproduce the reference tree's reachability: its split search (:640-650) leaves most
+ *                      leaves of a larger tree unreachable from the root, and an unreachable rectangle is never
+ *                      returned; 0 = every rectangle whose box is hit (what the method documents);
+ *   Cmax <= 32         capacity of a heliostat's candidate list;
+ *   flags [N]          out: 1 = in the filtered set;
+ *   cand [H,Cmax], cand_count [H]   out: filtered rectangles inside heliostat h's ray cone; cand_count[h] > Cmax
+ *                      reports an overflow (the list is then truncated: raise Cmax);
+ *   workspace          art_blocking_workspace_bytes(H, N) bytes of device memory, 256-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int64_t art_blocking_workspace_bytes(int64_t H, int64_t N);
+int art_blocking_filter(const float *origins, const float *normals, const float *incident,
+                        const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
+                        const int32_t *target_idx, const float *plane_centers, const float *plane_normals,
+                        const float *plane_dims, const float *cyl_centers, const float *cyl_normals,
+                        const float *cyl_axes, const float *cyl_radii, const float *cyl_heights,
+                        const float *cyl_opening, double ray_magnitude,
+                        int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh,
+                        const float *prim_corners, const int32_t *owner, int64_t N, double max_scatter_angle,
+                        int lbvh_compat, int64_t Cmax, int32_t *flags, int32_t *cand, int32_t *cand_count,
+                        void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * art_per_target_sum - HeliostatRayTracer.get_bitmaps_per_target

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
+from conftest import BLOCKING_CASES, CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
 
 pytestmark = pytest.mark.gpu
 
@@ -258,8 +258,6 @@ def test_full_size_properties(field):
 def test_error_behaviour(field):
     from artist_amd import ArtistHipError, HeliostatRayTracer, trace_rays
     scenario, group, mask, tix, inc = field
-    with pytest.raises(NotImplementedError):
-        HeliostatRayTracer(scenario, group)                       # blocking_active defaults to True
     rt = HeliostatRayTracer(scenario, group, blocking_active=False)
     with pytest.raises(AssertionError, match="Some heliostats were not aligned and cannot be raytraced."):
         rt.trace_rays(inc, torch.zeros_like(mask), tix)           # tests/raytracing/test_heliostat_ray_tracer.py:44-104
@@ -639,3 +637,159 @@ def test_cylinder_through_ray_tracer_mirror():
     pt, *_ = rt.trace_rays_per_target(inc, mask, tix)
     assert pt.shape[0] == 2
     assert rel_l2(n(pt), n(rt.get_bitmaps_per_target(flux, tix))) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# Blocking (artist/raytracing/blocking.py): filter (art_blocking_filter) + soft mask inside the trace kernels.
+# ---------------------------------------------------------------------------------------------
+def blocking_inputs(d, **extra):
+    H = d["aligned_points"].shape[0]
+    return dict(corners=t(d["prim_corners"]), spans=t(d["prim_spans"]), normals=t(d["prim_normals"]),
+                owner=torch.arange(H, dtype=torch.int32, device=DEV), **extra)
+
+
+@pytest.mark.parametrize("name", BLOCKING_CASES)
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_blocking_forward(golden, name, interleaved):
+    from artist_amd import trace_rays
+    d, d64 = golden(name), golden(name + "_f64")
+    H = d["aligned_points"].shape[0]
+    flux, fac, flags = trace_rays(**trace_inputs(d, interleaved), blocking=blocking_inputs(d))
+    np.testing.assert_array_equal(np.nonzero(n(flags))[0], d["filter_indices"])          # the reference's filtered set
+    o_flux, o_fac = oracle_fwd(d, blocking=oracle.blocking_tables(d, H))
+    yard = rel_l2(d["flux"], d64["flux"])               # sigmoid(1000 x) amplifies fp32 rounding in the edge band
+    assert rel_l2(n(flux), o_flux) < max(yard, 2e-4), (rel_l2(n(flux), o_flux), yard)
+    assert rel_l2(n(flux), d["flux"]) < max(yard, 2e-4), (rel_l2(n(flux), d["flux"]), yard)
+    rays = d["blocked"][0].size
+    np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=1.5 / rays)                    # <= 1 ray per counter
+    for row, key in enumerate(("intercept", "on_target", "blocking")):
+        np.testing.assert_allclose(n(fac[row]), d[key], rtol=0, atol=1.5 / rays)
+    assert float(fac[2].min()) < 0.9                                                       # the case does block
+    # measuring the scatter bound on the device gives the same result as passing it
+    bound = float(max(np.abs(d["distortions_u"]).max(), np.abs(d["distortions_e"]).max()))
+    flux2, fac2, flags2 = trace_rays(**trace_inputs(d, interleaved), blocking=blocking_inputs(d, max_scatter_angle=bound))
+    assert torch.equal(flags, flags2) and torch.equal(fac, fac2)
+    np.testing.assert_allclose(n(flux2), n(flux), rtol=0, atol=1e-5 * float(flux.max()))
+
+
+@pytest.mark.parametrize("name", BLOCKING_CASES)
+def test_blocking_backward(golden, name):
+    """Gradients w.r.t. ray origins / normals AND the rectangles; the aligned points are both ray origins and the
+    source of the rectangle corners, so the reference's gradient of them is the sum of both paths."""
+    from artist_amd import trace_rays
+    from artist_amd.blocking import create_blocking_primitives_rectangles_by_index
+    d, d64 = golden(name), golden(name + "_f64")
+    H = d["aligned_points"].shape[0]
+    inp = trace_inputs(d)
+    points = inp["origins"].requires_grad_(True)
+    inp["normals"].requires_grad_(True)
+    np.testing.assert_array_equal(d["blocking_surfaces"], d["aligned_points"])
+    corners, spans, normals = create_blocking_primitives_rectangles_by_index(points)     # one group, all active
+    for x in (corners, spans, normals):
+        x.retain_grad()
+    torch.testing.assert_close(corners.detach().cpu(), torch.from_numpy(d["prim_corners"]), rtol=0, atol=0)
+    torch.testing.assert_close(normals.detach().cpu(), torch.from_numpy(d["prim_normals"]), rtol=0, atol=3e-7)
+    flux, _, _ = trace_rays(**inp, blocking=dict(corners=corners, spans=spans, normals=normals,
+                                                 owner=torch.arange(H, dtype=torch.int32, device=DEV)))
+    (flux * t(d["loss_weights"])).sum().backward()
+    go, gn, gpc, gps, gpn = oracle.trace_bwd(
+        d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"], d["distortions_e"],
+        d["target_idx"], d["target_centers"], d["target_normals"], d["target_dims"], d["resolution"], d["loss_weights"],
+        float(d["ray_magnitude"]), float(d["extinction"]), float(d["reflectivity"]), blocking=oracle.blocking_tables(d, H))
+    for got, orc, key in ((inp["normals"].grad, gn, "grad_aligned_normals"), (normals.grad, gpn, "grad_prim_normals"),
+                          (points.grad, None, "grad_aligned_points"), (corners.grad, None, "grad_prim_corners"),
+                          (spans.grad, None, "grad_prim_spans")):
+        yard = rel_l2(d[key], d64[key])                 # the reference's own fp32-vs-fp64 distance
+        if orc is not None:
+            assert rel_l2(n(got), orc) < max(yard, 1e-3), (key, rel_l2(n(got), orc), yard)
+        assert rel_l2(n(got), d[key]) < max(2 * yard, 1e-3), (key, rel_l2(n(got), d[key]), yard)
+        assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)
+
+
+def test_blocking_filter_matches_reference_tree(golden):
+    """art_blocking_filter on the field-like layouts of known_answers.npz: with ``lbvh_compat`` only rectangles that
+    the reference's tree can reach are ever flagged (26 of 391, 3 of 2000), without it every hit rectangle is."""
+    from artist_amd import trace_rays
+    ka = golden("known_answers")
+    for i in (1, 2, 3):
+        corners_np = ka[f"tree{i}_corners"]
+        N = corners_np.shape[0]
+        corners = t(corners_np)
+        spans = torch.stack((corners[:, 1] - corners[:, 0], corners[:, 3] - corners[:, 0]), dim=1)
+        nrm = torch.nn.functional.normalize(torch.linalg.cross(spans[:, 0, :3], spans[:, 1, :3]), dim=-1)
+        nrm = torch.cat((nrm, torch.zeros(N, 1, device=DEV)), dim=-1)
+        # one ray bundle per rectangle: mirrors = the rectangles themselves (4 corner points + centre), low sun from
+        # the south, all aimed at a receiver above the origin: rows behind each other block
+        H = N
+        pts = torch.cat((corners, corners.mean(1, keepdim=True)), dim=1)                          # [N,5,4]
+        pts = 0.9 * pts + 0.1 * corners.mean(1, keepdim=True)
+        aim = torch.tensor([0.0, 0.0, 30.0], device=DEV)
+        to_t = torch.nn.functional.normalize(aim - pts[:, 4, :3], dim=-1)
+        sun = torch.tensor([0.0, 1.0, 0.0], device=DEV)
+        mn = torch.nn.functional.normalize(to_t - sun, dim=-1)
+        normals_ = torch.cat((mn, torch.zeros(N, 1, device=DEV)), dim=-1)[:, None].expand(-1, 5, -1).contiguous()
+        inc = torch.tensor([0.0, 1.0, 0.0, 0.0], device=DEV).expand(H, 4).contiguous()
+        both = torch.zeros((H, 2, 5, 2), device=DEV)
+        both[:, 1] = 1e-3
+        args = (pts.contiguous(), normals_, inc, both[..., 0], both[..., 1], torch.zeros(H, dtype=torch.int32, device=DEV),
+                torch.tensor([[0.0, 0.0, 30.0, 1.0]], device=DEV), torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=DEV),
+                torch.tensor([[60.0, 60.0]], device=DEV))
+        blk = dict(corners=corners, spans=spans, normals=nrm, owner=torch.arange(H, dtype=torch.int32, device=DEV))
+        _, _, flags = trace_rays(*args, resolution=(32, 32), blocking=dict(blk, lbvh_compat=True))
+        _, _, flags_all = trace_rays(*args, resolution=(32, 32), blocking=dict(blk, lbvh_compat=False))
+        got, every = set(np.nonzero(n(flags))[0].tolist()), set(np.nonzero(n(flags_all))[0].tolist())
+        reachable = set(ka[f"tree{i}_reachable"].tolist())
+        assert got == every & reachable, (i, len(got), len(every), len(reachable))
+        assert len(every) > N // 4 and len(got) < len(every)
+        # the same rays through the CPU restatement
+        o_np, n_np = n(pts), n(normals_)
+        _, _, dbg = oracle.trace_fwd(o_np, n_np, n(inc), n(both[..., 0]).copy(), n(both[..., 1]).copy(),
+                                     np.zeros(H, np.int32), n(args[6]), n(args[7]), n(args[8]), (32, 32), debug=True,
+                                     blocking=dict(corners=corners_np, spans=n(spans), normals=n(nrm),
+                                                   owner=np.arange(H, dtype=np.int32)))
+        assert got == set(np.nonzero(dbg["filter_flags"])[0].tolist())
+
+
+def test_blocking_through_ray_tracer_mirror():
+    """``HeliostatRayTracer`` with its default ``blocking_active=True`` on a column of heliostats behind each other."""
+    from artist_amd import HeliostatRayTracer
+    from artist_amd.scene import build_synthetic_scenario
+    H = 5
+    scenario, _ = build_synthetic_scenario(H, 12, n_eval=12, device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    group.positions = torch.tensor([[0.0, 150.0, 0.0, 1.0], [0.3, 147.2, 0.0, 1.0], [-0.8, 144.0, 0.0, 1.0],
+                                    [2.0, 141.0, 0.0, 1.0], [-25.0, 100.0, 0.0, 1.0]], device=DEV)
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    tix = torch.zeros(H, dtype=torch.long, device=DEV)
+    inc = torch.nn.functional.normalize(torch.tensor([0.1, 0.95, -0.1, 0.0], device=DEV), dim=0).expand(H, 4).contiguous()
+    group.activate_heliostats(mask, DEV)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask, DEV)
+    points = group.active_surface_points.detach().requires_grad_(True)
+    group.active_surface_points = points
+    rt = HeliostatRayTracer(scenario, group, bitmap_resolution=torch.tensor([64, 64]))           # blocking by default
+    rt.lbvh_compat = False
+    flux, intercept, on_target, blocking = rt.trace_rays(inc, mask, tix)
+    assert float(blocking.min()) < 0.8 and float(blocking[4]) == 1.0
+    filtered = rt.filtered_blocking_primitive_indices.tolist()
+    assert 0 not in filtered and 4 not in filtered and len(filtered) >= 2       # nobody stands behind 0, 4 is alone
+    free = HeliostatRayTracer(scenario, group, blocking_active=False, bitmap_resolution=torch.tensor([64, 64]))
+    flux_free, *_ = free.trace_rays(inc, mask, tix)
+    assert float(flux[0].sum()) < 0.8 * float(flux_free[0].sum())
+    assert rel_l2(n(flux[4]), n(flux_free[4])) < 1e-6
+    # against the CPU restatement, forward and the gradient of the aligned points (origins + corners paths)
+    planar = scenario.solar_tower.target_areas[0]
+    prims = oracle.blocking_primitives(n(points))
+    blk = dict(corners=prims[0], spans=prims[1], normals=prims[2], owner=np.arange(H, dtype=np.int32), lbvh_compat=False)
+    common = (n(points), n(group.active_surface_normals), n(inc), n(rt.distortions_dataset.distortions_u),
+              n(rt.distortions_dataset.distortions_e), n(tix), n(planar.centers), n(planar.normals), n(planar.dimensions),
+              (64, 64))
+    o_flux, o_fac, dbg = oracle.trace_fwd(*common, debug=True, blocking=blk)
+    assert sorted(filtered) == np.nonzero(dbg["filter_flags"])[0].tolist()
+    assert rel_l2(n(flux), o_flux) < 5e-4, rel_l2(n(flux), o_flux)
+    np.testing.assert_allclose(n(blocking), o_fac[2], rtol=0, atol=2.0 / dbg["blocked"][0].size)
+    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    (flux * w).sum().backward()
+    go, gn, gpc, gps, gpn = oracle.trace_bwd(*common, n(w), blocking=blk)
+    import test_oracle_golden as tog
+    _, _, _, g_sfc = tog._chain_primitive_grads(n(points), gpc, gps, gpn)
+    assert rel_l2(n(points.grad), go + g_sfc) < 5e-3, rel_l2(n(points.grad), go + g_sfc)

@@ -111,8 +111,20 @@ def test_tracer_bookkeeping_and_errors():
     sc, g = _tiny_scene()
     g.activate_heliostats(torch.tensor([2, 0, 1, 1], dtype=torch.int32))
     assert g.number_of_active_heliostats == 4 and g.active_surface_points.shape[0] == 4
-    with pytest.raises(NotImplementedError, match="blocking_active"):
-        HeliostatRayTracer(sc, g)                                        # reference default is blocking_active=True
+    with pytest.raises(Exception):                                       # replicas + blocking: the reference's
+        HeliostatRayTracer(sc, g)                                        # surfaces[mask] = active points fails too
+    # reference default is blocking_active=True: heliostat_ray_tracer.py:159-183 (aligned rows where active,
+    # surface + position elsewhere)
+    g.positions = torch.arange(16, dtype=torch.float32).reshape(4, 4)
+    g.activate_heliostats(torch.tensor([1, 0, 1, 1], dtype=torch.int32))
+    g.active_surface_points = g.active_surface_points + 5.0
+    rtb = HeliostatRayTracer(sc, g)
+    assert rtb.blocking_active and rtb.blocking_heliostat_surfaces_active.shape == (4, 8, 4)
+    assert torch.equal(rtb.blocking_heliostat_surfaces_active[1], g.surface_points[1] + g.positions[1])
+    assert torch.equal(rtb.blocking_heliostat_surfaces_active[[0, 2, 3]], g.active_surface_points)
+    assert rtb._max_scatter_angle == float(max(rtb.distortions_dataset.distortions_u.abs().max(),
+                                               rtb.distortions_dataset.distortions_e.abs().max()))
+    g.activate_heliostats(torch.tensor([2, 0, 1, 1], dtype=torch.int32))
     # heliostat_ray_tracer.py:185-203: ray magnitude from dni
     rt = HeliostatRayTracer(sc, g, blocking_active=False, dni=800.0, bitmap_resolution=torch.tensor([32, 16]))
     dims = torch.norm(g.canting[0], dim=1)[0][:2] * 4 + 0.02
