@@ -32,12 +32,12 @@ _ptr = ctypes.c_void_p
 SIGNATURES = {
     "art_trace_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                      _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64,
+                      _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_dbl,
                       _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr],
     "art_trace_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
-                      _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64,
+                      _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_dbl,
                       _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_blocking_workspace_bytes": [_c_i64, _c_i64],

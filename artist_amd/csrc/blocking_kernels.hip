@@ -304,6 +304,7 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
                                                                        int* __restrict__ flags)
 {
     __shared__ float s_box[kMaxCand][6];
+    __shared__ float s_sph[kMaxCand][4];      // centre + half diagonal of the box
     __shared__ int s_id[kMaxCand];
     __shared__ int s_done[kMaxCand];
     __shared__ int s_n, s_left;
@@ -327,7 +328,11 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
                 const float v0 = cr[ax], v1 = cr[4 + ax], v2 = cr[8 + ax], v3 = cr[12 + ax];
                 s_box[slot][ax] = fminf(fminf(v0, v1), fminf(v2, v3));            // :568-569
                 s_box[slot][3 + ax] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                s_sph[slot][ax] = 0.5f * (s_box[slot][ax] + s_box[slot][3 + ax]);
             }
+            const float ex = s_box[slot][3] - s_box[slot][0], ey = s_box[slot][4] - s_box[slot][1],
+                        ez = s_box[slot][5] - s_box[slot][2];
+            s_sph[slot][3] = 0.5f * sqrtf(ex * ex + ey * ey + ez * ez) * 1.001f + 1e-4f;
         }
     }
     __syncthreads();
@@ -352,6 +357,20 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
         reflect(a.incident[h], a.normals[(int64_t)h * a.P + p], d, s);
         if (is_cyl) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
     }
+    // boxes a ray of this point can reach at all: bounding sphere against the cone of the point's scattered rays
+    unsigned pmask = 0u;
+    if (active) {
+        const float il = rsqrtf(fmaxf(d.x * d.x + d.y * d.y + d.z * d.z, 1e-30f));
+        const float dx = d.x * il, dy = d.y * il, dz = d.z * il;
+        for (int c = 0; c < n; ++c) {
+            const float wx = s_sph[c][0] - o.x, wy = s_sph[c][1] - o.y, wz = s_sph[c][2] - o.z;
+            const float l2 = wx * wx + wy * wy + wz * wz, tt = wx * dx + wy * dy + wz * dz;
+            const float perp = sqrtf(fmaxf(l2 - tt * tt, 0.0f)), rho = s_sph[c][3];
+            if (perp * a.cone_cos - tt * a.cone_sin <= rho || l2 <= rho * rho) pmask |= 1u << c;
+        }
+    }
+    const unsigned wmask = wave_or_mask(pmask, n);
+    if (wmask == 0u) return;                                      // (no barrier below this point)
     const int r0 = rchunk * a.r_chunk;
     const int r1 = min(r0 + a.r_chunk, a.R);
     int64_t off = (int64_t)h * a.sh + (int64_t)r0 * a.sr + (int64_t)p * a.sp;
@@ -367,7 +386,8 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
             else { const Hit hit = intersect(pl, o, numer, rx, ry, rz); tt = hit.valid ? hit.t : 0.0f; }  // :186-190
         }
         const float ix = 1.0f / (rx + 1e-12f), iy = 1.0f / (ry + 1e-12f), iz = 1.0f / (rz + 1e-12f);     // blocking.py:912
-        for (int c = 0; c < n; ++c) {
+        for (unsigned mm = wmask; mm != 0u; mm &= mm - 1u) {
+            const int c = __builtin_ctz(mm);
             if (*(volatile int*)&s_done[c]) continue;
             // slab test, :787-791, and the hit condition :928-932
             const float x0 = (s_box[c][0] - o.x) * ix, x1 = (s_box[c][3] - o.x) * ix;
@@ -375,7 +395,7 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
             const float z0 = (s_box[c][2] - o.z) * iz, z1 = (s_box[c][5] - o.z) * iz;
             const float entry = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
             const float exit_ = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-            const bool hit = active && exit_ >= entry && exit_ > 1e-6f && entry <= tt;
+            const bool hit = ((pmask >> c) & 1u) && exit_ >= entry && exit_ > 1e-6f && entry <= tt;
             if (wave_any(hit)) {
                 if ((threadIdx.x & 63) == 0 && atomicExch(&s_done[c], 1) == 0) {
                     flags[s_id[c]] = 1;
@@ -442,6 +462,7 @@ extern "C" int art_blocking_filter(const float* origins, const float* normals, c
                    plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights, cyl_opening,
                    ray_magnitude, 0.0, 1.0, H, R, P, T, Tc, W, Hh, 0))
         return ART_EINVAL;
+    set_cone(a, max_scatter_angle);
     char* ws = static_cast<char*>(workspace);
     Beam* beams = reinterpret_cast<Beam*>(ws); ws += sizeof(Beam) * H;
     unsigned* scatter_bits = reinterpret_cast<unsigned*>(ws); ws += 16;

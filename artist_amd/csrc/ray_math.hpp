@@ -387,13 +387,14 @@ constexpr float kBlockOffset = 0.05f;         // :220
 constexpr float kBlockEps = 1e-12f;           // :217
 constexpr float kBlockMargin = 0.026f;        // sigmoid(-1000 * 0.026) = 5e-12
 
-struct Prim {            // one blocking rectangle, 16 floats in LDS
+struct Prim {            // one blocking rectangle, 20 floats in LDS
     float c0x, c0y, c0z;     // corner 0
     float sux, suy, suz;     // span u = corner 1 - corner 0
     float svx, svy, svz;     // span v = corner 3 - corner 0
     float nx, ny, nz;        // plane normal
     float suu, svv, suv;     // :333-335
     float det_safe;          // :338-339
+    float cx, cy, cz, rho;   // bounding sphere of the rectangle + its soft edge (per-point culling)
 };
 
 __device__ __forceinline__ Prim make_prim(const float* __restrict__ corners, const float* __restrict__ spans,
@@ -410,6 +411,10 @@ __device__ __forceinline__ Prim make_prim(const float* __restrict__ corners, con
     const float det = q.suu * q.svv - q.suv * q.suv;
     const float sgn = det > 0.0f ? 1.0f : (det < 0.0f ? -1.0f : 0.0f);
     q.det_safe = fabsf(det) < kBlockEps ? sgn * kBlockEps : det;
+    q.cx = q.c0x + 0.5f * (q.sux + q.svx); q.cy = q.c0y + 0.5f * (q.suy + q.svy); q.cz = q.c0z + 0.5f * (q.suz + q.svz);
+    // half diagonals |su + sv| / 2 and |su - sv| / 2; the mask reaches 2.6 % of a span beyond the edges
+    const float d1 = q.suu + q.svv + 2.0f * q.suv, d2 = q.suu + q.svv - 2.0f * q.suv;
+    q.rho = 0.5f * sqrtf(fmaxf(fmaxf(d1, d2), 0.0f)) * 1.06f + 2e-3f;
     return q;
 }
 
@@ -446,10 +451,6 @@ __device__ __forceinline__ void soft_uv(const Prim& q, float ox, float oy, float
              s.v < 1.0f + kBlockMargin;
 }
 
-// sum of sigma over the heliostat's candidate rectangles -> 1 - blocked = exp(-alpha sum)  (:362-365)
-__device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
-                                                    float rx, float ry, float rz);
-
 struct SoftSig { float f, Au, Bu, Av, Bv, sigma_raw; };
 
 __device__ __forceinline__ float soft_sigma(const SoftHit& s, SoftSig& g)     // :325-327, :353-361
@@ -461,22 +462,56 @@ __device__ __forceinline__ float soft_sigma(const SoftHit& s, SoftSig& g)     //
     return __builtin_amdgcn_fmed3f(g.sigma_raw, 0.0f, 1.0f);
 }
 
-__device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
-                                                    float rx, float ry, float rz)
+// Which of the n rectangles can a ray leaving o within `theta` of the unit direction (dx,dy,dz) touch at all?
+// Sphere against cone: the centre's distance to the cone surface is perp cos(theta) - t sin(theta).  (cos_t, sin_t) =
+// (0, 0) accepts everything (no bound on the scatter angle known).
+__device__ __forceinline__ unsigned cone_mask(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
+                                              float dx, float dy, float dz, float cos_t, float sin_t)
+{
+#pragma clang fp contract(fast)
+    unsigned mask = 0u;
+    for (int k = 0; k < n; ++k) {
+        const float wx = prims[k].cx - ox, wy = prims[k].cy - oy, wz = prims[k].cz - oz;
+        const float l2 = wx * wx + wy * wy + wz * wz;
+        const float t = wx * dx + wy * dy + wz * dz;
+        const float perp = sqrtf(fmaxf(l2 - t * t, 0.0f));
+        const float rho = prims[k].rho;
+        if (perp * cos_t - t * sin_t <= rho || l2 <= rho * rho) mask |= 1u << k;
+    }
+    return mask;
+}
+
+// exp(-alpha sum sigma) over the rectangles in `wave_mask` (wave-uniform union of the lanes' `mask`); `near` gets
+// the rectangles whose mask this ray actually entered.
+__device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, unsigned wave_mask, unsigned mask,
+                                                    float ox, float oy, float oz, float rx, float ry, float rz,
+                                                    unsigned& near)
 {
     float sum = 0.0f;
-    for (int k = 0; k < n; ++k) {
+    near = 0u;
+    for (unsigned m = wave_mask; m != 0u; m &= m - 1u) {
+        const int k = __builtin_ctz(m);
         const Prim q = prims[k];                       // wave-uniform LDS address: broadcast reads
         SoftHit s;
-        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s);
+        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s) && ((mask >> k) & 1u);
         if (!wave_any(in_front)) continue;
         soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, s);
         if (!wave_any(s.near)) continue;
         SoftSig g;
         const float sg = soft_sigma(s, g);
         sum += s.near ? sg : 0.0f;
+        near |= s.near ? 1u << k : 0u;
     }
     return __expf(-(kBlockAlpha * sum));
+}
+
+// wave-uniform OR of a per-lane mask over the ACTIVE lanes (n <= 32 ballots; once per point, not per ray)
+__device__ __forceinline__ unsigned wave_or_mask(unsigned mask, int n)
+{
+    unsigned out = 0u;
+    for (int k = 0; k < n; ++k)
+        if (__builtin_amdgcn_ballot_w64((mask >> k) & 1u) != 0ull) out |= 1u << k;
+    return out;
 }
 
 // Adjoint of sigma w.r.t. the ray (origin, direction) and the rectangle (corner 0, spans, normal).

@@ -395,6 +395,14 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         reflect(inc, n, d, s);
         float numer = 0.0f; CylPoint cp;
         if constexpr (CYL) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
+        unsigned pmask = 0u, wmask = 0u;       // rectangles this point's / this wave's rays can touch
+        if constexpr (BLOCKING) {
+            if (n_prims > 0) {
+                const float il = rsqrtf(fmaxf(d.x * d.x + d.y * d.y + d.z * d.z, 1e-30f));
+                pmask = cone_mask(s_tab.prim, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin);
+                wmask = wave_or_mask(pmask, n_prims);
+            }
+        }
         // One ray: scatter -> hit -> weights -> 4 pipelined LDS adds.  Ray arithmetic is the reference's
         // (ray_math.hpp); the masks are reduced to the one question the LDS path asks ("does this ray land inside
         // this pass's window?"), and everything rare - a scatter angle beyond the small-angle kernel, a valid ray
@@ -432,8 +440,9 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
                 // soft mask over this heliostat's rectangles, for every ray - also those that miss the target
                 // (blocking.py:212-354; heliostat_ray_tracer.py:462-480)
                 float blocked = 0.0f;
-                if (n_prims > 0) {
-                    blocked = 1.0f - soft_transmittance(s_tab.prim, n_prims, o.x, o.y, o.z, rx, ry, rz);   // :364-365
+                if (wmask != 0u) {
+                    unsigned near;
+                    blocked = 1.0f - soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);   // :364-365
                     keep = 1.0f - blocked;       // exactly 0 once the transmittance drops below 2^-25, as in the reference
                 }
                 n_free += __popcll(__builtin_amdgcn_ballot_w64(blocked < 1e-3f));
@@ -628,28 +637,28 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
 // copied once into LDS (row-contiguous loads) and the four per-ray gathers become LDS reads; rays
 // outside the window read global memory.  Gradients are accumulated per point in registers.
 // --------------------------------------------------------------------------------------------
-// Adjoint of the blocking mask for one ray of every lane: g_sigma = dL/dsigma of the lanes in `adj` (0 elsewhere).
-// Ray-side gradients come back per lane; the rectangles' gradients are accumulated in LDS (12 floats per
-// candidate: corner 0, span u, span v, normal) and flushed once per workgroup - few rays sit in the soft edge of
-// a rectangle, so the LDS float atomics are off the common path.
-__device__ __forceinline__ void block_adjoint(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
-                                              float rx, float ry, float rz, bool adj, float g_sigma, float& g_ox,
-                                              float& g_oy, float& g_oz, float& g_rx, float& g_ry, float& g_rz,
-                                              float* __restrict__ s_gprim)
+// Adjoint of the blocking mask for one ray of every lane: `near` = the rectangles whose mask the lane's ray entered
+// (0 for lanes without a gradient), g_sigma = dL/dsigma.  Ray-side gradients come back per lane; the rectangles'
+// gradients are accumulated in LDS (12 floats per candidate: corner 0, span u, span v, normal) and flushed once
+// per workgroup - few rays sit in the soft edge of a rectangle, so the LDS float atomics are off the common path.
+__device__ __attribute__((noinline)) void block_adjoint(const Prim* __restrict__ prims, unsigned wave_mask, unsigned near,
+                                              float ox, float oy, float oz, float rx, float ry, float rz,
+                                              float g_sigma, float& g_ox, float& g_oy, float& g_oz, float& g_rx,
+                                              float& g_ry, float& g_rz, float* __restrict__ s_gprim)
 {
-    for (int k = 0; k < n; ++k) {
+    for (unsigned m = wave_mask; m != 0u; m &= m - 1u) {
+        const int k = __builtin_ctz(m);
+        const bool on = (near >> k) & 1u;
+        if (!wave_any(on)) continue;
         const Prim q = prims[k];
         SoftHit sh;
         const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, sh);
-        if (!wave_any(adj && in_front)) continue;
         soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, sh);
-        const bool on = adj && sh.near;
-        if (!wave_any(on)) continue;
         SoftSig sg;
         (void)soft_sigma(sh, sg);
         SoftGrad g;
         soft_sigma_bwd(q, ox, oy, oz, rx, ry, rz, sh, sg, on ? g_sigma : 0.0f, g);
-        if (on) {     // lanes outside the edge band may hold non-finite intermediates: branch, do not multiply
+        if (on) {     // other lanes may hold non-finite intermediates: branch, do not multiply
             g_ox += g.ox; g_oy += g.oy; g_oz += g.oz;
             g_rx += g.rx; g_ry += g.ry; g_rz += g.rz;
             float* acc = s_gprim + 12 * k;
@@ -729,6 +738,14 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
         if constexpr (CYL) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
         float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // (cylinder: go in its local frame)
         float bgx = 0.f, bgy = 0.f, bgz = 0.f;                                     // dL/do through the blocking mask (world)
+        unsigned pmask = 0u, wmask = 0u;       // rectangles this point's / this wave's rays can touch
+        if constexpr (BLOCKING) {
+            if (n_prims > 0) {
+                const float il = rsqrtf(fmaxf(d.x * d.x + d.y * d.y + d.z * d.z, 1e-30f));
+                pmask = cone_mask(s_tab.prim, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin);
+                wmask = wave_or_mask(pmask, n_prims);
+            }
+        }
         // One ray.  The forward re-computation is the reference's arithmetic (it decides which cells the ray
         // touched); masks are reduced to "inside this pass's window?", strays and other bands' rays are handled by
         // a wave-uniform cold branch, and masked rays get zero gradient weights instead of an early exit.
@@ -737,19 +754,21 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
             float keep = 1.0f, trans = 1.0f, g_keep = 0.0f;        // 1 - blocked, exp(-alpha sum), dL/d(1 - blocked)
+            unsigned near = 0u;                                    // rectangles whose soft mask this ray entered
             if constexpr (BLOCKING) {
-                if (n_prims > 0) {
-                    trans = soft_transmittance(s_tab.prim, n_prims, o.x, o.y, o.z, rx, ry, rz);
+                if (wmask != 0u) {
+                    trans = soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
                     keep = 1.0f - (1.0f - trans);                  // the reference's rounding (blocked = 1 - trans)
                 }
             }
             // the mask's adjoint: ray side into this thread's accumulators, rectangle side into the tables
             auto mask_adjoint = [&]() {
                 if constexpr (BLOCKING) {
-                    const bool adj = g_keep != 0.0f && trans > 0.0f && n_prims > 0;
+                    // only rays inside some rectangle's mask that still carry light have a gradient through it
+                    const bool adj = near != 0u && g_keep != 0.0f && trans > 0.0f;
                     if (wave_any(adj)) {
                         float ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-                        block_adjoint(s_tab.prim, n_prims, o.x, o.y, o.z, rx, ry, rz, adj,
+                        block_adjoint(s_tab.prim, wmask, adj ? near : 0u, o.x, o.y, o.z, rx, ry, rz,
                                       adj ? -kBlockAlpha * trans * g_keep : 0.0f, ax, ay, az, bx, by, bz, s_tab.grad);
                         bgx += ax; bgy += ay; bgz += az;
                         gdx += m.cu * bx + m.m10 * by + m.m20 * bz;
@@ -1006,9 +1025,10 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                              const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
                              const float* cyl_heights, const float* cyl_opening, const float* prim_corners,
                              const float* prim_spans, const float* prim_normals, const int32_t* cand,
-                             const int32_t* cand_count, int64_t Cmax, double ray_magnitude,
-                             double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
-                             int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux, float* factors, void* stream_)
+                             const int32_t* cand_count, int64_t Cmax, double max_scatter_angle,
+                             double ray_magnitude, double extinction, double reflectivity, int64_t H, int64_t R,
+                             int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux,
+                             float* factors, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
@@ -1027,6 +1047,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > kMaxCand) return ART_EINVAL;
         a.prim_corners = prim_corners; a.prim_spans = prim_spans; a.prim_normals = prim_normals;
         a.cand = cand; a.cand_count = cand_count; a.Cmax = (int)Cmax;
+        set_cone(a, max_scatter_angle);
     }
     const int64_t n_maps = mode == 0 ? H : T + Tc;
     ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * n_maps * Hh * W, stream));
@@ -1086,7 +1107,8 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                              const float* cyl_normals, const float* cyl_axes, const float* cyl_radii,
                              const float* cyl_heights, const float* cyl_opening, const float* prim_corners,
                              const float* prim_spans, const float* prim_normals, const int32_t* cand,
-                             const int32_t* cand_count, int64_t Cmax, int64_t N, double ray_magnitude,
+                             const int32_t* cand_count, int64_t Cmax, int64_t N, double max_scatter_angle,
+                             double ray_magnitude,
                              double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
                              int64_t Tc, int64_t W, int64_t Hh, int mode, const float* grad_flux, float* grad_origins,
                              float* grad_normals, float* grad_prim_corners, float* grad_prim_spans,
@@ -1107,6 +1129,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             return ART_EINVAL;
         a.prim_corners = prim_corners; a.prim_spans = prim_spans; a.prim_normals = prim_normals;
         a.cand = cand; a.cand_count = cand_count; a.Cmax = (int)Cmax;
+        set_cone(a, max_scatter_angle);
         ART_HIP(hipMemsetAsync(grad_prim_corners, 0, sizeof(float) * 16 * N, stream));
         ART_HIP(hipMemsetAsync(grad_prim_spans, 0, sizeof(float) * 8 * N, stream));
         ART_HIP(hipMemsetAsync(grad_prim_normals, 0, sizeof(float) * 4 * N, stream));

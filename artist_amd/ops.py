@@ -117,6 +117,8 @@ class TraceRays(torch.autograd.Function):
         flags = torch.empty((0,), dtype=torch.int32, device=dev)
         if blocking and H > 0:
             _require_cuda(prim_corners, prim_spans, prim_normals, owner)
+            if max_scatter_angle < 0:    # the kernels cull per surface point with this bound: measure it once
+                max_scatter_angle = float(torch.maximum(dist_u.abs().max(), dist_e.abs().max()))
             prim_corners, prim_spans, prim_normals = _f32c(prim_corners), _f32c(prim_spans), _f32c(prim_normals)
             N = prim_corners.shape[0]
             if prim_corners.shape != (N, 4, 4) or prim_spans.shape != (N, 2, 4) or prim_normals.shape != (N, 4):
@@ -146,7 +148,8 @@ class TraceRays(torch.autograd.Function):
         factors = torch.empty((3, H), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_fwd(
-                *geometry, *block_ptrs, Cmax, float(ray_magnitude), float(extinction), float(reflectivity),
+                *geometry, *block_ptrs, Cmax, float(max_scatter_angle), float(ray_magnitude), float(extinction),
+                float(reflectivity),
                 H, R, P, T, Tc, width, height, 1 if per_target else 0, flux.data_ptr(), factors.data_ptr(),
                 _stream(dev))
         _lib.check(rc, "art_trace_fwd")
@@ -154,7 +157,7 @@ class TraceRays(torch.autograd.Function):
                               *cyl_tabs, *block_tabs)
         ctx.n_cyl = len(cyl_tabs)
         ctx.scalars = (float(ray_magnitude), float(extinction), float(reflectivity), width, height, bool(per_target),
-                       Cmax, N)
+                       Cmax, N, float(max_scatter_angle))
         ctx.mark_non_differentiable(factors, flags)
         return flux, factors, flags
 
@@ -167,7 +170,7 @@ class TraceRays(torch.autograd.Function):
         cyl_ptrs = tuple(t.data_ptr() for t in cyl_tabs) if cyl_tabs else (None,) * 6
         block_ptrs = tuple(t.data_ptr() for t in block_tabs) if block_tabs else (None,) * 5
         Tc = cyl_tabs[0].shape[0] if cyl_tabs else 0
-        mag, ext, refl, width, height, per_target, Cmax, N = ctx.scalars
+        mag, ext, refl, width, height, per_target, Cmax, N, max_scatter = ctx.scalars
         dev = origins.device
         H, P = origins.shape[0], origins.shape[1]
         R = dist_u.shape[1]
@@ -182,7 +185,7 @@ class TraceRays(torch.autograd.Function):
             rc = _lib.lib().art_trace_bwd(
                 origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
                 sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,
-                *block_ptrs, Cmax, N, mag, ext, refl, H, R, P, centers.shape[0], Tc, width, height,
+                *block_ptrs, Cmax, N, max_scatter, mag, ext, refl, H, R, P, centers.shape[0], Tc, width, height,
                 1 if per_target else 0, grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(),
                 *(t.data_ptr() if t is not None else None for t in (g_pc, g_ps, g_pn)), _stream(dev))
         _lib.check(rc, "art_trace_bwd")

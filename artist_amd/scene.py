@@ -38,8 +38,17 @@ class Sun:
         torch.manual_seed(random_seed)
         if torch.cuda.is_available():
             torch.cuda.manual_seed(random_seed)
-        distortions_u, distortions_e = self.distribution.sample(
-            (number_of_active_heliostats, self.number_of_rays, number_of_points)).permute(3, 0, 1, 2)
+        shape = (number_of_active_heliostats, self.number_of_rays, number_of_points)
+        loc, tril = self.distribution.loc, self.distribution.scale_tril
+        if loc.device.type == "cpu":
+            sample = self.distribution.sample(shape)
+        else:
+            # same draw as MultivariateNormal.sample (loc + scale_tril @ eps), written element-wise: its batched
+            # 2x2 matrix-vector product faults on ROCm for ~1e7 and more samples
+            eps = torch.randn(shape + (2,), dtype=loc.dtype, device=loc.device)
+            sample = torch.stack((loc[0] + tril[0, 0] * eps[..., 0],
+                                  loc[1] + tril[1, 0] * eps[..., 0] + tril[1, 1] * eps[..., 1]), dim=-1)
+        distortions_u, distortions_e = sample.permute(3, 0, 1, 2)
         return distortions_u, distortions_e
 
 

@@ -67,6 +67,8 @@ int art_last_hip_error(void);
  *   cand [H,Cmax], cand_count [H]   per heliostat the rectangles its rays are tested against, as written by
  *                     art_blocking_filter (the filtered set of lbvh_filter_blocking_planes, :832-995); the soft
  *                     mask (soft_ray_blocking_mask, :212-354) is evaluated in the kernel for every ray
+ *   max_scatter_angle bound on |distortion angle| in radians (blocking only; < 0 = unknown): lets a surface point
+ *                     skip the rectangles that none of its scattered rays can reach - speed only, never results
  *   ray_magnitude     Rays.ray_magnitudes fill value (heliostat_ray_tracer.py:185-203)
  *   extinction, reflectivity  trace_rays(ray_extinction_factor, mirror_reflectivity)
  *   W, Hh             bitmap_resolution[0] (east / angle), bitmap_resolution[1] (up)
@@ -82,7 +84,7 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
                   const float *cyl_axes, const float *cyl_radii, const float *cyl_heights,
                   const float *cyl_opening, const float *prim_corners, const float *prim_spans,
                   const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax,
-                  double ray_magnitude, double extinction, double reflectivity,
+                  double max_scatter_angle, double ray_magnitude, double extinction, double reflectivity,
                   int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
                   float *flux, float *factors, void *stream);
 
@@ -104,7 +106,7 @@ int art_trace_bwd(const float *origins, const float *normals, const float *incid
                   const float *cyl_axes, const float *cyl_radii, const float *cyl_heights,
                   const float *cyl_opening, const float *prim_corners, const float *prim_spans,
                   const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax, int64_t N,
-                  double ray_magnitude, double extinction, double reflectivity,
+                  double max_scatter_angle, double ray_magnitude, double extinction, double reflectivity,
                   int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
                   const float *grad_flux, float *grad_origins, float *grad_normals, float *grad_prim_corners,
                   float *grad_prim_spans, float *grad_prim_normals, void *stream);

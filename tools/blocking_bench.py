@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Cost of blocking at the metric size: 1000 heliostats x 100 rays x 10000 points on a dense grid (40 columns x 25
+rows, 4.2 m x 5 m pitch, sun 20 degrees above the southern horizon) - filter + forward + backward, against the same
+field traced with blocking off."""
+import json, sys, pathlib, time
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+import torch
+from artist_amd import HeliostatRayTracer
+from artist_amd.scene import build_synthetic_scenario
+
+dev = torch.device("cuda:0")
+
+
+def timed(fn, steps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main(H=1000, R=100, steps=5):
+    scenario, _ = build_synthetic_scenario(H, n_rays=R, device=dev)
+    g = scenario.heliostat_field.heliostat_groups[0]
+    i = torch.arange(H, device=dev)
+    g.positions = torch.stack([((i % 40) - 19.5) * 4.2, 60.0 + (i // 40) * 5.0, torch.zeros(H, device=dev),
+                               torch.ones(H, device=dev)], dim=1)
+    mask = torch.ones(H, dtype=torch.int32, device=dev)
+    g.activate_heliostats(mask)
+    tix = torch.zeros(H, dtype=torch.long, device=dev)
+    inc = torch.nn.functional.normalize(torch.tensor([[0.0, 0.94, -0.34, 0.0]], device=dev), dim=1).repeat(H, 1)
+    g.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask)
+    pts = g.active_surface_points.detach().requires_grad_(True)
+    g.active_surface_points = pts
+    out = {"H": H, "R": R, "rays": H * R * pts.shape[1]}
+    for label, kw in (("blocking_off", dict(blocking_active=False)), ("blocking_exact", dict(blocking_active=True)),
+                      ("blocking_reference_tree", dict(blocking_active=True))):
+        rt = HeliostatRayTracer(scenario, g, **kw)
+        rt.lbvh_compat = label == "blocking_reference_tree"
+        flux, intercept, on_target, unblocked = rt.trace_rays(inc, mask, tix)
+        w = torch.rand_like(flux)
+
+        def fwd():
+            return rt.trace_rays(inc, mask, tix)[0]
+
+        def fwd_bwd():
+            pts.grad = None
+            (rt.trace_rays(inc, mask, tix)[0] * w).sum().backward(retain_graph=True)   # the rectangles hang off the constructor's graph
+
+        out[label] = {"fwd_ms": timed(fwd, steps), "fwd_bwd_ms": timed(fwd_bwd, steps),
+                      "mean_unblocked_fraction": float(unblocked.mean()), "flux_sum": float(flux.sum()),
+                      "filtered": 0 if not rt.blocking_active else int(rt.filtered_blocking_primitive_indices.numel())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
