@@ -1,0 +1,342 @@
+// flux_kernels.hip - the flux epilogue that runs on the ray tracer's bitmaps every optimisation epoch (gfx950).
+//
+//   crop   crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246): centre of mass -> affine grid
+//          -> bilinear grid_sample (align_corners=True, zeros padding), forward and backward.  The sampling grid is
+//          an axis-aligned affine map, so the backward w.r.t. the bitmap is written as a GATHER (every input pixel
+//          sums the few output pixels that sampled it): deterministic, no atomics - torch's grid_sample backward
+//          scatters with atomics.
+//   loss   PixelLoss / KLDivergenceLoss (artist/optim/loss.py:251-410) with the reduction over the two bitmap
+//          dimensions, forward and backward, one workgroup per sample.
+//
+// All of it is HBM-bound elementwise / reduction work on [B,Hh,W] fp32: one read and one write of the bitmaps.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "launch_common.hpp"
+
+namespace art {
+
+constexpr int kFluxBlock = 256;
+constexpr int kReduceBlock = 1024;     // per-bitmap reductions: one workgroup per bitmap, 16 waves to hide latency
+
+// torch.linspace(-1, 1, n)[k]: the first half is filled from the start, the second half from the end
+__device__ __forceinline__ float lin11(int k, int n)
+{
+    if (n == 1) return -1.0f;
+    const float step = 2.0f / (float)(n - 1);
+    return k < n / 2 ? -1.0f + step * (float)k : 1.0f - step * (float)(n - 1 - k);
+}
+
+__device__ __forceinline__ double block_sum(double v, double* s_red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int w = 0; w < nw; ++w) r += s_red[w];
+    return r;
+}
+
+struct CropMap {       // pixel j of the output samples input coordinate ix(j); same arithmetic in every kernel
+    float sx, sy, xc, yc;
+    int W, Hh;
+    __device__ __forceinline__ float ix(int j) const { return (((sx * lin11(j, W) + xc) + 1.0f) / 2.0f) * (float)(W - 1); }
+    __device__ __forceinline__ float iy(int i) const { return (((sy * lin11(i, Hh) + yc) + 1.0f) / 2.0f) * (float)(Hh - 1); }
+};
+
+__device__ __forceinline__ CropMap make_map(const float* __restrict__ dims, const float* __restrict__ com, int b, int W,
+                                            int Hh, float crop_w, float crop_h)
+{
+    CropMap m;
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f);           // bitmap.py:218-225
+    m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.xc = com[3 * b]; m.yc = com[3 * b + 1];
+    m.W = W; m.Hh = Hh;
+    return m;
+}
+
+// com[b] = (x centre, y centre, sum + 1e-8) of bitmap b in normalised coordinates (:165-182).  One pass, sums in
+// fp64: sum x (f / S) and (sum x f) / S differ by far less than the fp32 rounding of the reference's own sums.
+__global__ __launch_bounds__(kReduceBlock) void flux_com_kernel(const float* __restrict__ flux, int Hh, int W,
+                                                              float* __restrict__ com)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.x;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    double s = 0.0, xs = 0.0, ys = 0.0;
+    if ((W & 3) == 0) {
+        // four pixels of one row per load; (y, x) advanced without a division
+        const int W4 = W >> 2;
+        int x4 = threadIdx.x % W4, y = threadIdx.x / W4;
+        const int dx = blockDim.x % W4, dy = blockDim.x / W4;
+        const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f);
+        for (int k = threadIdx.x; k < Hh * W4; k += blockDim.x) {
+            const float4 v = f4[k];
+            const int x = 4 * x4;
+            s += (double)((v.x + v.y) + (v.z + v.w));
+            xs += (double)((lin11(x, W) * v.x + lin11(x + 1, W) * v.y) + (lin11(x + 2, W) * v.z + lin11(x + 3, W) * v.w));
+            ys += (double)(lin11(y, Hh) * ((v.x + v.y) + (v.z + v.w)));
+            x4 += dx; y += dy;
+            if (x4 >= W4) { x4 -= W4; ++y; }
+        }
+    } else {
+        int x = threadIdx.x % W, y = threadIdx.x / W;
+        const int dx = blockDim.x % W, dy = blockDim.x / W;
+        for (int k = threadIdx.x; k < Hh * W; k += blockDim.x) {
+            const float v = f[k];
+            s += (double)v;
+            xs += (double)(lin11(x, W) * v);
+            ys += (double)(lin11(y, Hh) * v);
+            x += dx; y += dy;
+            if (x >= W) { x -= W; ++y; }
+        }
+    }
+    s = block_sum(s, s_red);
+    xs = block_sum(xs, s_red);
+    ys = block_sum(ys, s_red);
+    if (threadIdx.x == 0) {
+        const float S = (float)s + 1e-8f;
+        com[3 * b] = (float)(xs / (double)S); com[3 * b + 1] = (float)(ys / (double)S); com[3 * b + 2] = S;
+    }
+}
+
+// grid (ceil(Hh W / 256), B): one thread per output pixel
+__global__ __launch_bounds__(kFluxBlock) void flux_crop_fwd_kernel(const float* __restrict__ flux,
+                                                                   const float* __restrict__ dims,
+                                                                   const float* __restrict__ com, int Hh, int W,
+                                                                   float crop_w, float crop_h, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Hh * W) return;
+    const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const int i = k / W, j = k % W;
+    const float ix = m.ix(j), iy = m.iy(i);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = ix - x0f, ty = iy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool ya = y0 >= 0 && y0 < Hh, yb = y0 + 1 >= 0 && y0 + 1 < Hh;
+    float acc = 0.0f;
+    if (ya && xa) acc += f[y0 * W + x0] * ((1.0f - tx) * (1.0f - ty));
+    if (ya && xb) acc += f[y0 * W + x0 + 1] * (tx * (1.0f - ty));
+    if (yb && xa) acc += f[(y0 + 1) * W + x0] * ((1.0f - tx) * ty);
+    if (yb && xb) acc += f[(y0 + 1) * W + x0 + 1] * (tx * ty);
+    out[(int64_t)b * Hh * W + k] = acc;
+}
+
+// gcom[b] = (dL/dxc, dL/dyc): grid_sample's gradient w.r.t. its grid, summed through affine_grid's translation
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_bwd_com_kernel(const float* __restrict__ flux,
+                                                                       const float* __restrict__ dims,
+                                                                       const float* __restrict__ com,
+                                                                       const float* __restrict__ grad_out, int Hh, int W,
+                                                                       float crop_w, float crop_h,
+                                                                       float* __restrict__ gcom)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.x;
+    const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const float* __restrict__ g = grad_out + (int64_t)b * Hh * W;
+    double gx = 0.0, gy = 0.0;
+    int j = threadIdx.x % W, i = threadIdx.x / W;
+    const int dj = blockDim.x % W, di = blockDim.x / W;
+    for (int k = threadIdx.x; k < Hh * W; k += blockDim.x, j += dj, i += di) {
+        if (j >= W) { j -= W; ++i; }
+        const float ix = m.ix(j), iy = m.iy(i);
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float tx = ix - x0f, ty = iy - y0f;
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool ya = y0 >= 0 && y0 < Hh, yb = y0 + 1 >= 0 && y0 + 1 < Hh;
+        const float v00 = ya && xa ? f[y0 * W + x0] : 0.0f, v01 = ya && xb ? f[y0 * W + x0 + 1] : 0.0f;
+        const float v10 = yb && xa ? f[(y0 + 1) * W + x0] : 0.0f, v11 = yb && xb ? f[(y0 + 1) * W + x0 + 1] : 0.0f;
+        const float go = g[k];
+        gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
+        gy += (double)(go * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
+    }
+    gx = block_sum(gx, s_red);
+    gy = block_sum(gy, s_red);
+    if (threadIdx.x == 0) {
+        gcom[2 * b] = (float)(gx * (double)((float)(W - 1) / 2.0f));
+        gcom[2 * b + 1] = (float)(gy * (double)((float)(Hh - 1) / 2.0f));
+    }
+}
+
+// Weight with which output pixel `o` (sampling coordinate c = map(o)) read input pixel `p`.
+__device__ __forceinline__ float tap(float c, int p)
+{
+    const float c0 = floorf(c);
+    const int p0 = (int)c0;
+    const float t = c - c0;
+    return p == p0 ? 1.0f - t : (p == p0 + 1 ? t : 0.0f);
+}
+
+// One thread per INPUT pixel: direct part = sum over the output pixels that sampled it (the map is separable and
+// monotone, so they form a small index rectangle), plus the part through the centre of mass.
+__global__ __launch_bounds__(kFluxBlock) void flux_crop_bwd_kernel(const float* __restrict__ dims,
+                                                                   const float* __restrict__ com,
+                                                                   const float* __restrict__ gcom,
+                                                                   const float* __restrict__ grad_out, int Hh, int W,
+                                                                   float crop_w, float crop_h,
+                                                                   float* __restrict__ grad_flux)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Hh * W) return;
+    const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
+    const float* __restrict__ g = grad_out + (int64_t)b * Hh * W;
+    const int y = k / W, x = k % W;
+    // ix(j) = sx (j - (W-1)/2) + (xc + 1)(W-1)/2 up to rounding: candidates j with |ix(j) - x| < 1, one pixel of slack
+    int j0 = 0, j1 = W - 1, i0 = 0, i1 = Hh - 1;
+    if (m.sx > 1e-6f && m.sx < 1e6f) {
+        const float bx = (m.xc + 1.0f) * 0.5f * (float)(W - 1) - m.sx * 0.5f * (float)(W - 1);
+        const float lo = ((float)x - 1.0f - bx) / m.sx, hi = ((float)x + 1.0f - bx) / m.sx;
+        if (lo > -2.0e9f && lo < 2.0e9f && hi > -2.0e9f && hi < 2.0e9f) { j0 = max(0, (int)floorf(lo) - 1); j1 = min(W - 1, (int)ceilf(hi) + 1); }
+    }
+    if (m.sy > 1e-6f && m.sy < 1e6f) {
+        const float by = (m.yc + 1.0f) * 0.5f * (float)(Hh - 1) - m.sy * 0.5f * (float)(Hh - 1);
+        const float lo = ((float)y - 1.0f - by) / m.sy, hi = ((float)y + 1.0f - by) / m.sy;
+        if (lo > -2.0e9f && lo < 2.0e9f && hi > -2.0e9f && hi < 2.0e9f) { i0 = max(0, (int)floorf(lo) - 1); i1 = min(Hh - 1, (int)ceilf(hi) + 1); }
+    }
+    float acc = 0.0f;
+    constexpr int kTaps = 8;                 // crop scales >= 1/3 need at most 2/scale + 2 columns
+    if (j1 - j0 < kTaps) {
+        float wx[kTaps];
+#pragma unroll
+        for (int q = 0; q < kTaps; ++q) wx[q] = j0 + q <= j1 ? tap(m.ix(j0 + q), x) : 0.0f;
+        for (int i = i0; i <= i1; ++i) {
+            const float wy = tap(m.iy(i), y);
+            if (wy == 0.0f) continue;
+            const float* __restrict__ grow = g + i * W + j0;
+            float row = 0.0f;
+#pragma unroll
+            for (int q = 0; q < kTaps; ++q)
+                if (wx[q] != 0.0f) row += grow[q] * wx[q];
+            acc += row * wy;
+        }
+    } else {
+        for (int i = i0; i <= i1; ++i) {
+            const float wy = tap(m.iy(i), y);
+            if (wy == 0.0f) continue;
+            float row = 0.0f;
+            for (int j = j0; j <= j1; ++j) {
+                const float wx = tap(m.ix(j), x);
+                if (wx != 0.0f) row += g[i * W + j] * wx;
+            }
+            acc += row * wy;
+        }
+    }
+    const float S = com[3 * b + 2];
+    acc += gcom[2 * b] * (lin11(x, W) - m.xc) / S + gcom[2 * b + 1] * (lin11(y, Hh) - m.yc) / S;
+    grad_flux[(int64_t)b * Hh * W + k] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Losses: one workgroup per sample.  mode 0 = PixelLoss, 1 = KLDivergenceLoss.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kReduceBlock) void flux_loss_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                               int64_t npix, int mode, float* __restrict__ loss,
+                                                               const float* __restrict__ grad_loss,
+                                                               float* __restrict__ grad_pred)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.x;
+    const float* __restrict__ p = pred + (int64_t)b * npix;
+    const float* __restrict__ g = truth + (int64_t)b * npix;
+    float* __restrict__ gp = grad_pred ? grad_pred + (int64_t)b * npix : nullptr;
+    if (mode == 0) {                                           // loss.py:312-318
+        double se = 0.0, sg = 0.0;
+        for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) { const float d = p[k] - g[k]; se += (double)(d * d); sg += (double)g[k]; }
+        se = block_sum(se, s_red);
+        const float sgf = (float)block_sum(sg, s_red);
+        if (threadIdx.x == 0 && loss) loss[b] = (float)se / sgf;
+        if (gp) {
+            const float gl = grad_loss[b];
+            for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) gp[k] = gl * (2.0f * (p[k] - g[k])) / sgf;
+        }
+        return;
+    }
+    const float eps = 1e-12f;                                  // loss.py:385-410
+    double np_ = 0.0, ng = 0.0;
+    for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) { np_ += (double)fabsf(p[k]); ng += (double)fabsf(g[k]); }
+    const float npf = (float)block_sum(np_, s_red), ngf = (float)block_sum(ng, s_red);
+    const float dp = fmaxf(npf, eps), dg = fmaxf(ngf, eps);
+    double acc = 0.0, dot = 0.0;
+    for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) {
+        const float t = logf(g[k] / dg + eps), q = logf(p[k] / dp + eps);
+        const float et = expf(t);
+        acc += (double)(et * (t - q));
+        dot += (double)((-et / (p[k] / dp + eps)) * p[k]);
+    }
+    acc = block_sum(acc, s_red);
+    const float dotf = (float)block_sum(dot, s_red);
+    if (threadIdx.x == 0 && loss) loss[b] = (float)acc;
+    if (gp) {
+        const float gl = grad_loss[b];
+        for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) {
+            const float t = logf(g[k] / dg + eps);
+            const float a = -expf(t) / (p[k] / dp + eps);
+            const float sgn = p[k] > 0.0f ? 1.0f : (p[k] < 0.0f ? -1.0f : 0.0f);
+            const float through_norm = npf > eps ? sgn * dotf / (dp * dp) : 0.0f;
+            gp[k] = gl * (a / dp - through_norm);
+        }
+    }
+}
+
+}  // namespace art
+
+using namespace art;
+
+static bool crop_args_ok(const void* a, const void* b, const void* c, const void* d, int64_t B, int64_t Hh, int64_t W)
+{
+    return a && b && c && d && B >= 0 && Hh >= 1 && W >= 1 && Hh * W <= (int64_t)1 << 30 && B <= 65535;
+}
+
+extern "C" int art_flux_crop_fwd(const float* flux, const float* target_dims, int64_t B, int64_t Hh, int64_t W,
+                                 double crop_width, double crop_height, float* out, float* centers, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(flux, target_dims, out, centers, B, Hh, W)) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    hipLaunchKernelGGL(flux_com_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, (int)Hh, (int)W, centers);
+    hipLaunchKernelGGL(flux_crop_fwd_kernel, dim3((unsigned)((Hh * W + kFluxBlock - 1) / kFluxBlock), (unsigned)B),
+                       dim3(kFluxBlock), 0, stream, flux, target_dims, centers, (int)Hh, (int)W, (float)crop_width,
+                       (float)crop_height, out);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_crop_bwd(const float* flux, const float* target_dims, const float* centers, int64_t B,
+                                 int64_t Hh, int64_t W, double crop_width, double crop_height, const float* grad_out,
+                                 float* grad_flux, float* workspace, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(flux, target_dims, centers, grad_out, B, Hh, W) || !grad_flux || !workspace) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    hipLaunchKernelGGL(flux_crop_bwd_com_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims, centers,
+                       grad_out, (int)Hh, (int)W, (float)crop_width, (float)crop_height, workspace);
+    hipLaunchKernelGGL(flux_crop_bwd_kernel, dim3((unsigned)((Hh * W + kFluxBlock - 1) / kFluxBlock), (unsigned)B),
+                       dim3(kFluxBlock), 0, stream, target_dims, centers, workspace, grad_out, (int)Hh, (int)W,
+                       (float)crop_width, (float)crop_height, grad_flux);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_loss(const float* prediction, const float* ground_truth, int64_t B, int64_t npix, int kind,
+                             float* loss, const float* grad_loss, float* grad_prediction, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!prediction || !ground_truth || B < 0 || npix < 1 || (kind != 0 && kind != 1) || (!loss && !grad_prediction) ||
+        (grad_prediction && !grad_loss))
+        return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    hipLaunchKernelGGL(flux_loss_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, prediction, ground_truth, npix,
+                       kind, loss, grad_loss, grad_prediction);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}

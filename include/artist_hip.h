@@ -188,6 +188,31 @@ int art_align_bwd(const float *points, const float *normals, const float *orient
                   const float *grad_out_points, const float *grad_out_normals, int64_t H, int64_t P,
                   float *grad_points, float *grad_normals, float *grad_orientation, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * art_flux_crop_fwd - crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246): centre of mass of each
+ * bitmap (:165-182) -> affine grid scaled by crop size / target size and centred on it (:218-237) -> bilinear
+ * grid_sample, align_corners=True, zeros padding (:239-246).
+ *   flux [B,Hh,W]; target_dims [B,2] = (width, height) in metres of each bitmap's target area - planar
+ *   dimensions, or radius x opening angle and height for cylinders (the gather of :183-216 is host logic);
+ *   out [B,Hh,W]; centers [B,3] out = (x centre, y centre, sum + 1e-8), needed by the backward.
+ * art_flux_crop_bwd - its autograd w.r.t. flux: the sampled values (as a gather: deterministic) and the path
+ * through the centre of mass (grid_sample's grid gradient).  workspace: 2 B floats.
+ * ------------------------------------------------------------------------------------------- */
+int art_flux_crop_fwd(const float *flux, const float *target_dims, int64_t B, int64_t Hh, int64_t W,
+                      double crop_width, double crop_height, float *out, float *centers, void *stream);
+int art_flux_crop_bwd(const float *flux, const float *target_dims, const float *centers, int64_t B, int64_t Hh,
+                      int64_t W, double crop_width, double crop_height, const float *grad_out, float *grad_flux,
+                      float *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_flux_loss - PixelLoss (kind 0, artist/optim/loss.py:251-318: sum (p-g)^2 / sum g) or KLDivergenceLoss
+ * (kind 1, :321-410: L1-normalise both, KLDivLoss(log_target) on log(. + 1e-12)), reduced over the bitmap.
+ *   prediction, ground_truth [B,npix]; loss [B] out (may be NULL in a backward-only call);
+ *   grad_loss [B] + grad_prediction [B,npix] out: both NULL for forward only.
+ * ------------------------------------------------------------------------------------------- */
+int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B, int64_t npix, int kind,
+                  float *loss, const float *grad_loss, float *grad_prediction, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,6 +213,46 @@ def soft_blocking(origins3, dirs3, corners, spans, normals):
     return out
 
 
+def flux_crop(flux, dims, crop_width=6.0, crop_height=6.0, grad_out=None):
+    """crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246) for bitmaps ``[B,Hh,W]`` whose target
+    areas measure ``dims [B,2]`` metres.  Returns (cropped, centres [B,3]) or, with ``grad_out``, the gradient
+    w.r.t. ``flux``."""
+    dt = flux.dtype
+    f, dd = _c(flux, dt), _c(dims, dt)
+    B, Hh, W = f.shape
+    if grad_out is None:
+        out, com = np.empty_like(f), np.empty((B, 3), dt)
+        _check(getattr(lib(), "orc_flux_crop_fwd" + _sfx(dt))(_p(f), _p(dd), _i64(B), _i64(Hh), _i64(W), _dbl(crop_width),
+                                                              _dbl(crop_height), _p(out), _p(com)), "flux_crop_fwd")
+        return out, com
+    g, gf = _c(grad_out, dt), np.empty_like(f)
+    _check(getattr(lib(), "orc_flux_crop_bwd" + _sfx(dt))(_p(f), _p(dd), _i64(B), _i64(Hh), _i64(W), _dbl(crop_width),
+                                                          _dbl(crop_height), _p(g), _p(gf)), "flux_crop_bwd")
+    return gf
+
+
+def _loss(name, pred, truth, grad_loss):
+    dt = pred.dtype
+    p, g = _c(pred, dt), _c(truth, dt)
+    B, npix = p.shape[0], int(np.prod(p.shape[1:]))
+    loss = np.empty((B,), dt)
+    gl = None if grad_loss is None else _c(grad_loss, dt)
+    gp = None if grad_loss is None else np.empty_like(p)
+    _check(getattr(lib(), name + _sfx(dt))(_p(p), _p(g), _i64(B), _i64(npix), _p(loss), _p(gl), _p(gp)), name)
+    return loss if grad_loss is None else (loss, gp)
+
+
+def pixel_loss(pred, truth, grad_loss=None):
+    """PixelLoss (artist/optim/loss.py:251-318) per sample, reduction over the bitmap; with ``grad_loss`` [B] also
+    the gradient w.r.t. the prediction."""
+    return _loss("orc_pixel_loss", pred, truth, grad_loss)
+
+
+def kl_loss(pred, truth, grad_loss=None):
+    """KLDivergenceLoss (artist/optim/loss.py:321-410) per sample."""
+    return _loss("orc_kl_loss", pred, truth, grad_loss)
+
+
 def blocking_tables(d, H=None):
     """The blocking tables of a golden fixture as the ``blocking=`` argument (one group, every heliostat active:
     heliostat h owns primitive h)."""

@@ -588,6 +588,68 @@ def known_answers():
             stack += [left[node], right[node]]
         out.update({f"tree{i}_corners": npy(corners), f"tree{i}_reachable": np.asarray(sorted(reachable), np.int64)})
     out["tree_count"] = np.int64(i + 1)
+
+    # tests/flux/test_bitmap.py:66-173 crop_flux_distributions_around_center known answers (planar area 3 m x 3 m at
+    # index 0, cylinder radius 1 m x opening 3 rad, height 3 m at index 1) + the reference's own output, and a random
+    # case with autograd gradients in fp32 and fp64.
+    from artist.flux import bitmap as ref_bitmap
+    from artist.optim.loss import KLDivergenceLoss, PixelLoss
+
+    def crop_tower(dtype):
+        planar = TowerTargetAreasPlanar(names=["multi_focus_tower"], centers=torch.zeros(1, 4, dtype=dtype),
+                                        normals=torch.zeros(1, 4, dtype=dtype),
+                                        dimensions=torch.tensor([[3.0, 3.0]], dtype=dtype))
+        cyl = TowerTargetAreasCylindrical(names=["receiver"], centers=torch.zeros(1, 4, dtype=dtype),
+                                          normals=torch.zeros(1, 4, dtype=dtype), axes=torch.zeros(1, 4, dtype=dtype),
+                                          radii=torch.tensor([1.0], dtype=dtype), heights=torch.tensor([3.0], dtype=dtype),
+                                          opening_angles=torch.tensor([3.0], dtype=dtype))
+        return SolarTower([planar, cyl], device=CPU)
+
+    crop_cases = [
+        ([[[1.0, 2.0, 1.0], [2.0, 3.0, 2.0], [1.0, 2.0, 1.0]], [[0.5, 0.0, 0.5], [0.5, 1.0, 0.5], [0.5, 0.0, 0.5]]], 3.0, [0, 1],
+         [[[1.0, 2.0, 1.0], [2.0, 3.0, 2.0], [1.0, 2.0, 1.0]], [[0.5, 0.0, 0.5], [0.5, 1.0, 0.5], [0.5, 0.0, 0.5]]]),
+        ([[[1.0, 2.0, 2.0, 1.0], [2.0, 3.0, 3.0, 2.0], [2.0, 3.0, 3.0, 2.0], [1.0, 2.0, 2.0, 1.0]]] * 2, 5.0, [0, 1],
+         [[[0.0, 0.0, 0.0, 0.0], [0.0, 2.3333, 2.3333, 0.0], [0.0, 2.3333, 2.3333, 0.0], [0.0, 0.0, 0.0, 0.0]]] * 2),
+        ([[[1.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 0.0]], [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [1.0, 0.0, 0.0]]], 3.0, [0, 1],
+         [[[0.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 0.0]]] * 2),
+        ([[[1.0, 1.0, 1.0, 0.0, 0.0, 0.0], [1.0, 2.0, 1.0, 0.0, 0.0, 0.0], [1.0, 1.0, 1.0, 0.0, 0.0, 0.0],
+           [0.0] * 6, [0.0] * 6, [0.0] * 6]], 2.0, [0],
+         [[[0.1111, 0.3333, 0.3333, 0.3333, 0.3333, 0.1111], [0.3333, 1.0, 1.0, 1.0, 1.0, 0.3333],
+           [0.3333, 1.0, 1.4444, 1.4444, 1.0, 0.3333], [0.3333, 1.0, 1.4444, 1.4444, 1.0, 0.3333],
+           [0.3333, 1.0, 1.0, 1.0, 1.0, 0.3333], [0.1111, 0.3333, 0.3333, 0.3333, 0.3333, 0.1111]]]),
+    ]
+    for i, (image, crop, tix, expected) in enumerate(crop_cases):
+        img = torch.tensor(image)
+        got = ref_bitmap.crop_flux_distributions_around_center(img, crop_tower(torch.float32), torch.tensor(tix), crop, crop, device=CPU)
+        out.update({f"crop{i}_image": npy(img), f"crop{i}_size": np.float64(crop), f"crop{i}_target_idx": np.asarray(tix),
+                    f"crop{i}_dims": np.asarray([[3.0, 3.0] for _ in tix], np.float32),
+                    f"crop{i}_expected": np.asarray(expected, np.float32), f"crop{i}_reference": npy(got)})
+    out["crop_count"] = np.int64(i + 1)
+    g2 = torch.Generator().manual_seed(4242)
+    img32 = torch.rand((4, 48, 64), generator=g2) ** 4
+    img32[1, :, :30] = 0.0
+    img32[2] = 0.0                                       # an empty bitmap: the 1e-8 in the normalisation matters
+    img32[2, 5, 7] = 1e-9
+    ground_truth32 = torch.rand((4, 48, 64), generator=g2) + 0.1
+    weights32 = torch.rand((4, 48, 64), generator=g2)
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        torch.set_default_dtype(dtype)
+        img = img32.to(dtype).clone().requires_grad_(True)
+        tower = crop_tower(dtype)
+        tix = torch.tensor([0, 1, 0, 1])
+        cropped = ref_bitmap.crop_flux_distributions_around_center(img, tower, tix, device=CPU)     # default 6 m x 6 m
+        (cropped * weights32.to(dtype)).sum().backward()
+        out.update({f"cropgrad_{tag}_out": npy(cropped), f"cropgrad_{tag}_grad": npy(img.grad)})
+        # losses on the cropped prediction (artist/optim/loss.py:251-410), gradients w.r.t. the prediction
+        for name, loss_cls in (("pixel", PixelLoss), ("kl", KLDivergenceLoss)):
+            pred = (img32.to(dtype) + 0.05).clone().requires_grad_(True)
+            per_sample = loss_cls()(pred, ground_truth32.to(dtype), reduction_dimensions=(1, 2))
+            (per_sample * torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=dtype)).sum().backward()
+            out.update({f"loss_{name}_{tag}": npy(per_sample), f"loss_{name}_{tag}_grad": npy(pred.grad)})
+        torch.set_default_dtype(torch.float32)
+    out.update(cropgrad_image=npy(img32), cropgrad_weights=npy(weights32), cropgrad_target_idx=np.asarray([0, 1, 0, 1]),
+               cropgrad_dims=np.asarray([[3.0, 3.0]] * 4, np.float32), loss_ground_truth=npy(ground_truth32),
+               loss_sample_weights=np.asarray([1.0, 2.0, 3.0, 4.0], np.float32))
     # rotate_distortions: tests/geometry/test_transforms.py (test_distortion_rotations)
     tt = importlib.import_module("tests.geometry.test_transforms")
     k = 0

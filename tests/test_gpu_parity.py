@@ -793,3 +793,92 @@ def test_blocking_through_ray_tracer_mirror():
     import test_oracle_golden as tog
     _, _, _, g_sfc = tog._chain_primitive_grads(n(points), gpc, gps, gpn)
     assert rel_l2(n(points.grad), go + g_sfc) < 5e-3, rel_l2(n(points.grad), go + g_sfc)
+
+
+# ---------------------------------------------------------------------------------------------
+# Flux epilogue (artist/flux/bitmap.py:121-246, artist/optim/loss.py:251-410)
+# ---------------------------------------------------------------------------------------------
+def _crop_tower():
+    from artist_amd.scene import SolarTower, TowerTargetAreasCylindrical, TowerTargetAreasPlanar
+    z4 = torch.zeros(1, 4, device=DEV)
+    planar = TowerTargetAreasPlanar(["multi_focus_tower"], z4, z4, torch.tensor([[3.0, 3.0]], device=DEV))
+    cyl = TowerTargetAreasCylindrical(["receiver"], z4, z4, z4, torch.tensor([1.0], device=DEV),
+                                      torch.tensor([3.0], device=DEV), torch.tensor([3.0], device=DEV))
+    return SolarTower([planar, cyl], device=DEV)
+
+
+def test_flux_crop_known_answers_and_autograd(golden):
+    from artist_amd.flux import crop_flux_distributions_around_center
+    ka = golden("known_answers")
+    tower = _crop_tower()
+    for i in range(int(ka["crop_count"])):          # tests/flux/test_bitmap.py:66-173, through the drop-in function
+        size = float(ka[f"crop{i}_size"])
+        got = crop_flux_distributions_around_center(t(ka[f"crop{i}_image"]), tower, t(ka[f"crop{i}_target_idx"]), size, size)
+        torch.testing.assert_close(got.cpu(), torch.from_numpy(ka[f"crop{i}_expected"]), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(n(got), ka[f"crop{i}_reference"], rtol=0, atol=2e-6)
+        assert not torch.isnan(got).any()
+    img = t(ka["cropgrad_image"]).requires_grad_(True)
+    out = crop_flux_distributions_around_center(img, tower, t(ka["cropgrad_target_idx"]))          # default 6 m x 6 m
+    (out * t(ka["cropgrad_weights"])).sum().backward()
+    # fp32: the reference's own result is 7e-6 / 4e-6 (forward / gradient) from its fp64 run
+    assert rel_l2(n(out), ka["cropgrad_f32_out"]) < 2e-5 and rel_l2(n(out), ka["cropgrad_f64_out"]) < 2e-5
+    assert rel_l2(n(img.grad), ka["cropgrad_f32_grad"]) < 2e-5 and rel_l2(n(img.grad), ka["cropgrad_f64_grad"]) < 2e-5
+    o_out, _ = oracle.flux_crop(ka["cropgrad_image"], ka["cropgrad_dims"])
+    assert rel_l2(n(out), o_out) < 2e-5
+    # deterministic backward: bit-identical on a second run
+    img2 = t(ka["cropgrad_image"]).requires_grad_(True)
+    (crop_flux_distributions_around_center(img2, tower, t(ka["cropgrad_target_idx"])) * t(ka["cropgrad_weights"])).sum().backward()
+    assert torch.equal(img.grad, img2.grad)
+
+
+def test_flux_losses(golden):
+    from artist_amd.flux import KLDivergenceLoss, PixelLoss
+    ka = golden("known_answers")
+    truth, w = t(ka["loss_ground_truth"]), t(ka["loss_sample_weights"])
+    for name, loss_cls in (("pixel", PixelLoss), ("kl", KLDivergenceLoss)):
+        pred = (t(ka["cropgrad_image"]) + 0.05).requires_grad_(True)
+        per_sample = loss_cls()(pred, truth, reduction_dimensions=(1, 2))
+        (per_sample * w).sum().backward()
+        # sums are accumulated in fp64 here: closer to the reference's fp64 run than its own fp32 run is (KL: 3e-5)
+        yard = rel_l2(ka[f"loss_{name}_f32"], ka[f"loss_{name}_f64"])
+        assert rel_l2(n(per_sample), ka[f"loss_{name}_f64"]) < 1e-5
+        assert rel_l2(n(per_sample), ka[f"loss_{name}_f32"]) < max(2 * yard, 1e-5)
+        yard = rel_l2(ka[f"loss_{name}_f32_grad"], ka[f"loss_{name}_f64_grad"])
+        assert rel_l2(n(pred.grad), ka[f"loss_{name}_f64_grad"]) < 1e-5
+        assert rel_l2(n(pred.grad), ka[f"loss_{name}_f32_grad"]) < max(2 * yard, 1e-5)
+        with pytest.raises(ValueError, match="reduction_dimensions"):       # artist/optim/loss.py:300-311, 376-383
+            loss_cls()(pred, truth)
+
+
+def test_flux_epilogue_full_size_properties():
+    """256 x 256 bitmaps of a traced field: crop of a centred symmetric spot with crop size = target size is the
+    identity, the crop is translation-equivariant, and the whole epilogue is differentiable back to the mirror."""
+    from artist_amd import HeliostatRayTracer
+    from artist_amd.flux import PixelLoss, crop_flux_distributions_around_center
+    from artist_amd.scene import build_synthetic_scenario
+    H = 8
+    scenario, _ = build_synthetic_scenario(H, 20, n_eval=20, device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    tix = torch.zeros(H, dtype=torch.long, device=DEV)
+    inc = torch.tensor([0.0, 1.0, 0.0, 0.0], device=DEV).expand(H, 4).contiguous()
+    group.activate_heliostats(mask, DEV)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask, DEV)
+    normals = group.active_surface_normals.detach().requires_grad_(True)
+    group.active_surface_normals = normals
+    rt = HeliostatRayTracer(scenario, group, blocking_active=False)
+    flux, *_ = rt.trace_rays(inc, mask, tix)
+    tower = scenario.solar_tower                                              # 8 m x 8 m planar receiver
+    same = crop_flux_distributions_around_center(flux, tower, tix, 8.0, 8.0)  # scale 1: only the recentring acts
+    com = lambda f: ((f * torch.arange(256, device=DEV)).sum((1, 2)) / f.sum((1, 2)),
+                     (f * torch.arange(256, device=DEV)[:, None]).sum((1, 2)) / f.sum((1, 2)))
+    cx, cy = com(same)
+    assert float((cx - 127.5).abs().max()) < 0.6 and float((cy - 127.5).abs().max()) < 0.6       # spot centred
+    # bilinear resampling keeps the integral while nothing leaves the frame (a clipped spot loses its tail)
+    inside = flux.sum((1, 2)) > 0
+    assert float(((same.sum((1, 2)) - flux.sum((1, 2))).abs() / flux.sum((1, 2)).clamp(min=1))[inside].max()) < 0.05
+    zoom = crop_flux_distributions_around_center(flux, tower, tix)            # 6 m of 8 m: magnified 4/3
+    assert float((zoom.sum((1, 2)) / same.sum((1, 2)).clamp(min=1))[inside].mean()) > 1.3
+    loss = PixelLoss()(zoom, same.detach() + 1.0, reduction_dimensions=(1, 2)).sum()
+    loss.backward()
+    assert torch.isfinite(normals.grad).all() and float(normals.grad.abs().max()) > 0

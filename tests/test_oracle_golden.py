@@ -388,3 +388,33 @@ def test_lbvh_reachability_equals_reference_tree(golden):
     full = oracle.blocking_filter(ka[f"lbvh{i}_origins"], ka[f"lbvh{i}_dirs"], ka[f"lbvh{i}_t"], ka[f"lbvh{i}_owner"],
                                   ka[f"lbvh{i}_corners"], lbvh_compat=False)
     assert set(ka[f"lbvh{i}_filtered"].tolist()) < set(full.tolist())
+
+
+# ---------------------------------------------------------------------------------------------
+# Flux epilogue: crop around the centre of mass (artist/flux/bitmap.py:121-246) and the bitmap losses
+# (artist/optim/loss.py:251-410)
+# ---------------------------------------------------------------------------------------------
+def test_flux_crop_known_answers(golden):
+    """tests/flux/test_bitmap.py:66-173 (rtol = atol = 1e-4 there) + the reference's own outputs."""
+    ka = golden("known_answers")
+    for i in range(int(ka["crop_count"])):
+        size = float(ka[f"crop{i}_size"])
+        out, _ = oracle.flux_crop(ka[f"crop{i}_image"], ka[f"crop{i}_dims"], size, size)
+        np.testing.assert_allclose(out, ka[f"crop{i}_expected"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(out, ka[f"crop{i}_reference"], rtol=0, atol=1e-6)
+        assert not np.isnan(out).any()
+
+
+@pytest.mark.parametrize("tag,dt,tol", [("f32", np.float32, 2e-5), ("f64", np.float64, 1e-12)])
+def test_flux_crop_and_losses_vs_reference_autograd(golden, tag, dt, tol):
+    ka = golden("known_answers")
+    img, dims = ka["cropgrad_image"].astype(dt), ka["cropgrad_dims"].astype(dt)
+    out, com = oracle.flux_crop(img, dims)
+    grad = oracle.flux_crop(img, dims, grad_out=ka["cropgrad_weights"].astype(dt))
+    assert rel_l2(out, ka[f"cropgrad_{tag}_out"]) < tol and rel_l2(grad, ka[f"cropgrad_{tag}_grad"]) < tol
+    assert np.abs(out[2]).max() < 1e-6 and np.isfinite(grad).all()      # the (nearly) empty bitmap stays harmless
+    pred, truth, w = img + dt(0.05), ka["loss_ground_truth"].astype(dt), ka["loss_sample_weights"].astype(dt)
+    for name, fn in (("pixel", oracle.pixel_loss), ("kl", oracle.kl_loss)):
+        loss, g = fn(pred, truth, w)
+        assert rel_l2(loss, ka[f"loss_{name}_{tag}"]) < tol, name
+        assert rel_l2(g, ka[f"loss_{name}_{tag}_grad"]) < tol, name
