@@ -176,6 +176,28 @@ __device__ __forceinline__ float tap(float c, int p)
     return p == p0 ? 1.0f - t : (p == p0 + 1 ? t : 0.0f);
 }
 
+// sum_i wy(i) sum_q wx[q] g[i, j0 + q] with the K column weights held in registers
+template <int K>
+__device__ __forceinline__ float gather_rows(const CropMap& m, const float* __restrict__ g, int W, int x, int y, int j0,
+                                             int j1, int i0, int i1)
+{
+    float wx[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) wx[q] = j0 + q <= j1 ? tap(m.ix(j0 + q), x) : 0.0f;
+    float acc = 0.0f;
+    for (int i = i0; i <= i1; ++i) {
+        const float wy = tap(m.iy(i), y);
+        if (wy == 0.0f) continue;
+        const float* __restrict__ grow = g + i * W + j0;
+        float row = 0.0f;
+#pragma unroll
+        for (int q = 0; q < K; ++q)
+            if (wx[q] != 0.0f) row += grow[q] * wx[q];
+        acc += row * wy;
+    }
+    return acc;
+}
+
 // One thread per INPUT pixel: direct part = sum over the output pixels that sampled it (the map is separable and
 // monotone, so they form a small index rectangle), plus the part through the centre of mass.
 __global__ __launch_bounds__(kFluxBlock) void flux_crop_bwd_kernel(const float* __restrict__ dims,
@@ -191,35 +213,23 @@ __global__ __launch_bounds__(kFluxBlock) void flux_crop_bwd_kernel(const float* 
     const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
     const float* __restrict__ g = grad_out + (int64_t)b * Hh * W;
     const int y = k / W, x = k % W;
-    // ix(j) = sx (j - (W-1)/2) + (xc + 1)(W-1)/2 up to rounding: candidates j with |ix(j) - x| < 1, one pixel of slack
+    // ix(j) = sx (j - (W-1)/2) + (xc + 1)(W-1)/2 up to rounding (<< 1e-3 pixel for bitmaps up to 32768 wide):
+    // candidates j with |ix(j) - x| < 1 + 4e-3; tap() decides exactly
     int j0 = 0, j1 = W - 1, i0 = 0, i1 = Hh - 1;
     if (m.sx > 1e-6f && m.sx < 1e6f) {
         const float bx = (m.xc + 1.0f) * 0.5f * (float)(W - 1) - m.sx * 0.5f * (float)(W - 1);
-        const float lo = ((float)x - 1.0f - bx) / m.sx, hi = ((float)x + 1.0f - bx) / m.sx;
-        if (lo > -2.0e9f && lo < 2.0e9f && hi > -2.0e9f && hi < 2.0e9f) { j0 = max(0, (int)floorf(lo) - 1); j1 = min(W - 1, (int)ceilf(hi) + 1); }
+        const float lo = ((float)x - 1.004f - bx) / m.sx, hi = ((float)x + 1.004f - bx) / m.sx;
+        if (lo > -2.0e9f && lo < 2.0e9f && hi > -2.0e9f && hi < 2.0e9f) { j0 = max(0, (int)ceilf(lo)); j1 = min(W - 1, (int)floorf(hi)); }
     }
     if (m.sy > 1e-6f && m.sy < 1e6f) {
         const float by = (m.yc + 1.0f) * 0.5f * (float)(Hh - 1) - m.sy * 0.5f * (float)(Hh - 1);
-        const float lo = ((float)y - 1.0f - by) / m.sy, hi = ((float)y + 1.0f - by) / m.sy;
-        if (lo > -2.0e9f && lo < 2.0e9f && hi > -2.0e9f && hi < 2.0e9f) { i0 = max(0, (int)floorf(lo) - 1); i1 = min(Hh - 1, (int)ceilf(hi) + 1); }
+        const float lo = ((float)y - 1.004f - by) / m.sy, hi = ((float)y + 1.004f - by) / m.sy;
+        if (lo > -2.0e9f && lo < 2.0e9f && hi > -2.0e9f && hi < 2.0e9f) { i0 = max(0, (int)ceilf(lo)); i1 = min(Hh - 1, (int)floorf(hi)); }
     }
     float acc = 0.0f;
-    constexpr int kTaps = 8;                 // crop scales >= 1/3 need at most 2/scale + 2 columns
-    if (j1 - j0 < kTaps) {
-        float wx[kTaps];
-#pragma unroll
-        for (int q = 0; q < kTaps; ++q) wx[q] = j0 + q <= j1 ? tap(m.ix(j0 + q), x) : 0.0f;
-        for (int i = i0; i <= i1; ++i) {
-            const float wy = tap(m.iy(i), y);
-            if (wy == 0.0f) continue;
-            const float* __restrict__ grow = g + i * W + j0;
-            float row = 0.0f;
-#pragma unroll
-            for (int q = 0; q < kTaps; ++q)
-                if (wx[q] != 0.0f) row += grow[q] * wx[q];
-            acc += row * wy;
-        }
-    } else {
+    if (j1 - j0 < 4) acc = gather_rows<4>(m, g, W, x, y, j0, j1, i0, i1);
+    else if (j1 - j0 < 8) acc = gather_rows<8>(m, g, W, x, y, j0, j1, i0, i1);
+    else {
         for (int i = i0; i <= i1; ++i) {
             const float wy = tap(m.iy(i), y);
             if (wy == 0.0f) continue;

@@ -923,17 +923,44 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
 }
 
 // out[t] = sum_h [target_idx[h] == t] bitmaps[h]   (heliostat_ray_tracer.py:593-608)
-// One thread per (t, pixel); heliostats summed in index order (deterministic).
-__global__ void per_target_sum_kernel(const float* __restrict__ bitmaps, const int32_t* __restrict__ target_idx,
-                                      int H, int T, int64_t npix, float* __restrict__ out)
+// One thread per (t, VEC pixels); heliostats are added in index order (deterministic) with 8-16 loads in flight.
+// A 256 x 256 bitmap has too few pixels to fill the chip with 4-pixel threads: VEC = 4 only for large bitmaps.
+template <int VEC>
+__global__ __launch_bounds__(256) void per_target_sum_kernel(const float* __restrict__ bitmaps,
+                                                             const int32_t* __restrict__ target_idx, int H, int T,
+                                                             int64_t npix, float* __restrict__ out)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
     if (i >= npix) return;
     const int t = blockIdx.y;
-    float acc = 0.0f;
-    for (int h = 0; h < H; ++h)
-        if (target_idx[h] == t) acc += bitmaps[(int64_t)h * npix + i];
-    out[(int64_t)t * npix + i] = acc;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+    constexpr int kInFlight = VEC == 1 ? 16 : 8;
+    for (int h0 = 0; h0 < H; h0 += kInFlight) {
+        float val[kInFlight][VEC];
+#pragma unroll
+        for (int q = 0; q < kInFlight; ++q) {
+            const int h = h0 + q;
+            const bool mine = h < H && target_idx[h] == t;          // wave-uniform
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) val[q][v] = 0.0f;
+            if (mine) {
+                if constexpr (VEC == 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(bitmaps + (int64_t)h * npix + i);
+                    val[q][0] = x.x; val[q][1] = x.y; val[q][2] = x.z; val[q][3] = x.w;
+                } else {
+                    val[q][0] = bitmaps[(int64_t)h * npix + i];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kInFlight; ++q)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += val[q][v];       // adding 0 for foreign heliostats changes nothing
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) out[(int64_t)t * npix + i + v] = acc[v];
 }
 
 // Pick the sample-chunk so that the grid has a few thousand blocks (>> 256 CUs) without
@@ -1199,8 +1226,14 @@ extern "C" int art_per_target_sum(const float* bitmaps, const int32_t* target_id
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!out || T <= 0 || npix <= 0 || H < 0 || T > 65535 || (H > 0 && (!bitmaps || !target_idx))) return ART_EINVAL;
-    hipLaunchKernelGGL(per_target_sum_kernel, dim3((unsigned)((npix + 255) / 256), (unsigned)T), dim3(256), 0, stream,
-                       bitmaps, target_idx, (int)H, (int)T, npix, out);
+    const bool vec4 = npix >= (int64_t)1 << 20 && (npix % 4) == 0 && (reinterpret_cast<uintptr_t>(bitmaps) % 16) == 0 &&
+                      (reinterpret_cast<uintptr_t>(out) % 16) == 0;
+    if (vec4)
+        hipLaunchKernelGGL(per_target_sum_kernel<4>, dim3((unsigned)((npix / 4 + 255) / 256), (unsigned)T), dim3(256), 0,
+                           stream, bitmaps, target_idx, (int)H, (int)T, npix, out);
+    else
+        hipLaunchKernelGGL(per_target_sum_kernel<1>, dim3((unsigned)((npix + 255) / 256), (unsigned)T), dim3(256), 0, stream,
+                           bitmaps, target_idx, (int)H, (int)T, npix, out);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

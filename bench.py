@@ -7,8 +7,9 @@ workload : the metric config of BASELINE.md section 4 - H=1000 heliostats x R=10
            receiver, 256x256 bitmap, Gaussian sun; synthetic data, random (seeded) surface noise.
 step     : one surface-reconstruction epoch over the whole field:
            NURBS points+normals (HIP) -> alignment (HIP) -> trace_rays (HIP) -> per-target sum ->
-           [N>1: RCCL all_reduce of the [T,256,256] flux] -> MSE loss vs fixed target bitmaps ->
-           backward (trace_bwd HIP, alignment, nurbs_bwd HIP) -> [N>1: RCCL all_reduce of the
+           [N>1: RCCL all_reduce of the [T,256,256] flux] -> crop around the centre of mass (HIP) -> PixelLoss
+           vs fixed measured bitmaps (HIP) -> backward (loss, crop, trace_bwd, alignment, nurbs_bwd: all HIP)
+           -> [N>1: RCCL all_reduce of the
            control-point gradients, like surface_reconstructor.py:767-777].
            Inputs (control points, orientations, distortions) are resident in HBM before timing.
 N GPUs   : heliostats are sharded over ranks exactly like RestrictedDistributedSampler
@@ -146,6 +147,7 @@ def main():
     dist_u, dist_e = both[..., 0], both[..., 1]
 
     from artist_amd import ops
+    from artist_amd.flux import FluxCrop, PixelLoss
     target = None
 
     def forward():
@@ -163,16 +165,21 @@ def main():
             per_target = ops.per_target_sum(flux.detach(), tix, T)
             all_reduce_sum(per_target)                           # RCCL reduce of the receiver flux bitmap
             if backward:
-                loss = torch.nn.functional.mse_loss(flux, target)
+                # the epoch's epilogue (surface_reconstructor.py:575-590, 664-676): crop around the centre of mass,
+                # pixel loss against the (cropped) measured flux
+                cropped = FluxCrop.apply(flux, crop_dims, 6.0, 6.0)
+                loss = pixel_loss(cropped, target, reduction_dimensions=(1, 2)).sum()
                 loss.backward()
                 full = torch.zeros_like(cp_all)
                 full[own_t] = cp.grad
                 all_reduce_sum(full)                             # surface_reconstructor.py:767-777
         return per_target
 
+    crop_dims = planar.dimensions.index_select(0, tix.long()).contiguous()
+    pixel_loss = PixelLoss()
     with torch.no_grad():
         f0, _ = forward()
-        target = (f0 * 1.05).detach()
+        target = (FluxCrop.apply(f0, crop_dims, 6.0, 6.0) * 1.05 + 1e-3).detach()     # stands in for the measured flux
         del f0
 
     def sync():
