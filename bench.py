@@ -32,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+MEASURED_COPY_GBS = 4796.8   # tools/hbm_peak.py on this pool's MI355X (profiles/r01_hbm_peak.json)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 
 
@@ -275,6 +276,7 @@ def main():
                         "trace_bwd_GBps": bytes_bwd / (ms_bwd * 1e-3) / 1e9},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak_measured_copy": MEASURED_COPY_GBS, "frac_of_measured_copy": achieved / MEASURED_COPY_GBS,
                          "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -52,7 +52,10 @@ def _import_reference():
             pass
 
     stub("colorlog", ColoredFormatter=_Fmt)
-    stub("h5py", File=object, Group=object)
+    # h5py is absent: tests/golden/mini_h5.py reads the reference's own scenario files (superblock-0 HDF5)
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
+    import mini_h5
+    stub("h5py", File=mini_h5.File, Group=mini_h5.Group, Dataset=mini_h5.Dataset)
     stub("torchvision")
     stub("torchvision.transforms")
     stub("paint")
@@ -376,6 +379,115 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
         ref_blocking.create_blocking_primitives_rectangles_by_index = _orig_builder
     torch.set_default_dtype(torch.float32)
     return out, (du32, de32)
+
+
+def run_scenario_file(filename, mapping, n_rays, points_per_facet, blocking, resolution, dtype=torch.float32,
+                      distortions_f32=None):
+    """The reference's own scenario files (tests/data/scenarios/*.h5) through its own loader, kinematics and ray
+    tracer - the path of tests/raytracing/test_blocking.py:336-426 and tests/field/test_integration_alignment.py -
+    captured at the boundary of the hot path: aligned surface points / normals in, bitmaps / factors / gradients out.
+    ``mapping`` = [(heliostat name, target name, incident direction)]."""
+    import h5py     # the stand-in installed by _import_reference()
+    torch.set_default_dtype(dtype)
+    torch.manual_seed(7)
+    with h5py.File(pathlib.Path(REFERENCE) / "tests/data/scenarios" / filename, "r") as scenario_file:
+        scenario = Scenario.load_scenario_from_hdf5(
+            scenario_file=scenario_file, number_of_surface_points_per_facet=torch.tensor(points_per_facet), device=CPU)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    string_mapping = [(h, t_, torch.nn.functional.normalize(torch.tensor(d, dtype=dtype), dim=-1)) for h, t_, d in mapping]
+    mask, target_idx, incident = scenario.index_mapping(heliostat_group=group, string_mapping=string_mapping, device=CPU)
+    group.activate_heliostats(active_heliostats_mask=mask, device=CPU)
+    group.align_surfaces_with_incident_ray_directions(
+        aim_points=scenario.solar_tower.get_centers_of_target_areas(target_area_indices=target_idx, device=CPU),
+        incident_ray_directions=incident, active_heliostats_mask=mask, device=CPU)
+    apts = group.active_surface_points.detach().to(dtype).clone().requires_grad_(True)
+    anrm = group.active_surface_normals.detach().to(dtype).clone().requires_grad_(True)
+    group.active_surface_points, group.active_surface_normals = apts, anrm
+    scenario.set_number_of_rays(number_of_rays=n_rays)
+    captured = []
+    _orig_builder = ref_blocking.create_blocking_primitives_rectangles_by_index
+
+    def _capturing_builder(*a, **k):
+        prims = _orig_builder(*a, **k)
+        if prims[0].requires_grad:
+            for t_ in prims:
+                t_.retain_grad()
+        captured.append(prims)
+        return prims
+
+    ref_blocking.create_blocking_primitives_rectangles_by_index = _capturing_builder
+    res = torch.tensor(resolution)
+    rt = HeliostatRayTracer(scenario=scenario, heliostat_group=group, blocking_active=blocking, batch_size=100,
+                            bitmap_resolution=res)
+    du32, de32 = rt.distortions_dataset.distortions_u, rt.distortions_dataset.distortions_e
+    if distortions_f32 is not None:
+        du32, de32 = distortions_f32
+    rt.distortions_dataset.distortions_u, rt.distortions_dataset.distortions_e = du32.to(dtype), de32.to(dtype)
+    flux, intercept, on_target, unblocked = rt.trace_rays(
+        incident_ray_directions=incident, active_heliostats_mask=mask, target_area_indices=target_idx, device=CPU)
+    g = torch.Generator().manual_seed(1234)
+    weights = torch.rand(flux.shape, generator=g, dtype=torch.float32).to(dtype)
+    (flux * weights).sum().backward()
+    tower = scenario.solar_tower
+    planar, cyl = tower.target_areas[0], tower.target_areas[1]
+    out = dict(
+        aligned_points=npy(apts), aligned_normals=npy(anrm), incident=npy(incident), target_idx=npy(target_idx),
+        active_mask=npy(mask), distortions_u=npy(rt.distortions_dataset.distortions_u),
+        distortions_e=npy(rt.distortions_dataset.distortions_e), resolution=npy(res),
+        target_centers=npy(planar.centers), target_normals=npy(planar.normals), target_dims=npy(planar.dimensions),
+        cyl_centers=npy(cyl.centers), cyl_normals=npy(cyl.normals), cyl_axes=npy(cyl.axes), cyl_radii=npy(cyl.radii),
+        cyl_heights=npy(cyl.heights), cyl_opening=npy(cyl.opening_angles),
+        ray_magnitude=np.float64(float(rt.ray_magnitude)), extinction=np.float64(0.0), reflectivity=np.float64(0.935),
+        flux=npy(flux), intercept=npy(intercept), on_target=npy(on_target), blocking=npy(unblocked),
+        loss_weights=npy(weights), grad_aligned_points=npy(apts.grad), grad_aligned_normals=npy(anrm.grad),
+        control_points=npy(group.nurbs_control_points), positions=npy(group.positions))
+    if blocking:
+        c_, s_, n_ = captured[-1]
+        out.update(blocking_surfaces=npy(rt.blocking_heliostat_surfaces_active), prim_corners=npy(c_), prim_spans=npy(s_),
+                   prim_normals=npy(n_), owner=npy(torch.nonzero(mask, as_tuple=True)[0]))
+        if c_.grad is not None:
+            out.update(grad_prim_corners=npy(c_.grad), grad_prim_spans=npy(s_.grad), grad_prim_normals=npy(n_.grad))
+        # the filtered set, from a second (gradient-free) pass through the same stages
+        with torch.no_grad():
+            refl = geometry.reflect(incident.unsqueeze(1), anrm)
+            rays = rt.scatter_rays(distortion_u=rt.distortions_dataset.distortions_u.contiguous(),
+                                   distortion_e=rt.distortions_dataset.distortions_e.contiguous(),
+                                   original_ray_direction=refl, device=CPU)
+            n_planar = planar.centers.shape[0]
+            t = torch.zeros(rays.ray_magnitudes.shape, dtype=dtype)
+            pm = target_idx < n_planar
+            if pm.any():
+                t[pm] = geometry.line_plane_intersections(
+                    rays=Rays(rays.ray_directions[pm], rays.ray_magnitudes[pm]), points_at_ray_origins=apts[pm],
+                    target_areas=planar, target_area_indices=target_idx[pm], bitmap_resolution=res, device=CPU)[2]
+            if (~pm).any():
+                t[~pm] = geometry.line_cylinder_intersections(
+                    rays=Rays(rays.ray_directions[~pm], rays.ray_magnitudes[~pm]), points_at_ray_origins=apts[~pm],
+                    target_areas=cyl, target_area_indices=target_idx[~pm] - n_planar, bitmap_resolution=res, device=CPU)[2]
+            owner = torch.nonzero(mask, as_tuple=True)[0].repeat_interleave(t.shape[1] * t.shape[2])
+            filt = ref_blocking.lbvh_filter_blocking_planes(
+                points_at_ray_origins=apts, ray_directions=rays.ray_directions, blocking_primitives_corners=c_.detach(),
+                ray_to_heliostat_mapping=owner, intersection_distances_target=t, device=CPU)
+            out.update(filter_indices=npy(filt))
+    ref_blocking.create_blocking_primitives_rectangles_by_index = _orig_builder
+    torch.set_default_dtype(torch.float32)
+    return out, (du32, de32)
+
+
+# The reference's own scenario files.  "real_blocking" is the setting of tests/raytracing/test_blocking.py:336-426 (six
+# heliostats, five of them in a cluster north of the tower, planar target_0) with fewer rays and surface points so that
+# the fixture stays small; "real_paint_mixed" traces the four PAINT heliostats onto the cylindrical receiver and the
+# planar multi-focus tower with a slanted sun.
+REAL_CASES = {
+    "real_blocking": dict(
+        filename="test_blocking.h5", n_rays=6, points_per_facet=[10, 10], blocking=True, resolution=[64, 64],
+        mapping=[(f"heliostat_{i}", "target_0", [0.0, 1.0, 0.0, 0.0]) for i in range(6)]),
+    "real_paint_mixed": dict(
+        filename="test_scenario_paint_four_heliostats.h5", n_rays=5, points_per_facet=[8, 8], blocking=False,
+        resolution=[96, 64],
+        mapping=[("AA28", "receiver", [0.3, 0.8, -0.52, 0.0]), ("AA31", "multi_focus_tower", [0.3, 0.8, -0.52, 0.0]),
+                 ("AA39", "receiver", [0.3, 0.8, -0.52, 0.0]), ("AC43", "solar_tower_juelich_upper", [0.3, 0.8, -0.52, 0.0])]),
+}
 
 
 def save(name, arrays):
@@ -724,6 +836,13 @@ def main():
         drop = {"reflected", "scattered", "distances", "stage_bitmaps", "aligned_points", "aligned_normals",
                 "grad_nurbs_points", "grad_nurbs_normals", "knots_u", "knots_v"}
         save(name + "_f64", {k: v for k, v in arrs64.items() if k not in drop})
+    for name, case in REAL_CASES.items():
+        if only is not None and name not in only:
+            continue
+        arrs32, dist = run_scenario_file(dtype=torch.float32, **case)
+        save(name, arrs32)
+        arrs64, _ = run_scenario_file(dtype=torch.float64, distortions_f32=dist, **case)
+        save(name + "_f64", arrs64)
     # config 1 / config 2: inputs regenerate from the recipe (seeded torch CPU RNG); store outputs only.
     keep = {"flux", "intercept", "on_target", "blocking", "per_target", "control_points", "orientation",
             "aligned_points", "aligned_normals", "incident", "target_idx", "target_centers", "target_normals",

@@ -1,0 +1,309 @@
+"""A read-only stand-in for the few h5py calls ARTIST's scenario loader makes - TEST INFRASTRUCTURE ONLY.
+
+h5py is not installed in this image, so the reference cannot open its own scenario files
+(``/root/reference/tests/data/scenarios/*.h5``).  Those files use the oldest HDF5 layout (superblock version 0,
+symbol-table groups, contiguous or compact uncompressed datasets), which this module parses from the published
+HDF5 file-format specification: enough for ``File(path, "r")`` as a context manager, ``group[key]`` (also with
+``a/b/c`` paths), ``key in group``, ``.keys()``, ``.items()``, ``.values()``, ``len()``, iteration, ``.name``,
+``dataset[()]``, ``dataset[...]``, ``.shape``, ``.dtype``.  ``tests/golden/generate_golden.py`` installs it as
+``sys.modules["h5py"]`` before importing the reference; nothing in the product or on the GPU box uses it.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+_SIGNATURE = b"\x89HDF\r\n\x1a\n"
+_UNDEFINED = 0xFFFFFFFFFFFFFFFF
+
+
+class _Reader:
+    def __init__(self, path):
+        with open(path, "rb") as fh:
+            self.buf = fh.read()
+        if self.buf[:8] != _SIGNATURE or self.buf[8] != 0:
+            raise OSError(f"{path}: not an HDF5 file with a version-0 superblock")
+        if self.buf[13] != 8 or self.buf[14] != 8:
+            raise OSError("only 8-byte offsets and lengths are supported")
+        self.base = struct.unpack_from("<Q", self.buf, 24)[0]
+        self.root_entry = 24 + 32            # base, free-space, end-of-file, driver-info addresses, then the root entry
+
+    def u(self, fmt, off):
+        return struct.unpack_from("<" + fmt, self.buf, off)
+
+    def cstring(self, off):
+        end = self.buf.index(b"\0", off)
+        return self.buf[off:end].decode("utf-8")
+
+    # -- object headers (version 1) ----------------------------------------------------------------------
+    def messages(self, addr):
+        addr += self.base
+        version, _, n_msgs, _, size = self.u("BBHII", addr)
+        if version != 1:
+            raise OSError(f"object header version {version} is not supported")
+        blocks = [(addr + 16, size)]
+        out = []
+        while blocks and len(out) < n_msgs:
+            pos, remaining = blocks.pop(0)
+            end = pos + remaining
+            while pos + 8 <= end and len(out) < n_msgs:
+                mtype, msize, _flags = self.u("HHB", pos)
+                body = pos + 8
+                if mtype == 0x10:                                   # continuation block
+                    c_off, c_len = self.u("QQ", body)
+                    blocks.append((c_off + self.base, c_len))
+                out.append((mtype, body, msize))
+                pos = body + msize
+        return out
+
+    # -- old-style groups: B-tree of symbol-table nodes + local heap of names ------------------------------
+    def group_entries(self, btree_addr, heap_addr):
+        heap = heap_addr + self.base
+        if self.buf[heap:heap + 4] != b"HEAP":
+            raise OSError("bad local heap")
+        data_addr = self.u("Q", heap + 24)[0] + self.base
+        entries = {}
+
+        def walk(node):
+            node += self.base
+            if self.buf[node:node + 4] != b"TREE":
+                raise OSError("bad group B-tree node")
+            ntype, level, used = self.u("BBH", node + 4)
+            if ntype != 0:
+                raise OSError("unexpected B-tree node type")
+            pos = node + 24                                          # after left / right sibling addresses
+            for i in range(used):
+                child = self.u("Q", pos + 8 + i * 16)[0]             # key_i, child_i, key_i+1, ...
+                if level > 0:
+                    walk(child)
+                else:
+                    snod = child + self.base
+                    if self.buf[snod:snod + 4] != b"SNOD":
+                        raise OSError("bad symbol table node")
+                    count = self.u("H", snod + 6)[0]
+                    for k in range(count):
+                        e = snod + 8 + 40 * k
+                        name_off, header = self.u("QQ", e)
+                        entries[self.cstring(data_addr + name_off)] = header
+        walk(btree_addr)
+        return entries
+
+    def open_object(self, header_addr, name):
+        msgs = self.messages(header_addr)
+        for mtype, body, _ in msgs:
+            if mtype == 0x11:                                        # symbol table message: this is a group
+                btree, heap = self.u("QQ", body)
+                return Group(self, name, self.group_entries(btree, heap), self.attributes(msgs))
+        return Dataset(self, name, msgs)
+
+    def attributes(self, msgs):
+        """Attribute messages (type 0x0C, versions 1-3) of an object header -> {name: value}."""
+        out = {}
+        for mtype, body, _ in msgs:
+            if mtype != 0x0C:
+                continue
+            version = self.buf[body]
+            name_size, type_size, space_size = self.u("HHH", body + 2)
+            pos = body + 8 + (1 if version == 3 else 0)
+            pad = (lambda n: (n + 7) & ~7) if version == 1 else (lambda n: n)
+            name = self.buf[pos:pos + name_size].split(b"\0")[0].decode("utf-8")
+            pos += pad(name_size)
+            dtype, kind = _parse_datatype(self, pos)
+            type_at = pos
+            pos += pad(type_size)
+            sv, rank = self.u("BB", pos)
+            dims_at = pos + (8 if sv == 1 else 4)
+            shape = tuple(self.u("Q", dims_at + 8 * i)[0] for i in range(rank))
+            pos += pad(space_size)
+            count = int(np.prod(shape)) if shape else 1
+            if kind == "vlen_string":
+                vals = []
+                for i in range(count):
+                    _length, collection, index = self.u("IQI", pos + 16 * i)
+                    vals.append(self.global_heap_object(collection, index).decode("utf-8"))
+                value = vals[0] if not shape else np.array(vals, dtype=object).reshape(shape)
+            elif kind == "string":
+                size = self.u("I", type_at + 4)[0]
+                vals = [self.buf[pos + i * size:pos + (i + 1) * size].split(b"\0")[0].decode("utf-8") for i in range(count)]
+                value = vals[0] if not shape else np.array(vals, dtype=object).reshape(shape)
+            else:
+                arr = np.frombuffer(self.buf, dtype=dtype, count=count, offset=pos).copy()
+                value = arr.reshape(shape) if shape else arr[0]
+            out[name] = value
+        return out
+
+    # -- datasets ---------------------------------------------------------------------------------------
+    def global_heap_object(self, collection, index):
+        pos = collection + self.base
+        if self.buf[pos:pos + 4] != b"GCOL":
+            raise OSError("bad global heap collection")
+        size = self.u("Q", pos + 8)[0]
+        cur, end = pos + 16, pos + size
+        while cur + 16 <= end:
+            idx, _, _, osize = self.u("HHIQ", cur)
+            if idx == 0:
+                break
+            if idx == index:
+                return self.buf[cur + 16:cur + 16 + osize]
+            cur += 16 + ((osize + 7) & ~7)
+        raise KeyError(f"global heap object {index}")
+
+
+def _parse_datatype(r, body):
+    class_and_version, b0, _b1, _b2, size = r.u("BBBBI", body)
+    cls = class_and_version & 0x0F
+    if cls == 0:                                                    # fixed point
+        return np.dtype(("<" if not (b0 & 1) else ">") + ("i" if b0 & 8 else "u") + str(size)), None
+    if cls == 1:                                                    # floating point
+        return np.dtype(("<" if not (b0 & 1) else ">") + "f" + str(size)), None
+    if cls == 3:                                                    # fixed-length string
+        return np.dtype(f"S{size}"), "string"
+    if cls == 9:                                                    # variable length
+        if (b0 & 0x0F) == 1:
+            return np.dtype("O"), "vlen_string"
+        raise OSError("variable-length sequences are not supported")
+    if cls == 8:                                                    # enumeration (h5py stores bool like this)
+        base, _ = _parse_datatype(r, body + 8)
+        return base, "enum"
+    raise OSError(f"datatype class {cls} is not supported")
+
+
+class Dataset:
+    def __init__(self, r, name, msgs):
+        self._r, self.name = r, name
+        self.shape, self.dtype, self._kind, self._data = (), None, None, None
+        for mtype, body, msize in msgs:
+            if mtype == 0x01:                                       # dataspace
+                version, rank, flags = r.u("BBB", body)
+                dims_at = body + (8 if version == 1 else 4)
+                self.shape = tuple(r.u("Q", dims_at + 8 * i)[0] for i in range(rank))
+            elif mtype == 0x03:
+                self.dtype, self._kind = _parse_datatype(r, body)
+                self._elem_size = r.u("I", body + 4)[0]
+            elif mtype == 0x08:                                     # data layout
+                version = r.buf[body]
+                if version == 3:
+                    lclass = r.buf[body + 1]
+                    if lclass == 0:
+                        size = r.u("H", body + 2)[0]
+                        self._data = (body + 4, size)
+                    elif lclass == 1:
+                        addr, size = r.u("QQ", body + 2)
+                        self._data = (None, 0) if addr == _UNDEFINED else (addr + r.base, size)
+                    else:
+                        raise OSError(f"{name}: chunked datasets are not supported")
+                else:
+                    rank, lclass = r.u("BB", body + 1)
+                    if lclass != 1:
+                        raise OSError(f"{name}: only contiguous version-1/2 layouts are supported")
+                    addr = r.u("Q", body + 8)[0]
+                    self._data = (addr + r.base, None)
+        if self.dtype is None or self._data is None:
+            raise OSError(f"{name}: incomplete dataset header")
+
+    def _read(self):
+        count = int(np.prod(self.shape)) if self.shape else 1
+        off, _ = self._data
+        r = self._r
+        if self._kind == "vlen_string":
+            out = []
+            for i in range(count):
+                _length, collection, index = r.u("IQI", off + 16 * i)
+                out.append(r.global_heap_object(collection, index))
+            arr = np.array(out, dtype=object)
+        elif off is None:
+            arr = np.zeros(count, dtype=self.dtype)
+        else:
+            arr = np.frombuffer(r.buf, dtype=self.dtype, count=count, offset=off).copy()
+        if self._kind == "string":
+            arr = np.array([bytes(x).split(b"\0")[0] for x in arr], dtype=object)
+        return arr.reshape(self.shape) if self.shape else arr.reshape(())[()]
+
+    def __getitem__(self, key):
+        value = self._read()
+        if key == () or key is Ellipsis:
+            return value
+        return value[key]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __bool__(self):          # an open h5py object is truthy whatever its length
+        return True
+
+    def __array__(self, dtype=None):
+        return np.asarray(self._read(), dtype=dtype)
+
+
+class Group:
+    def __init__(self, r, name, entries, attrs=None):
+        self._r, self.name, self._entries = r, name, entries
+        self.attrs = attrs or {}
+
+    def _child(self, key):
+        return self._r.open_object(self._entries[key], (self.name.rstrip("/") + "/" + key))
+
+    def __getitem__(self, path):
+        node = self
+        for part in [p for p in str(path).split("/") if p]:
+            if not isinstance(node, Group) or part not in node._entries:
+                raise KeyError(f"Unable to open object (object '{part}' doesn't exist)")
+            node = node._child(part)
+        return node
+
+    def get(self, path, default=None):
+        try:
+            return self[path]
+        except KeyError:
+            return default
+
+    def __contains__(self, path):
+        try:
+            self[path]
+            return True
+        except KeyError:
+            return False
+
+    def keys(self):
+        return sorted(self._entries)          # h5py iterates symbol-table groups in name order
+
+    def values(self):
+        return [self._child(k) for k in self.keys()]
+
+    def items(self):
+        return [(k, self._child(k)) for k in self.keys()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self._entries)
+
+    def __bool__(self):
+        return True
+
+
+class File(Group):
+    def __init__(self, path, mode="r", **_kwargs):
+        if mode != "r":
+            raise OSError("mini_h5 is read-only")
+        r = _Reader(str(path))
+        e = r.root_entry
+        _name_off, header, cache_type = r.u("QQI", e)
+        if cache_type == 1:
+            btree, heap = r.u("QQ", e + 24)
+            entries = r.group_entries(btree, heap)
+        else:
+            entries = r.open_object(header, "/")._entries
+        super().__init__(r, "/", entries, r.attributes(r.messages(header)))
+        self.filename = str(path)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def close(self):
+        pass

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import BLOCKING_CASES, CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
+from conftest import BLOCKING_CASES, CYL_CASES, REAL_CASES, STAGE_CASES, rel_l2, sun_distortions
 
 pytestmark = pytest.mark.gpu
 
@@ -882,3 +882,37 @@ def test_flux_epilogue_full_size_properties():
     loss = PixelLoss()(zoom, same.detach() + 1.0, reduction_dimensions=(1, 2)).sum()
     loss.backward()
     assert torch.isfinite(normals.grad).all() and float(normals.grad.abs().max()) > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's own scenario files (fitted surfaces, rigid-body kinematics, planar + cylindrical areas, blocking)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", REAL_CASES)
+def test_real_scenarios(golden, name):
+    from artist_amd import trace_rays
+    from artist_amd.blocking import create_blocking_primitives_rectangles_by_index
+    d, d64 = golden(name), golden(name + "_f64")
+    inp = trace_inputs(d)
+    points = inp["origins"].requires_grad_(True)
+    inp["normals"].requires_grad_(True)
+    kw = dict(cyl=cyl_inputs(d))
+    blocking = "prim_corners" in d
+    if blocking:
+        np.testing.assert_array_equal(d["blocking_surfaces"], d["aligned_points"])      # every heliostat is active
+        corners, spans, normals = create_blocking_primitives_rectangles_by_index(points)
+        kw["blocking"] = dict(corners=corners, spans=spans, normals=normals, owner=t(d["owner"]).int())
+    out = trace_rays(**inp, **kw)
+    flux, fac = out[0], out[1]
+    if blocking:
+        np.testing.assert_array_equal(np.nonzero(n(out[2]))[0], d["filter_indices"])
+    (flux * t(d["loss_weights"])).sum().backward()
+    yard = rel_l2(d["flux"], d64["flux"])
+    assert rel_l2(n(flux), d["flux"]) < max(yard, 2e-4), (rel_l2(n(flux), d["flux"]), yard)
+    assert rel_l2(n(flux), d64["flux"]) < 2 * max(yard, 2e-4)
+    rays = d["distortions_u"][0].size
+    for row, key in enumerate(("intercept", "on_target", "blocking")):
+        np.testing.assert_allclose(n(fac[row]), d[key], rtol=0, atol=2.5 / rays)
+    for got, key in ((points.grad, "grad_aligned_points"), (inp["normals"].grad, "grad_aligned_normals")):
+        yard = rel_l2(d[key], d64[key])
+        assert rel_l2(n(got), d[key]) < max(2 * yard, 1e-3), (key, rel_l2(n(got), d[key]), yard)
+        assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)

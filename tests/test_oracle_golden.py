@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import BLOCKING_CASES, CYL_CASES, STAGE_CASES, rel_l2, sun_distortions
+from conftest import BLOCKING_CASES, CYL_CASES, REAL_CASES, STAGE_CASES, rel_l2, sun_distortions
 
 
 # ---- reference's own known answers -----------------------------------------------------------
@@ -418,3 +418,47 @@ def test_flux_crop_and_losses_vs_reference_autograd(golden, tag, dt, tol):
         loss, g = fn(pred, truth, w)
         assert rel_l2(loss, ka[f"loss_{name}_{tag}"]) < tol, name
         assert rel_l2(g, ka[f"loss_{name}_{tag}_grad"]) < tol, name
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's own scenario files (HDF5, read by tests/golden/mini_h5.py in the generator): fitted NURBS surfaces,
+# rigid-body kinematics with real actuators, planar and cylindrical target areas, blocking between six heliostats.
+# ---------------------------------------------------------------------------------------------
+def _real_case_blocking(d):
+    if "prim_corners" not in d:
+        return None
+    return dict(corners=d["prim_corners"], spans=d["prim_spans"], normals=d["prim_normals"], owner=d["owner"].astype(np.int32))
+
+
+@pytest.mark.parametrize("name", REAL_CASES)
+def test_real_scenarios(golden, name):
+    d, d64 = golden(name), golden(name + "_f64")
+    for dd, tight in ((d64, True), (d, False)):
+        args = (dd["aligned_points"], dd["aligned_normals"], dd["incident"], dd["distortions_u"], dd["distortions_e"],
+                dd["target_idx"], dd["target_centers"], dd["target_normals"], dd["target_dims"], dd["resolution"])
+        sc = (float(dd["ray_magnitude"]), float(dd["extinction"]), float(dd["reflectivity"]))
+        blk = _real_case_blocking(dd)
+        flux, fac, dbg = oracle.trace_fwd(*args, *sc, debug=True, cyl=oracle.cyl_tables(dd), blocking=blk)
+        out = oracle.trace_bwd(*args, dd["loss_weights"], *sc, cyl=oracle.cyl_tables(dd), blocking=blk)
+        go, gn = out[0], out[1]
+        if blk is not None:
+            np.testing.assert_array_equal(np.nonzero(dbg["filter_flags"])[0], dd["filter_indices"])
+            _, _, _, g_sfc = _chain_primitive_grads(dd["blocking_surfaces"], *out[2:])
+            # the traced heliostats are rows of the blocking surfaces (all six are active here)
+            go = go + g_sfc[dd["owner"]]
+        yard_f = rel_l2(d["flux"], d64["flux"])
+        if tight:
+            np.testing.assert_allclose(flux, dd["flux"], rtol=1e-6, atol=1e-9)
+            assert rel_l2(go, dd["grad_aligned_points"]) < 1e-6 and rel_l2(gn, dd["grad_aligned_normals"]) < 1e-6
+            for row, key in enumerate(("intercept", "on_target", "blocking")):
+                np.testing.assert_array_equal(fac[row], dd[key])
+        else:
+            assert rel_l2(flux, dd["flux"]) < max(yard_f, 1e-5), (rel_l2(flux, dd["flux"]), yard_f)
+            for got, key in ((go, "grad_aligned_points"), (gn, "grad_aligned_normals")):
+                yard = rel_l2(d[key], d64[key])
+                assert rel_l2(got, dd[key]) < max(yard, 1e-3), (key, rel_l2(got, dd[key]), yard)
+            rays = dd["distortions_u"][0].size
+            for row, key in enumerate(("intercept", "on_target", "blocking")):
+                np.testing.assert_allclose(fac[row], dd[key], rtol=0, atol=1.5 / rays)
+    if name == "real_blocking":
+        assert d["blocking"].min() < 0.01 and (d["blocking"] == 1).any()      # from fully blocked to free
