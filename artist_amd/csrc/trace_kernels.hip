@@ -473,6 +473,9 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
                 // (heliostat_ray_tracer.py:723-728), or a stray of the union window -> global atomics, once
                 const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
                 const bool in_union = (unsigned)le < twm1 && (unsigned)(iu - win.u0) < uthm1;
+#ifdef ART_DEBUG_COUNT_STRAYS    // diagnostic build: factors row 2 = share of stray rays
+                if (first) n_free += __popcll(__builtin_amdgcn_ballot_w64(valid && on && !in_union));
+#endif
 #ifndef ART_ABLATE_NO_STRAYS   // diagnostic build drops the stray rays (wrong bitmap) to price them
                 if (first && valid && on && !in_union) {
                     float* row_hi = bitmap + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
@@ -514,7 +517,11 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
     if (first && lane == 0) {                                                           // wave totals
         atomicAdd(&s_cnt[0], lean ? n_valid : n_int); atomicAdd(&s_cnt[1], n_valid);
+#ifdef ART_DEBUG_COUNT_STRAYS
+        atomicAdd(&s_cnt[2], n_free);
+#else
         if constexpr (BLOCKING) atomicAdd(&s_cnt[2], n_free);
+#endif
     }
     __syncthreads();
 
@@ -524,7 +531,11 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         const unsigned* trow = tile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) {
             const unsigned q = trow[c];
+#ifdef ART_ABLATE_NO_FLUSH      // diagnostic build: price the global atomics of the flush (wrong bitmap)
+            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (float)q * win.inv_scale);
+#else
             if (q != 0u) atomicAdd(g + c, (float)q * win.inv_scale);
+#endif
         }
     }
     __syncthreads();   // the band is flushed before the next pass re-zeroes the tile
@@ -542,6 +553,9 @@ __global__ void finalize_factors_kernel(float* factors, int H, float rays_per_he
     factors[h] = (float)n_int / rays_per_heliostat;
     factors[H + h] = (float)n_on / rays_per_heliostat;
     // blocking off: blocked == 0 everywhere
+#ifdef ART_DEBUG_COUNT_STRAYS
+    blocking = 1;
+#endif
     factors[2 * H + h] = (blocking ? (float)n_free : rays_per_heliostat) / rays_per_heliostat;
 }
 
@@ -804,12 +818,14 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
             if (__builtin_expect(wave_any(valid && !inwin), 0)) {
                 const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
                 const bool in_union = (unsigned)le < twm1 && (unsigned)(iu - win.u0) < uthm1;
+#ifndef ART_ABLATE_NO_STRAYS
                 if (first && valid && on && !in_union) {              // stray: global gather, once
                     const float* g_hi = G + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
                     const float* g_lo = g_hi + a.W;
                     g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
                     use = true;
                 }
+#endif
             }
             if constexpr (CYL) {
                 if (use) {     // divergent, but a masked ray's intermediates are not finite: no zero-weight trick here
