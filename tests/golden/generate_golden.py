@@ -261,6 +261,23 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
             incident_ray_directions=incident, aim_points=aim, device=CPU
         )
     orientation = orientation.detach().clone().requires_grad_(with_grads)
+    if with_grads:
+        # kinematic parameters: d(orientation)/d(rotation / translation deviations) of the reference's rigid-body
+        # kinematics (artist/field/kinematics_rigid_body.py:194-634), per heliostat - the chain by which the
+        # orientation gradient reaches the parameters the kinematics reconstructor optimises
+        kin = group.kinematics
+        rot0 = kin.active_rotation_deviation_parameters.detach().clone()
+        trans0 = kin.active_translation_deviation_parameters.detach().clone()
+
+        def _orientations(rot, trans):
+            kin.active_rotation_deviation_parameters, kin.active_translation_deviation_parameters = rot, trans
+            return kin.incident_ray_directions_to_orientations(incident_ray_directions=incident, aim_points=aim, device=CPU)
+
+        jr, jt = torch.autograd.functional.jacobian(_orientations, (rot0, trans0))      # [H,4,4,H,4], [H,4,4,H,9]
+        hh = torch.arange(H)
+        out.update(kin_rot_params=npy(rot0), kin_trans_params=npy(trans0),
+                   kin_jac_rot=npy(jr[hh, :, :, hh]), kin_jac_trans=npy(jt[hh, :, :, hh]))
+        kin.active_rotation_deviation_parameters, kin.active_translation_deviation_parameters = rot0, trans0
     apts = sp @ orientation.transpose(1, 2)
     anrm = sn @ orientation.transpose(1, 2)
     if with_grads:
@@ -372,6 +389,9 @@ def run_case(name, case, with_grads=True, store_rays=True, dtype=torch.float32, 
                    grad_aligned_points=npy(apts.grad), grad_aligned_normals=npy(anrm.grad),
                    grad_nurbs_points=npy(sp.grad), grad_nurbs_normals=npy(sn.grad),
                    grad_orientation=npy(orientation.grad), grad_control_points=npy(cp_active.grad))
+        # gradients of the loss w.r.t. the kinematic deviation parameters = orientation gradient through the Jacobians
+        out.update(grad_kin_rot=np.einsum("hij,hijk->hk", out["grad_orientation"], out["kin_jac_rot"]),
+                   grad_kin_trans=np.einsum("hij,hijk->hk", out["grad_orientation"], out["kin_jac_trans"]))
         if use_blocking and captured_prims and captured_prims[-1][0].grad is not None:
             c_, s_, n_ = captured_prims[-1]
             out.update(grad_prim_corners=npy(c_.grad), grad_prim_spans=npy(s_.grad), grad_prim_normals=npy(n_.grad))

@@ -180,6 +180,18 @@ def test_end_to_end_autograd_to_control_points(golden, name):
             continue
         ref_err = rel_l2(ref, d64[key])
         assert rel_l2(n(got), ref) < max(3 * ref_err, 5e-4), (key, rel_l2(n(got), ref), ref_err)
+    # ... and on to the kinematic parameters: d(orientation)/d(rotation, translation deviations) of the reference's
+    # rigid-body kinematics is stored with the fixture (torch.autograd.functional.jacobian of
+    # kinematics_rigid_body.py:540-634), the chain rule does the rest
+    for jac, key in (("kin_jac_rot", "grad_kin_rot"), ("kin_jac_trans", "grad_kin_trans")):
+        got = torch.einsum("hij,hijk->hk", ori.grad, t(d[jac]))
+        ref, ref64 = d[key], d64[key]
+        if np.linalg.norm(ref64) == 0:
+            assert float(got.abs().sum()) == 0
+            continue
+        ref_err = rel_l2(ref, ref64)
+        assert rel_l2(n(got), ref) < max(3 * ref_err, 5e-4), (key, rel_l2(n(got), ref), ref_err)
+        assert rel_l2(n(got), ref64) < max(4 * ref_err, 5e-4), (key, rel_l2(n(got), ref64), ref_err)
 
 
 @pytest.mark.parametrize("name,tol", [("config1", 1e-6), ("config2", 1e-5)])

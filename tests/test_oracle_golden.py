@@ -209,6 +209,11 @@ def test_backward_f64_tight(golden, name):
     g_ori = np.einsum("hpi,hpj->hij", go, pts.reshape(H, -1, 4)) + np.einsum("hpi,hpj->hij", gn, nrm.reshape(H, -1, 4))
     if np.linalg.norm(d64["grad_orientation"]) > 0:
         assert rel_l2(g_ori, d64["grad_orientation"]) < 1e-9 * loose
+    # kinematic deviation parameters through the reference's Jacobians (kinematics_rigid_body.py:540-634)
+    for jac, key in (("kin_jac_rot", "grad_kin_rot"), ("kin_jac_trans", "grad_kin_trans")):
+        got = np.einsum("hij,hijk->hk", g_ori, d64[jac])
+        if np.linalg.norm(d64[key]) > 0:
+            assert rel_l2(got, d64[key]) < 1e-9 * loose, key
 
 
 @pytest.mark.parametrize("name,tol", [("config1", 1e-6), ("config2", 1e-5)])
