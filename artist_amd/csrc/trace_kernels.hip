@@ -372,6 +372,7 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     // (blocking: an intensity can be attenuated to 0 as well)
     const bool lean = !CYL && !BLOCKING && a.mag >= 1e-6f && k_ext >= 1e-6f && k_refl >= 1e-6f && a.mag <= 1e6f && k_ext <= 1e6f &&
                       k_refl <= 1e6f;
+    const unsigned long long lean_all = lean ? ~0ull : 0ull;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
     const int pth = min(win.ths, win.u0 + win.th - pu0);                 // rows held in LDS in this pass
@@ -412,9 +413,13 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
             float be, bu, I0; bool valid;
+            // lane masks as wave-uniform 64-bit scalars (ballots of the raw compares: no round trip through a VGPR):
+            // the ray counters and the rare-branch tests then run on the scalar unit
+            unsigned long long m_valid;
             if constexpr (CYL) {
                 const CylHit ch = cyl_hit(cy, cp, rx, ry, rz);                     // geometry.py:287-445
                 valid = ch.ok; be = ch.be; bu = ch.bu; I0 = ch.I0;
+                m_valid = __builtin_amdgcn_ballot_w64(valid);
             } else {
                 const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
                 const bool front = ah < 0.0f;
@@ -423,16 +428,22 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
                 const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
                 bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;                // :154-174
                 // :178-184.  0 <= x <= hi  <=>  x == med3(x, 0, hi)   (NaN compares false)
-                valid = front && be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1) &&
-                        bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
+                const bool e_ok = be0 == __builtin_amdgcn_fmed3f(be0, 0.0f, pl.wm1);
+                const bool u_ok = bu == __builtin_amdgcn_fmed3f(bu, 0.0f, pl.hm1);
+                valid = front && e_ok && u_ok;
+                m_valid = __builtin_amdgcn_ballot_w64(front) & __builtin_amdgcn_ballot_w64(e_ok) &
+                          __builtin_amdgcn_ballot_w64(u_ok);
                 be = pl.wm1 - be0;                                                 // :195-197
                 I0 = pl.mag * (-ah);                                               // :139
             }
+
             const float tbe = truncf(be), tbu = truncf(bu);                    // heliostat_ray_tracer.py:674-675
             const float cle = (tbe + 1.0f) - be, clu = (tbu + 1.0f) - bu, che = be - tbe, chu = bu - tbu;   // :694-700
             const int ie = (int)tbe, iu = (int)tbu;
             const int le = ie - win.e0, lu = iu - pu0;
             const bool inwin = valid && (unsigned)le < twm1 && (unsigned)lu < thm1;     // implies ie+1 < W, iu+1 < Hh
+            const unsigned long long m_inwin = m_valid & __builtin_amdgcn_ballot_w64((unsigned)le < twm1) &
+                                               __builtin_amdgcn_ballot_w64((unsigned)lu < thm1);
             const int cell_lo = inwin ? (int)__umul24(lu, win.tw) + le : dummy;        // flat row iu
             const int cell_hi = inwin ? cell_lo + win.tw : dummy;                       // flat row iu + 1
             float keep = 1.0f;                                                          // 1 - blocked
@@ -452,8 +463,9 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             const float Is = inwin ? fabsf(I) * win.scale : 0.0f;
             // ray counters live in SGPRs (v_cmp + s_bcnt1).  With positive, sanely scaled intensity factors
             // (`lean`) I0 > 0 and I > 0 follow from `valid` and one count serves both.
-            n_valid += __popcll(__builtin_amdgcn_ballot_w64(valid && (lean || I0 > 0.0f)));
-            if (!lean) n_int += __popcll(__builtin_amdgcn_ballot_w64(valid && I > 0.0f));
+            // (`lean_all` = all ones when a valid ray is known to carry intensity: no data-dependent control flow here)
+            n_valid += __popcll(m_valid & (__builtin_amdgcn_ballot_w64(I0 > 0.0f) | lean_all));
+            n_int += __popcll(m_valid & __builtin_amdgcn_ballot_w64(I > 0.0f) & ~lean_all);
             // the previous ray's adds have landed; a carry needs a cell that was already above 2^31 (q < 2^22)
             if (__builtin_expect(wave_any(((ps.o1 | ps.o2 | ps.o3 | ps.o4) >> 31) != 0u), 0))
                 resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             ps.o3 = atomicAdd(tile + cell_lo + 1, ps.q3);
             ps.o4 = atomicAdd(tile + cell_lo, ps.q4);
 #endif
-            if (__builtin_expect(wave_any(valid && !inwin), 0)) {
+            if (__builtin_expect((m_valid & ~m_inwin) != 0ull, 0)) {
                 // valid but not in this pass's band: another band's ray, the last pixel row/column
                 // (heliostat_ray_tracer.py:723-728), or a stray of the union window -> global atomics, once
                 const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
@@ -815,7 +827,7 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
             const int cell_hi = inwin ? cell_lo + win.tw : dummy;
             float g1 = gtile[cell_hi], g2 = gtile[cell_hi + 1], g3 = gtile[cell_lo + 1], g4 = gtile[cell_lo];
             bool use = inwin;
-            if (__builtin_expect(wave_any(valid && !inwin), 0)) {
+            if (__builtin_expect((__builtin_amdgcn_ballot_w64(valid) & ~__builtin_amdgcn_ballot_w64(inwin)) != 0ull, 0)) {
                 const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
                 const bool in_union = (unsigned)le < twm1 && (unsigned)(iu - win.u0) < uthm1;
 #ifndef ART_ABLATE_NO_STRAYS
