@@ -127,6 +127,36 @@ __device__ __forceinline__ Rot make_rot(float e, float u)
     return m;
 }
 
+// Same with the range test hoisted by the caller (one test per group of four rays): SMALL = every angle of the
+// group is within the Taylor kernel's range on every lane.
+template <bool SMALL>
+__device__ __forceinline__ Rot make_rot_t(float e, float u)
+{
+    if constexpr (!SMALL) return make_rot(e, u);
+    Rot m;
+    sincos_small(e, m.se, m.ce);
+    sincos_small(u, m.su, m.cu);
+    m.m10 = m.ce * m.su; m.m11 = m.ce * m.cu; m.m20 = m.se * m.su; m.m21 = m.se * m.cu;
+    return m;
+}
+
+// n / a, correctly rounded, without the range scaling of the generic IEEE sequence (v_div_scale / v_div_fixup): the
+// same Newton + two residual corrections, valid while neither operand nor the quotient leaves the normal range -
+// path lengths and direction cosines here are ~1e-3 .. 1e3.  Bit-identical to n / a on 6e8 random operand pairs
+// with every reciprocal seed within 1 ULP (tools/fastdiv_check.c); a denormal cosine yields NaN instead of a
+// huge quotient, and both fail the validity test the same way.
+__device__ __forceinline__ float div_noscale(float n, float a)
+{
+    const float y0 = __builtin_amdgcn_rcpf(a);
+    const float e = fmaf(-a, y0, 1.0f);
+    const float y = fmaf(e, y0, y0);
+    float q = n * y;
+    float r = fmaf(-a, q, n);
+    q = fmaf(r, y, q);
+    r = fmaf(-a, q, n);
+    return fmaf(r, y, q);
+}
+
 // heliostat_ray_tracer.py:547-552: 4-term dot products, k = 0..3 sequential; the w column of the
 // matrix is zero for rows 0..2 and d.w is finite, so "+ 0*d.w" is an exact no-op apart from the
 // sign of a zero result, which nothing downstream observes.

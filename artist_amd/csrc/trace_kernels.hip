@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "trace_common.hpp"
 
 namespace art {
@@ -408,8 +410,8 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         // (ray_math.hpp); the masks are reduced to the one question the LDS path asks ("does this ray land inside
         // this pass's window?"), and everything rare - a scatter angle beyond the small-angle kernel, a valid ray
         // outside the window, a cell that may have wrapped - sits behind wave-uniform branches.
-        auto trace_one = [&](const float u, const float e) {
-            const Rot m = make_rot(e, u);
+        auto trace_one = [&](auto small_angles, const float u, const float e) {
+            const Rot m = make_rot_t<decltype(small_angles)::value>(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
             float be, bu, I0; bool valid;
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             } else {
                 const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
                 const bool front = ah < 0.0f;
-                const float tt = numer / (front ? ah : 1.0f);                      // :130-131
+                const float tt = div_noscale(numer, front ? ah : 1.0f);            // :130-131
                 const float hx = o.x + rx * tt, hz = o.z + rz * tt;                // :133-136
                 const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
                 bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;                // :154-174
@@ -519,10 +521,21 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
             load_dist_row<INTERLEAVED>(bu_ + o5, be_ + o5, lane_off, nu1, ne1);
             load_dist_row<INTERLEAVED>(bu_ + o6, be_ + o6, lane_off, nu2, ne2);
             load_dist_row<INTERLEAVED>(bu_ + o7, be_ + o7, lane_off, nu3, ne3);
-            trace_one(cu0, ce0);
-            if (k + 1 < nr) trace_one(cu1, ce1);
-            if (k + 2 < nr) trace_one(cu2, ce2);
-            if (k + 3 < nr) trace_one(cu3, ce3);
+            // one range test for the group's eight angles: sun-shape angles are milliradians, so the Taylor kernels
+            // serve every lane almost always and the full-range sin/cos code stays out of the hot loop
+            const float amax = fmaxf(fmaxf(fmaxf(fabsf(cu0), fabsf(ce0)), fmaxf(fabsf(cu1), fabsf(ce1))),
+                                     fmaxf(fmaxf(fabsf(cu2), fabsf(ce2)), fmaxf(fabsf(cu3), fabsf(ce3))));
+            if (__builtin_expect(wave_any(!(amax <= kSmallAngle)), 0)) {
+                trace_one(std::false_type{}, cu0, ce0);
+                if (k + 1 < nr) trace_one(std::false_type{}, cu1, ce1);
+                if (k + 2 < nr) trace_one(std::false_type{}, cu2, ce2);
+                if (k + 3 < nr) trace_one(std::false_type{}, cu3, ce3);
+            } else {
+                trace_one(std::true_type{}, cu0, ce0);
+                if (k + 1 < nr) trace_one(std::true_type{}, cu1, ce1);
+                if (k + 2 < nr) trace_one(std::true_type{}, cu2, ce2);
+                if (k + 3 < nr) trace_one(std::true_type{}, cu3, ce3);
+            }
             cu0 = nu0; ce0 = ne0; cu1 = nu1; ce1 = ne1; cu2 = nu2; ce2 = ne2; cu3 = nu3; ce3 = ne3;
         }
     }
@@ -775,8 +788,8 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
         // One ray.  The forward re-computation is the reference's arithmetic (it decides which cells the ray
         // touched); masks are reduced to "inside this pass's window?", strays and other bands' rays are handled by
         // a wave-uniform cold branch, and masked rays get zero gradient weights instead of an early exit.
-        auto trace_one = [&](const float u, const float e) {
-            const Rot m = make_rot(e, u);
+        auto trace_one = [&](auto small_angles, const float u, const float e) {
+            const Rot m = make_rot_t<decltype(small_angles)::value>(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
             float keep = 1.0f, trans = 1.0f, g_keep = 0.0f;        // 1 - blocked, exp(-alpha sum), dL/d(1 - blocked)
@@ -810,7 +823,7 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
             } else {
                 ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
                 const bool front = ah < 0.0f;
-                tt = numer / (front ? ah : 1.0f);
+                tt = div_noscale(numer, front ? ah : 1.0f);
                 const float hx = o.x + rx * tt, hz = o.z + rz * tt;
                 const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;
                 bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;
@@ -901,10 +914,19 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
             load_dist_row<INTERLEAVED>(bu_ + o5, be_ + o5, lane_off, nu1, ne1);
             load_dist_row<INTERLEAVED>(bu_ + o6, be_ + o6, lane_off, nu2, ne2);
             load_dist_row<INTERLEAVED>(bu_ + o7, be_ + o7, lane_off, nu3, ne3);
-            trace_one(cu0, ce0);
-            if (k + 1 < nr) trace_one(cu1, ce1);
-            if (k + 2 < nr) trace_one(cu2, ce2);
-            if (k + 3 < nr) trace_one(cu3, ce3);
+            const float amax = fmaxf(fmaxf(fmaxf(fabsf(cu0), fabsf(ce0)), fmaxf(fabsf(cu1), fabsf(ce1))),
+                                     fmaxf(fmaxf(fabsf(cu2), fabsf(ce2)), fmaxf(fabsf(cu3), fabsf(ce3))));
+            if (__builtin_expect(wave_any(!(amax <= kSmallAngle)), 0)) {       // see the forward kernel
+                trace_one(std::false_type{}, cu0, ce0);
+                if (k + 1 < nr) trace_one(std::false_type{}, cu1, ce1);
+                if (k + 2 < nr) trace_one(std::false_type{}, cu2, ce2);
+                if (k + 3 < nr) trace_one(std::false_type{}, cu3, ce3);
+            } else {
+                trace_one(std::true_type{}, cu0, ce0);
+                if (k + 1 < nr) trace_one(std::true_type{}, cu1, ce1);
+                if (k + 2 < nr) trace_one(std::true_type{}, cu2, ce2);
+                if (k + 3 < nr) trace_one(std::true_type{}, cu3, ce3);
+            }
             cu0 = nu0; ce0 = ne0; cu1 = nu1; ce1 = ne1; cu2 = nu2; ce2 = ne2; cu3 = nu3; ce3 = ne3;
         }
         const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
