@@ -30,6 +30,14 @@ def all_reduce_sum(tensor: torch.Tensor, group=None) -> torch.Tensor:
     return tensor
 
 
+def all_reduce_sum_async(tensor: torch.Tensor, group=None):
+    """Start an in-place SUM all-reduce and return a ``wait()``-able handle (None in a single-process run), so that
+    the 256 KB flux reduce travels over xGMI while the backward kernels run."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
+
+
 def reduce_flux_per_target(flux_local: torch.Tensor, target_idx_local: torch.Tensor, n_targets: int,
                            per_target_sum, group=None) -> torch.Tensor:
     """Local per-heliostat bitmaps -> field-wide per-target bitmaps: local segment sum

@@ -114,7 +114,7 @@ def main():
             dist.init_process_group(backend)
 
     from artist_amd import HeliostatRayTracer, NURBSSurfaces
-    from artist_amd.distributed import all_reduce_sum, owned_heliostats
+    from artist_amd.distributed import all_reduce_sum, all_reduce_sum_async, owned_heliostats
     from artist_amd.scene import build_synthetic_scenario
 
     H_total, R, n_eval = args.heliostats, args.rays, args.n_eval
@@ -164,7 +164,7 @@ def main():
         with torch.set_grad_enabled(backward):
             flux, _ = forward()
             per_target = ops.per_target_sum(flux.detach(), tix, T)
-            all_reduce_sum(per_target)                           # RCCL reduce of the receiver flux bitmap
+            pending = all_reduce_sum_async(per_target)           # RCCL reduce of the receiver flux bitmap, overlapped
             if backward:
                 # the epoch's epilogue (surface_reconstructor.py:575-590, 664-676): crop around the centre of mass,
                 # pixel loss against the (cropped) measured flux
@@ -174,6 +174,8 @@ def main():
                 full = torch.zeros_like(cp_all)
                 full[own_t] = cp.grad
                 all_reduce_sum(full)                             # surface_reconstructor.py:767-777
+            if pending is not None:
+                pending.wait()
         return per_target
 
     crop_dims = planar.dimensions.index_select(0, tix.long()).contiguous()
