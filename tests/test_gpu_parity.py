@@ -928,3 +928,98 @@ def test_real_scenarios(golden, name):
         yard = rel_l2(d[key], d64[key])
         assert rel_l2(n(got), d[key]) < max(2 * yard, 1e-3), (key, rel_l2(n(got), d[key]), yard)
         assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)
+
+
+# ---------------------------------------------------------------------------------------------
+# Randomised scenes: every feature at once (planar + cylindrical areas, blocking rectangles, ragged sizes, sample
+# counts above the 4-ray groups and the 128-sample range), HIP vs the CPU oracle on the same inputs.
+# ---------------------------------------------------------------------------------------------
+def _random_scene(seed, H, P, R):
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *shape: torch.rand(shape, generator=g)
+    centre = torch.tensor([0.0, 0.0, 40.0])
+    pos = torch.stack([(rnd(H) - 0.5) * 60.0, 50.0 + rnd(H) * 60.0, rnd(H) * 2.0], dim=1)
+    sun = torch.nn.functional.normalize(torch.tensor([0.15, 0.9, -0.4]) + 0.1 * (rnd(3) - 0.5), dim=0)
+    target_idx = torch.randint(0, 3, (H,), generator=g).int()                    # 0, 1 planar; 2 = the cylinder
+    aim = centre.expand(H, 3).clone()
+    hdir = (pos - centre) * torch.tensor([1.0, 1.0, 0.0])
+    on_cyl = target_idx == 2
+    aim[on_cyl] = (centre + 20.0 * hdir / hdir.norm(dim=1, keepdim=True))[on_cyl]   # the mantle of the 20 m cylinder
+    to_t = torch.nn.functional.normalize(aim - pos, dim=1)
+    n0 = torch.nn.functional.normalize(to_t - sun, dim=1)
+    ex = torch.nn.functional.normalize(torch.linalg.cross(n0, torch.tensor([[0.0, 0.0, 1.0]]).expand(H, 3)), dim=1)
+    ey = torch.linalg.cross(n0, ex)
+    local = (rnd(H, P, 2) - 0.5) * torch.tensor([3.0, 2.5])
+    pts = pos[:, None] + local[..., :1] * ex[:, None] + local[..., 1:] * ey[:, None]
+    nrm = torch.nn.functional.normalize(n0[:, None] + 1.5e-3 * torch.randn((H, P, 3), generator=g), dim=-1)
+    origins = torch.cat([pts, torch.ones(H, P, 1)], -1)
+    normals = torch.cat([nrm, torch.zeros(H, P, 1)], -1)
+    incident = torch.cat([sun, torch.zeros(1)]).expand(H, 4).contiguous()
+    both = 2.5e-3 * torch.randn((H, R, P, 2), generator=g)
+    planes = dict(centers=torch.tensor([[0.0, 0.0, 40.0, 1.0], [0.5, -1.0, 41.0, 1.0]]),
+                  normals=torch.nn.functional.normalize(torch.tensor([[0.0, 1.0, 0.0, 0.0], [0.1, 0.95, 0.3, 0.0]]), dim=1),
+                  dims=torch.tensor([[9.0, 7.0], [6.0, 8.0]]))
+    cyl = dict(centers=torch.tensor([[0.0, 0.0, 40.0, 1.0]]), normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]]),
+               axes=torch.tensor([[0.0, 0.0, 1.0, 0.0]]), radii=torch.tensor([20.0]), heights=torch.tensor([14.0]),
+               opening=torch.tensor([2.8]))
+    # blocking rectangles: the mirrors themselves (bounding rectangle of the random points) + two free-standing
+    # panels placed into the beams of heliostats 0 and 1, one of them grazing the beam edge
+    lo, hi_ = local.amin(1), local.amax(1)
+    def rect(c0, su, sv):
+        return torch.stack([c0, c0 + su, c0 + su + sv, c0 + sv], dim=0)
+    corners = []
+    for h in range(H):
+        c0 = pos[h] + lo[h, 0] * ex[h] + lo[h, 1] * ey[h]
+        corners.append(rect(c0, (hi_[h, 1] - lo[h, 1]) * ey[h], (hi_[h, 0] - lo[h, 0]) * ex[h]))
+    for h, shift in ((0, 0.0), (1 % H, 1.6)):
+        mid = pos[h] + 12.0 * to_t[h] + shift * ex[h]
+        corners.append(rect(mid - 1.0 * ex[h] - 0.8 * ey[h], 1.6 * ey[h], 2.0 * ex[h]))
+    corners = torch.stack(corners)
+    corners = torch.cat([corners, torch.ones(corners.shape[0], 4, 1)], -1)
+    spans = torch.stack((corners[:, 1] - corners[:, 0], corners[:, 3] - corners[:, 0]), dim=1)
+    pn = torch.nn.functional.normalize(torch.linalg.cross(spans[:, 0, :3], spans[:, 1, :3]), dim=-1)
+    pn = torch.cat([pn, torch.zeros(pn.shape[0], 1)], -1)
+    return dict(origins=origins, normals=normals, incident=incident, both=both, target_idx=target_idx, planes=planes,
+                cyl=cyl, prims=dict(corners=corners, spans=spans, normals=pn, owner=torch.arange(H, dtype=torch.int32)))
+
+
+@pytest.mark.parametrize("seed,H,P,R,res,interleaved,lbvh_compat",
+                         [(0, 5, 192, 7, (96, 64), True, False), (1, 4, 333, 130, (64, 80), False, False),
+                          (2, 7, 64, 5, (48, 48), True, True), (3, 3, 1100, 9, (128, 96), True, False)])
+def test_random_scenes_all_features(seed, H, P, R, res, interleaved, lbvh_compat):
+    from artist_amd import per_target_sum, trace_rays
+    sc = _random_scene(seed, H, P, R)
+    dv = lambda x: x.to(DEV)
+    both = dv(sc["both"])
+    du, de = (both[..., 0], both[..., 1]) if interleaved else (both[..., 0].contiguous(), both[..., 1].contiguous())
+    o, nn_ = dv(sc["origins"]).requires_grad_(True), dv(sc["normals"]).requires_grad_(True)
+    prims = {k: dv(v) for k, v in sc["prims"].items()}
+    prims["corners"].requires_grad_(True)
+    cyl_dev = tuple(dv(sc["cyl"][k]) for k in ("centers", "normals", "axes", "radii", "heights", "opening"))
+    kw = dict(ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=res, cyl=cyl_dev,
+              blocking=dict(prims, lbvh_compat=lbvh_compat))
+    args = (o, nn_, dv(sc["incident"]), du, de, dv(sc["target_idx"]), dv(sc["planes"]["centers"]), dv(sc["planes"]["normals"]),
+            dv(sc["planes"]["dims"]))
+    flux, fac, flags = trace_rays(*args, **kw)
+    f32 = lambda x: np.ascontiguousarray(x.detach().cpu().numpy())
+    oracle_args = (f32(sc["origins"]), f32(sc["normals"]), f32(sc["incident"]), f32(sc["both"][..., 0]), f32(sc["both"][..., 1]),
+                   f32(sc["target_idx"]), f32(sc["planes"]["centers"]), f32(sc["planes"]["normals"]), f32(sc["planes"]["dims"]), res)
+    okw = dict(cyl={k: f32(v) for k, v in sc["cyl"].items()},
+               blocking=dict({k: f32(v) for k, v in sc["prims"].items()}, lbvh_compat=lbvh_compat))
+    o_flux, o_fac, dbg = oracle.trace_fwd(*oracle_args, 0.7, 0.05, 0.9, debug=True, **okw)
+    np.testing.assert_array_equal(np.nonzero(n(flags))[0], np.nonzero(dbg["filter_flags"])[0])
+    assert o_flux.sum() > 0 and (dbg["blocked"] > 0.5).any() == bool((n(fac[2]) < 1).any())
+    assert rel_l2(n(flux), o_flux) < 5e-4, rel_l2(n(flux), o_flux)
+    np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=3.0 / (R * P))
+    # fused per-target mode on the same scene
+    flux_t, _, _ = trace_rays(*args, per_target=True, **kw)
+    summed = per_target_sum(flux.detach(), args[5], 3)
+    np.testing.assert_allclose(n(flux_t), n(summed), rtol=0, atol=3e-6 * float(summed.max()))
+    # gradients (origins, normals, rectangle corners 0 through the three tables)
+    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    (flux * w).sum().backward()
+    go, gn, gpc, gps, gpn = oracle.trace_bwd(*oracle_args, f32(w), 0.7, 0.05, 0.9, **okw)
+    assert rel_l2(n(o.grad), go) < 3e-3, rel_l2(n(o.grad), go)
+    assert rel_l2(n(nn_.grad), gn) < 3e-3, rel_l2(n(nn_.grad), gn)
+    if np.linalg.norm(gpc) > 0:
+        assert rel_l2(n(prims["corners"].grad), gpc) < 3e-3, rel_l2(n(prims["corners"].grad), gpc)
