@@ -103,18 +103,19 @@ __global__ __launch_bounds__(kReduceBlock) void flux_com_kernel(const float* __r
     }
 }
 
-// grid (ceil(Hh W / 256), B): one thread per output pixel
+// grid (ceil(W / 256), Hh, B): one thread per output pixel, one output row per workgroup (the row's sampling
+// coordinate and weights are wave-uniform)
 __global__ __launch_bounds__(kFluxBlock) void flux_crop_fwd_kernel(const float* __restrict__ flux,
                                                                    const float* __restrict__ dims,
                                                                    const float* __restrict__ com, int Hh, int W,
                                                                    float crop_w, float crop_h, float* __restrict__ out)
 {
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Hh * W) return;
+    const int b = blockIdx.z;
+    const int i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= W) return;
+    const int k = i * W + j;
     const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
     const float* __restrict__ f = flux + (int64_t)b * Hh * W;
-    const int i = k / W, j = k % W;
     const float ix = m.ix(j), iy = m.iy(i);
     const float x0f = floorf(ix), y0f = floorf(iy);
     const float tx = ix - x0f, ty = iy - y0f;
@@ -198,21 +199,12 @@ __device__ __forceinline__ float gather_rows(const CropMap& m, const float* __re
     return acc;
 }
 
-// One thread per INPUT pixel: direct part = sum over the output pixels that sampled it (the map is separable and
-// monotone, so they form a small index rectangle), plus the part through the centre of mass.
-__global__ __launch_bounds__(kFluxBlock) void flux_crop_bwd_kernel(const float* __restrict__ dims,
-                                                                   const float* __restrict__ com,
-                                                                   const float* __restrict__ gcom,
-                                                                   const float* __restrict__ grad_out, int Hh, int W,
-                                                                   float crop_w, float crop_h,
-                                                                   float* __restrict__ grad_flux)
+// Gradient of one INPUT pixel (x, y): direct part = sum over the output pixels that sampled it (the map is separable
+// and monotone, so they form a small index rectangle), plus the part through the centre of mass.  General form, any
+// crop scale; the tiled kernel below uses it for bitmaps whose scale needs more than four taps per axis.
+__device__ __forceinline__ float crop_bwd_pixel(const CropMap& m, const float* __restrict__ g, const float* __restrict__ com,
+                                                const float* __restrict__ gcom, int b, int Hh, int W, int x, int y)
 {
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= Hh * W) return;
-    const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
-    const float* __restrict__ g = grad_out + (int64_t)b * Hh * W;
-    const int y = k / W, x = k % W;
     // ix(j) = sx (j - (W-1)/2) + (xc + 1)(W-1)/2 up to rounding (<< 1e-3 pixel for bitmaps up to 32768 wide):
     // candidates j with |ix(j) - x| < 1 + 4e-3; tap() decides exactly
     int j0 = 0, j1 = W - 1, i0 = 0, i1 = Hh - 1;
@@ -242,8 +234,100 @@ __global__ __launch_bounds__(kFluxBlock) void flux_crop_bwd_kernel(const float* 
         }
     }
     const float S = com[3 * b + 2];
-    acc += gcom[2 * b] * (lin11(x, W) - m.xc) / S + gcom[2 * b + 1] * (lin11(y, Hh) - m.yc) / S;
-    grad_flux[(int64_t)b * Hh * W + k] = acc;
+    return acc + gcom[2 * b] * (lin11(x, W) - m.xc) / S + gcom[2 * b + 1] * (lin11(y, Hh) - m.yc) / S;
+}
+
+// Candidate output indices whose sampling coordinate can lie within one pixel of input index `p` (see above).
+__device__ __forceinline__ void tap_range(float scale, float centre, int n, int p, int& lo_i, int& hi_i)
+{
+    lo_i = 0; hi_i = n - 1;
+    if (scale > 1e-6f && scale < 1e6f) {
+        const float b = (centre + 1.0f) * 0.5f * (float)(n - 1) - scale * 0.5f * (float)(n - 1);
+        const float lo = ((float)p - 1.004f - b) / scale, hi = ((float)p + 1.004f - b) / scale;
+        if (lo > -2.0e9f && lo < 2.0e9f && hi > -2.0e9f && hi < 2.0e9f) { lo_i = max(0, (int)ceilf(lo)); hi_i = min(n - 1, (int)floorf(hi)); }
+    }
+}
+
+// The same gradient organised by tiles of 64 x 16 input pixels: the map is separable, so the
+// first output index and the (at most four) weights of a column are shared by the 16 pixels of that column and those
+// of a row by its 64 pixels - they are computed once per tile into LDS - and the sum factorises into a horizontal
+// pass (4 global loads per output row and column, kept in LDS) and a vertical pass (4 LDS reads per pixel).  A bitmap
+// whose crop scale needs more than four taps per axis (scale < ~0.6) takes the per-pixel form.
+constexpr int kTileX = 64, kTileY = 16, kTaps = 4, kTileRows = 32;
+__global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* __restrict__ dims, const float* __restrict__ com,
+                                                                  const float* __restrict__ gcom,
+                                                                  const float* __restrict__ grad_out, int Hh, int W,
+                                                                  float crop_w, float crop_h, float* __restrict__ grad_flux)
+{
+    __shared__ int s_j0[kTileX], s_i0[kTileY];
+    __shared__ float s_wx[kTileX][kTaps], s_wy[kTileY][kTaps];
+    __shared__ float s_t[kTileRows][kTileX];        // horizontal pass: T[i][x] = sum_q wx[x][q] g[i][j0(x) + q]
+    __shared__ int s_wide, s_ilo, s_ihi;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * kTileX, y0 = blockIdx.y * kTileY;
+    const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
+    if (threadIdx.x == 0) { s_wide = 0; s_ilo = 0x7fffffff; s_ihi = -1; }
+    __syncthreads();
+    if (threadIdx.x < kTileX + kTileY) {
+        const bool col = threadIdx.x < kTileX;
+        const int t = col ? threadIdx.x : threadIdx.x - kTileX;
+        const int p = col ? x0 + t : y0 + t;
+        const int n = col ? W : Hh;
+        int lo_i = 0, hi_i = -1;
+        if (p < n) tap_range(col ? m.sx : m.sy, col ? m.xc : m.yc, n, p, lo_i, hi_i);
+        if (hi_i - lo_i >= kTaps) s_wide = 1;
+        (col ? s_j0 : s_i0)[t] = lo_i;
+        for (int q = 0; q < kTaps; ++q) {
+            const int o = lo_i + q;
+            (col ? s_wx[t] : s_wy[t])[q] = o <= hi_i ? tap(col ? m.ix(o) : m.iy(o), p) : 0.0f;
+        }
+        if (!col && hi_i >= lo_i) { atomicMin(&s_ilo, lo_i); atomicMax(&s_ihi, hi_i); }
+    }
+    __syncthreads();
+    const int ilo = s_ilo, ihi = s_ihi;
+    const float* __restrict__ g = grad_out + (int64_t)b * Hh * W;
+    if (s_wide || ihi - ilo >= kTileRows) {    // strong magnification: per-pixel form for this tile
+        for (int k = threadIdx.x; k < kTileX * kTileY; k += 256) {
+            const int x = x0 + (k & (kTileX - 1)), y = y0 + k / kTileX;
+            if (x < W && y < Hh) grad_flux[((int64_t)b * Hh + y) * W + x] = crop_bwd_pixel(m, g, com, gcom, b, Hh, W, x, y);
+        }
+        return;
+    }
+    const int tx = threadIdx.x & (kTileX - 1);
+    const int x = x0 + tx;
+    const bool in_x = x < W;
+    const int j0 = s_j0[tx];
+    const float wx0 = s_wx[tx][0], wx1 = s_wx[tx][1], wx2 = s_wx[tx][2], wx3 = s_wx[tx][3];
+    const int c0 = min(j0, W - 1), c1 = min(j0 + 1, W - 1), c2 = min(j0 + 2, W - 1), c3 = min(j0 + 3, W - 1);   // weight 0 there
+    // horizontal pass over the output rows this tile's input rows sampled from
+    for (int r = threadIdx.x / kTileX; r <= ihi - ilo; r += 256 / kTileX) {
+        float v = 0.0f;
+        if (in_x) {
+            const float* __restrict__ row = g + (int64_t)(ilo + r) * W;
+            if (wx0 != 0.0f) v += row[c0] * wx0;
+            if (wx1 != 0.0f) v += row[c1] * wx1;
+            if (wx2 != 0.0f) v += row[c2] * wx2;
+            if (wx3 != 0.0f) v += row[c3] * wx3;
+        }
+        s_t[r][tx] = v;
+    }
+    __syncthreads();
+    if (!in_x) return;
+    const float S = com[3 * b + 2];
+    const float gx = gcom[2 * b] * (lin11(x, W) - m.xc) / S, gyc = gcom[2 * b + 1];
+    for (int ty = threadIdx.x / kTileX; ty < kTileY; ty += 256 / kTileX) {
+        const int y = y0 + ty;
+        if (y >= Hh) break;
+        const int r0 = s_i0[ty] - ilo;
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < kTaps; ++a) {
+            const float wy = s_wy[ty][a];
+            if (wy != 0.0f) acc += s_t[r0 + a][tx] * wy;      // uniform across the 64 lanes of a row
+        }
+        acc += gx + gyc * (lin11(y, Hh) - m.yc) / S;
+        grad_flux[((int64_t)b * Hh + y) * W + x] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -304,7 +388,7 @@ using namespace art;
 
 static bool crop_args_ok(const void* a, const void* b, const void* c, const void* d, int64_t B, int64_t Hh, int64_t W)
 {
-    return a && b && c && d && B >= 0 && Hh >= 1 && W >= 1 && Hh * W <= (int64_t)1 << 30 && B <= 65535;
+    return a && b && c && d && B >= 0 && Hh >= 1 && W >= 1 && Hh <= 65535 && Hh * W <= (int64_t)1 << 30 && B <= 65535;
 }
 
 extern "C" int art_flux_crop_fwd(const float* flux, const float* target_dims, int64_t B, int64_t Hh, int64_t W,
@@ -314,7 +398,7 @@ extern "C" int art_flux_crop_fwd(const float* flux, const float* target_dims, in
     if (!crop_args_ok(flux, target_dims, out, centers, B, Hh, W)) return ART_EINVAL;
     if (B == 0) return ART_OK;
     hipLaunchKernelGGL(flux_com_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, (int)Hh, (int)W, centers);
-    hipLaunchKernelGGL(flux_crop_fwd_kernel, dim3((unsigned)((Hh * W + kFluxBlock - 1) / kFluxBlock), (unsigned)B),
+    hipLaunchKernelGGL(flux_crop_fwd_kernel, dim3((unsigned)((W + kFluxBlock - 1) / kFluxBlock), (unsigned)Hh, (unsigned)B),
                        dim3(kFluxBlock), 0, stream, flux, target_dims, centers, (int)Hh, (int)W, (float)crop_width,
                        (float)crop_height, out);
     ART_HIP(hipGetLastError());
@@ -330,8 +414,9 @@ extern "C" int art_flux_crop_bwd(const float* flux, const float* target_dims, co
     if (B == 0) return ART_OK;
     hipLaunchKernelGGL(flux_crop_bwd_com_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims, centers,
                        grad_out, (int)Hh, (int)W, (float)crop_width, (float)crop_height, workspace);
-    hipLaunchKernelGGL(flux_crop_bwd_kernel, dim3((unsigned)((Hh * W + kFluxBlock - 1) / kFluxBlock), (unsigned)B),
-                       dim3(kFluxBlock), 0, stream, target_dims, centers, workspace, grad_out, (int)Hh, (int)W,
+    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel,
+                       dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),
+                       dim3(256), 0, stream, target_dims, centers, workspace, grad_out, (int)Hh, (int)W,
                        (float)crop_width, (float)crop_height, grad_flux);
     ART_HIP(hipGetLastError());
     return ART_OK;

@@ -58,7 +58,7 @@ class FluxCrop(torch.autograd.Function):
         B, Hh, W = flux.shape
         grad_out = _f32c(grad_out)
         grad_flux = torch.empty_like(flux)
-        workspace = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        workspace = torch.empty((B, 3), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().art_flux_crop_bwd(flux.data_ptr(), dims.data_ptr(), centers.data_ptr(), B, Hh, W, *ctx.crop,
                                               grad_out.data_ptr(), grad_flux.data_ptr(), workspace.data_ptr(),

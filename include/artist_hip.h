@@ -196,7 +196,7 @@ int art_align_bwd(const float *points, const float *normals, const float *orient
  *   dimensions, or radius x opening angle and height for cylinders (the gather of :183-216 is host logic);
  *   out [B,Hh,W]; centers [B,3] out = (x centre, y centre, sum + 1e-8), needed by the backward.
  * art_flux_crop_bwd - its autograd w.r.t. flux: the sampled values (as a gather: deterministic) and the path
- * through the centre of mass (grid_sample's grid gradient).  workspace: 2 B floats.
+ * XX
  * ------------------------------------------------------------------------------------------- */
 int art_flux_crop_fwd(const float *flux, const float *target_dims, int64_t B, int64_t Hh, int64_t W,
                       double crop_width, double crop_height, float *out, float *centers, void *stream);

@@ -30,7 +30,7 @@ cy = 128 + 40 * torch.rand(B, 1, 1, device=dev, generator=g) - 20
 flux = torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * 18.0 ** 2)).contiguous()
 dims = torch.full((B, 2), 8.0, device=dev)
 out, com = torch.empty_like(flux), torch.empty(B, 3, device=dev)
-gout, gflux, ws = torch.rand_like(flux), torch.empty_like(flux), torch.empty(B, 2, device=dev)
+gout, gflux, ws = torch.rand_like(flux), torch.empty_like(flux), torch.empty(B, 3, device=dev)
 truth, loss, gl, gp = torch.rand_like(flux) + 0.1, torch.empty(B, device=dev), torch.ones(B, device=dev), torch.empty_like(flux)
 lib, s = _lib.lib(), torch.cuda.current_stream().cuda_stream
 p = lambda t: t.data_ptr()
