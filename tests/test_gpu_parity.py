@@ -1023,3 +1023,28 @@ def test_random_scenes_all_features(seed, H, P, R, res, interleaved, lbvh_compat
     assert rel_l2(n(nn_.grad), gn) < 3e-3, rel_l2(n(nn_.grad), gn)
     if np.linalg.norm(gpc) > 0:
         assert rel_l2(n(prims["corners"].grad), gpc) < 3e-3, rel_l2(n(prims["corners"].grad), gpc)
+
+
+@pytest.mark.parametrize("res", [(700, 40), (40, 700), (2, 2), (3, 1500)])
+def test_extreme_bitmap_shapes(golden, res):
+    """Very wide / very tall / minimal bitmaps: windows wider than half the LDS capacity, multi-pass row bands, and
+    the 2 x 2 bitmap whose only cell quadruple is (0,0)-(1,1)."""
+    from artist_amd import trace_rays
+    d = golden("mid_256")
+    inp = trace_inputs(d)
+    inp["resolution"] = res
+    inp["origins"].requires_grad_(True)
+    flux, fac = trace_rays(**inp)
+    dd = dict(d, resolution=np.asarray(res))
+    o_flux, o_fac = oracle_fwd(dd)
+    assert flux.shape == (d["aligned_points"].shape[0], res[1], res[0])
+    assert rel_l2(n(flux), o_flux) < 2e-4 or float(np.abs(o_flux).max()) == 0, rel_l2(n(flux), o_flux)
+    np.testing.assert_array_equal(n(fac), o_fac)
+    w = torch.linspace(0.5, 1.5, res[0] * res[1], device=DEV).reshape(res[1], res[0])
+    (flux * w).sum().backward()
+    go, _ = oracle.trace_bwd(d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"], d["distortions_e"],
+                             d["target_idx"], d["target_centers"], d["target_normals"], d["target_dims"], res,
+                             np.broadcast_to(n(w), o_flux.shape).copy(), float(d["ray_magnitude"]), float(d["extinction"]),
+                             float(d["reflectivity"]))
+    if np.linalg.norm(go) > 0:
+        assert rel_l2(n(inp["origins"].grad), go) < 5e-3, rel_l2(n(inp["origins"].grad), go)
