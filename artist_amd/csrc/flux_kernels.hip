@@ -333,6 +333,24 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
 // ---------------------------------------------------------------------------------------------------
 // Losses: one workgroup per sample.  mode 0 = PixelLoss, 1 = KLDivergenceLoss.
 // ---------------------------------------------------------------------------------------------------
+// Element loop over one sample with four elements per load when the sample is 16-byte aligned: fewer, wider loads
+// in flight per thread (a sample is streamed by ONE workgroup, so the loop is latency-bound when B is small).
+template <typename F>
+__device__ __forceinline__ void for_each_pair(const float* __restrict__ p, const float* __restrict__ g, int64_t npix, F&& f)
+{
+    const bool vec = (npix & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    if (vec) {
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+        for (int64_t k = threadIdx.x; k < (npix >> 2); k += blockDim.x) {
+            const float4 a = p4[k], c = g4[k];
+            f(4 * k, a.x, c.x); f(4 * k + 1, a.y, c.y); f(4 * k + 2, a.z, c.z); f(4 * k + 3, a.w, c.w);
+        }
+    } else {
+        for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) f(k, p[k], g[k]);
+    }
+}
+
 __global__ __launch_bounds__(kReduceBlock) void flux_loss_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
                                                                int64_t npix, int mode, float* __restrict__ loss,
                                                                const float* __restrict__ grad_loss,
@@ -345,40 +363,40 @@ __global__ __launch_bounds__(kReduceBlock) void flux_loss_kernel(const float* __
     float* __restrict__ gp = grad_pred ? grad_pred + (int64_t)b * npix : nullptr;
     if (mode == 0) {                                           // loss.py:312-318
         double se = 0.0, sg = 0.0;
-        for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) { const float d = p[k] - g[k]; se += (double)(d * d); sg += (double)g[k]; }
+        for_each_pair(p, g, npix, [&](int64_t, float pk, float gk) { const float d = pk - gk; se += (double)(d * d); sg += (double)gk; });
         se = block_sum(se, s_red);
         const float sgf = (float)block_sum(sg, s_red);
         if (threadIdx.x == 0 && loss) loss[b] = (float)se / sgf;
         if (gp) {
             const float gl = grad_loss[b];
-            for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) gp[k] = gl * (2.0f * (p[k] - g[k])) / sgf;
+            for_each_pair(p, g, npix, [&](int64_t k, float pk, float gk) { gp[k] = gl * (2.0f * (pk - gk)) / sgf; });
         }
         return;
     }
     const float eps = 1e-12f;                                  // loss.py:385-410
     double np_ = 0.0, ng = 0.0;
-    for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) { np_ += (double)fabsf(p[k]); ng += (double)fabsf(g[k]); }
+    for_each_pair(p, g, npix, [&](int64_t, float pk, float gk) { np_ += (double)fabsf(pk); ng += (double)fabsf(gk); });
     const float npf = (float)block_sum(np_, s_red), ngf = (float)block_sum(ng, s_red);
     const float dp = fmaxf(npf, eps), dg = fmaxf(ngf, eps);
     double acc = 0.0, dot = 0.0;
-    for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) {
-        const float t = logf(g[k] / dg + eps), q = logf(p[k] / dp + eps);
+    for_each_pair(p, g, npix, [&](int64_t, float pk, float gk) {
+        const float t = logf(gk / dg + eps), q = logf(pk / dp + eps);
         const float et = expf(t);
         acc += (double)(et * (t - q));
-        dot += (double)((-et / (p[k] / dp + eps)) * p[k]);
-    }
+        dot += (double)((-et / (pk / dp + eps)) * pk);
+    });
     acc = block_sum(acc, s_red);
     const float dotf = (float)block_sum(dot, s_red);
     if (threadIdx.x == 0 && loss) loss[b] = (float)acc;
     if (gp) {
         const float gl = grad_loss[b];
-        for (int64_t k = threadIdx.x; k < npix; k += blockDim.x) {
-            const float t = logf(g[k] / dg + eps);
-            const float a = -expf(t) / (p[k] / dp + eps);
-            const float sgn = p[k] > 0.0f ? 1.0f : (p[k] < 0.0f ? -1.0f : 0.0f);
+        for_each_pair(p, g, npix, [&](int64_t k, float pk, float gk) {
+            const float t = logf(gk / dg + eps);
+            const float a = -expf(t) / (pk / dp + eps);
+            const float sgn = pk > 0.0f ? 1.0f : (pk < 0.0f ? -1.0f : 0.0f);
             const float through_norm = npf > eps ? sgn * dotf / (dp * dp) : 0.0f;
             gp[k] = gl * (a / dp - through_norm);
-        }
+        });
     }
 }
 
