@@ -510,6 +510,69 @@ REAL_CASES = {
 }
 
 
+def save_interop_check():
+    """Duck-typing check of the drop-in classes against the REFERENCE's own objects (no kernel runs: there is no GPU
+    here): ``artist_amd.HeliostatRayTracer`` is constructed on ARTIST's ``Scenario`` / ``HeliostatGroupRigidBody``
+    loaded from its own HDF5 file, and every host-side helper that reads ARTIST attributes is called on them.  The
+    result (what was checked, sizes seen) is stored as tests/golden/interop_check.json."""
+    import json
+
+    import h5py
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
+    import artist_amd
+    from artist_amd import flux as amd_flux
+    from artist_amd import raytracing as amd_rt
+    from artist_amd.blocking import create_blocking_primitives_rectangles_by_index
+
+    torch.manual_seed(7)
+    with h5py.File(pathlib.Path(REFERENCE) / "tests/data/scenarios/test_blocking.h5", "r") as scenario_file:
+        scenario = Scenario.load_scenario_from_hdf5(scenario_file=scenario_file,
+                                                    number_of_surface_points_per_facet=torch.tensor([10, 10]), device=CPU)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    mapping = [(f"heliostat_{i}", "target_0", torch.tensor([0.0, 1.0, 0.0, 0.0])) for i in range(6)]
+    mask, target_idx, incident = scenario.index_mapping(heliostat_group=group, string_mapping=mapping, device=CPU)
+    group.activate_heliostats(active_heliostats_mask=mask, device=CPU)
+    group.align_surfaces_with_incident_ray_directions(
+        aim_points=scenario.solar_tower.get_centers_of_target_areas(target_area_indices=target_idx, device=CPU),
+        incident_ray_directions=incident, active_heliostats_mask=mask, device=CPU)
+    scenario.set_number_of_rays(number_of_rays=3)
+    ours = artist_amd.HeliostatRayTracer(scenario=scenario, heliostat_group=group, blocking_active=True, batch_size=10,
+                                         bitmap_resolution=torch.tensor([64, 64]))
+    theirs = HeliostatRayTracer(scenario=scenario, heliostat_group=group, blocking_active=True, batch_size=10,
+                                bitmap_resolution=torch.tensor([64, 64]))
+    checks = {}
+    checks["blocking_surfaces_equal"] = bool(torch.equal(ours.blocking_heliostat_surfaces_active,
+                                                         theirs.blocking_heliostat_surfaces_active))
+    checks["distortions_equal"] = bool(torch.equal(ours.distortions_dataset.distortions_u, theirs.distortions_dataset.distortions_u)
+                                       and torch.equal(ours.distortions_dataset.distortions_e, theirs.distortions_dataset.distortions_e))
+    checks["sampler_indices_equal"] = ours.get_sampler_indices().tolist() == theirs.get_sampler_indices().tolist()
+    checks["ray_magnitude_equal"] = float(ours.ray_magnitude) == float(theirs.ray_magnitude)
+    planar = amd_rt._planar_tables(scenario.solar_tower, CPU)
+    cyl = amd_rt._cylinder_tables(scenario.solar_tower)
+    checks["planar_tables"] = [list(t.shape) for t in planar]
+    checks["cylinder_tables"] = [list(t.shape) for t in cyl]
+    ref_prims = ref_blocking.create_blocking_primitives_rectangles_by_index(theirs.blocking_heliostat_surfaces_active, device=CPU)
+    our_prims = create_blocking_primitives_rectangles_by_index(ours.blocking_heliostat_surfaces_active)
+    checks["primitives_max_abs_diff"] = float(max((a - b).abs().max() for a, b in zip(ref_prims, our_prims)))
+    tix_all = torch.tensor([0, 4, 5, 10])           # planar 0 and 4, cylinders 0 and 5
+    dims = amd_flux.target_dimensions(scenario.solar_tower, tix_all)
+    checks["target_dimensions"] = dims.tolist()
+    corners, _, _, owner, max_angle, compat = ours._blocking_arguments(None, mask)
+    checks["owner"] = owner.tolist()
+    checks["max_scatter_angle"] = max_angle
+    with torch.no_grad():
+        try:
+            ours.trace_rays(incident, mask, target_idx)
+            checks["cpu_trace"] = "unexpectedly ran"
+        except artist_amd.ArtistHipError as exc:       # the product has no CPU path: must fail loudly
+            checks["cpu_trace"] = f"ArtistHipError: {exc}"[:120]
+    assert checks["blocking_surfaces_equal"] and checks["distortions_equal"] and checks["sampler_indices_equal"]
+    assert checks["primitives_max_abs_diff"] < 1e-6 and "no CPU fallback" in checks["cpu_trace"]
+    path = OUT_DIR / "interop_check.json"
+    path.write_text(json.dumps(checks, indent=1))
+    print(f"wrote {path.name}: {checks}")
+
+
 def save(name, arrays):
     path = OUT_DIR / f"{name}.npz"
     np.savez_compressed(path, **arrays)
@@ -863,6 +926,8 @@ def main():
         save(name, arrs32)
         arrs64, _ = run_scenario_file(dtype=torch.float64, distortions_f32=dist, **case)
         save(name + "_f64", arrs64)
+    if only is None or "interop" in only:
+        save_interop_check()
     # config 1 / config 2: inputs regenerate from the recipe (seeded torch CPU RNG); store outputs only.
     keep = {"flux", "intercept", "on_target", "blocking", "per_target", "control_points", "orientation",
             "aligned_points", "aligned_normals", "incident", "target_idx", "target_centers", "target_normals",
