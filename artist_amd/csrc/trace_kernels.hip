@@ -7,8 +7,10 @@
 // consecutive points of the same sample r).
 //
 // Replaces (ARTIST v2.0.0): heliostat_ray_tracer.py:285-290 (reflect), :328-335 + :510-561
-// (scatter_rays), :390-409 (line_plane_intersections), :482-487 (intensities), :489-494 +
-// :610-778 (bilinear_splatting), :498-506 (factors), :563-608 (per-target sums, mode 1).
+// (scatter_rays), :390-409 (line_plane_intersections), :411-433 + geometry.py:207-445 (cylindrical
+// receivers, template parameter CYL), :435-480 + blocking.py:212-354 (soft blocking mask over the
+// rectangles art_blocking_filter selected, template parameter BLOCKING), :482-487 (intensities),
+// :489-494 + :610-778 (bilinear_splatting), :498-506 (factors), :563-608 (per-target sums, mode 1).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
