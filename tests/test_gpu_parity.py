@@ -934,7 +934,7 @@ def test_real_scenarios(golden, name):
 # Randomised scenes: every feature at once (planar + cylindrical areas, blocking rectangles, ragged sizes, sample
 # counts above the 4-ray groups and the 128-sample range), HIP vs the CPU oracle on the same inputs.
 # ---------------------------------------------------------------------------------------------
-def _random_scene(seed, H, P, R):
+def _random_feature_scene(seed, H, P, R):
     g = torch.Generator().manual_seed(seed)
     rnd = lambda *shape: torch.rand(shape, generator=g)
     centre = torch.tensor([0.0, 0.0, 40.0])
@@ -988,7 +988,7 @@ def _random_scene(seed, H, P, R):
                           (2, 7, 64, 5, (48, 48), True, True), (3, 3, 1100, 9, (128, 96), True, False)])
 def test_random_scenes_all_features(seed, H, P, R, res, interleaved, lbvh_compat):
     from artist_amd import per_target_sum, trace_rays
-    sc = _random_scene(seed, H, P, R)
+    sc = _random_feature_scene(seed, H, P, R)
     dv = lambda x: x.to(DEV)
     both = dv(sc["both"])
     du, de = (both[..., 0], both[..., 1]) if interleaved else (both[..., 0].contiguous(), both[..., 1].contiguous())
