@@ -873,8 +873,11 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
                 mask_adjoint();
                 return;
             }
-            const float I = use ? (((pl.mag * (-ah)) * keep) * pl.k_ext) * pl.k_refl : 0.0f;
+            // The gradient arithmetic is not tied to the reference's operation order (it is compared with a tolerance,
+            // like autograd's own reassociations): intensity in one multiply, and the origin gradient kept as three
+            // running sums (hit-point x, hit-point z, plane offset) that are combined once per point.
             const float kIm = use ? kI * keep : 0.0f;
+            const float I = -(kIm * ah);                                      // mag (-a) keep k_ext k_refl
             {
 #pragma clang fp contract(fast)
                 const float gI = cle * (chu * g1 + clu * g4) + che * (chu * g2 + clu * g3);
@@ -889,9 +892,9 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
                 const float grx = g_hx * tt + g_a * pl.mx;
                 const float gry = g_a * pl.my;
                 const float grz = g_hz * tt + g_a * pl.mz;
-                gox += g_hx - g_numer * pl.mx;
-                goy -= g_numer * pl.my;
-                goz += g_hz - g_numer * pl.mz;
+                gox += g_hx;                     // (planar: gox / goz / goy hold sum g_hx / sum g_hz / sum g_numer)
+                goz += g_hz;
+                goy += g_numer;
                 gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
                 gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
                 gdz += m.ce * grz - m.se * gry;
@@ -937,6 +940,9 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
             const float wy = gox * cy.r01 + goy * cy.r11 + goz * cy.r21;
             const float wz = gox * cy.r02 + goy * cy.r12 + goz * cy.r22;
             gox = wx; goy = wy; goz = wz;
+        } else {               // hit = o + t r, t = (c - o).m / (r.m): dL/do = (g_hx, 0, g_hz) - m * sum g_numer
+            const float sn = goy;
+            gox = gox - sn * pl.mx; goy = -(sn * pl.my); goz = goz - sn * pl.mz;
         }
         if constexpr (BLOCKING) { gox += bgx; goy += bgy; goz += bgz; }
         const float4 go = make_float4(gox, goy, goz, 0.0f);
