@@ -3,7 +3,7 @@
 
 usage: python tools/make_profiles.py <tag>      (after `bash tools/prof_pass.sh <tag>` and `bash tools/pmc_hbm.sh <tag>`
                                                  ran on the GPU box and gpurun merged their output back)
-  gpurun_out/prof_<tag>/**/_kernel_stats.csv                 -> profiles/r01_kernel_stats_bench_H1000_steps3.csv
+  gpurun_out/prof_<tag>/**/_kernel_stats.csv                 -> profiles/r01_kernel_stats_bench_default.csv
   gpurun_out/hbm_<tag>_{FETCH_SIZE,WRITE_SIZE,...}/**/*.csv  -> profiles/r01_hbm_traffic.json (bytes per launch)
 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts TCC_EA0_RDREQ x 64 B while the requests are 128 B, so it
 is doubled (MI355X_MICROARCH.md, HBM section) and cross-checked against TCC_EA0_RDREQ_sum x 128 B.
@@ -14,7 +14,7 @@ tag = sys.argv[1]
 root = pathlib.Path(__file__).resolve().parent.parent
 stats = sorted(glob.glob(str(root / f"gpurun_out/prof_{tag}/*/*_kernel_stats.csv")))
 if stats:
-    shutil.copy(stats[-1], root / "profiles/r01_kernel_stats_bench_H1000_steps3.csv")
+    shutil.copy(stats[-1], root / "profiles/r01_kernel_stats_bench_default.csv")
     print("kernel stats <-", stats[-1])
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(str(root / f"gpurun_out/hbm_{tag}_*/*/*_counter_collection.csv")):
