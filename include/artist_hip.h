@@ -213,6 +213,35 @@ int art_flux_crop_bwd(const float *flux, const float *target_dims, const float *
 int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B, int64_t npix, int kind,
                   float *loss, const float *grad_loss, float *grad_prediction, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * art_rigid_body_fwd - RigidBody kinematics of H heliostats in one launch
+ * (artist/field/kinematics_rigid_body.py:194-634 with artist/field/actuators_ideal.py:66-111 and
+ * actuators_linear.py:79-370).
+ *   mode 0 = motor_positions_to_orientations (:510-538): orientations from the given motor_positions [H,2];
+ *   mode 1 = incident_ray_directions_to_orientations (:540-634): the fixed-point iteration from motor positions
+ *            0, at most max_iter evaluations, stopped when EVERY heliostat's loss moved by <= min_eps;
+ *            motor_positions [H,2] receives the final motor positions (RigidBody.active_motor_positions).
+ *   positions [H,4]; rot_dev [H,4]; trans_dev [H,9]; act_nonopt [H,act_rows,2] with act_rows 4 (ideal) or
+ *   7 (linear: + increment, offset, pivot radius); act_opt [H,2,2] (linear; NULL for ideal);
+ *   offsets [4,4] = RigidBody.initial_orientation_offsets; incident, aim [H,4] (mode 1; may be NULL in mode 0).
+ *   orientations [H,4,4] out (already multiplied by offsets); scratch [H] floats; evaluations [1] int32 out =
+ *   number of forward-kinematics evaluations made (what the backward replays).
+ * art_rigid_body_bwd - its autograd w.r.t. rot_dev, trans_dev and act_opt by forward-mode differentiation of the
+ *   same chain (the gradients torch.autograd gives the reference): grad_orientations [H,4,4] in;
+ *   grad_rot_dev [H,4], grad_trans_dev [H,9], grad_act_opt [H,2,2] (NULL for ideal actuators) out, fully written.
+ *   motor_positions is the forward's input in mode 0 and ignored in mode 1; evaluations as written by the forward.
+ * ------------------------------------------------------------------------------------------- */
+int art_rigid_body_fwd(int mode, const float *positions, const float *rot_dev, const float *trans_dev,
+                       const float *act_nonopt, int64_t act_rows, const float *act_opt, const float *offsets,
+                       const float *incident, const float *aim, int64_t H, int max_iter, double min_eps,
+                       float *motor_positions, float *orientations, float *scratch, int32_t *evaluations,
+                       void *stream);
+int art_rigid_body_bwd(int mode, const float *positions, const float *rot_dev, const float *trans_dev,
+                       const float *act_nonopt, int64_t act_rows, const float *act_opt, const float *offsets,
+                       const float *incident, const float *aim, int64_t H, const float *motor_positions,
+                       const int32_t *evaluations, const float *grad_orientations, float *grad_rot_dev,
+                       float *grad_trans_dev, float *grad_act_opt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

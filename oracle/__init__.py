@@ -253,6 +253,29 @@ def kl_loss(pred, truth, grad_loss=None):
     return _loss("orc_kl_loss", pred, truth, grad_loss)
 
 
+def rigid_body_orientations(positions, rot_dev, trans_dev, act_nonopt, act_opt, offsets, incident=None, aim=None,
+                            motor_positions=None, max_iter=4, min_eps=1e-4):
+    """RigidBody.incident_ray_directions_to_orientations (artist/field/kinematics_rigid_body.py:540-634) when
+    ``incident``/``aim`` are given, ``motor_positions_to_orientations`` (:510-538) when ``motor_positions`` are.
+    Returns (orientations [H,4,4], motor positions [H,2], number of forward evaluations)."""
+    dt = positions.dtype
+    pos, rd, td, an = _c(positions, dt), _c(rot_dev, dt), _c(trans_dev, dt), _c(act_nonopt, dt)
+    H, rows = pos.shape[0], an.shape[1]
+    ao = _c(act_opt, dt) if act_opt is not None and np.size(act_opt) else None
+    off = _c(offsets, dt)
+    mode = 0 if motor_positions is not None else 1
+    motor = _c(motor_positions, dt).copy() if mode == 0 else np.zeros((H, 2), dt)
+    inc = _c(incident, dt) if mode == 1 else None
+    aimc = _c(aim, dt) if mode == 1 else None
+    ori = np.empty((H, 4, 4), dt)
+    rc = getattr(lib(), "orc_rigid_body" + _sfx(dt))(
+        ctypes.c_int(mode), _p(pos), _p(rd), _p(td), _p(an), _i64(rows), _p(ao), _p(off), _p(inc), _p(aimc), _i64(H),
+        ctypes.c_int(max_iter), _dbl(min_eps), _p(ori), _p(motor))
+    if rc < 0:
+        _check(rc, "rigid_body")
+    return ori, motor, rc
+
+
 def blocking_tables(d, H=None):
     """The blocking tables of a golden fixture as the ``blocking=`` argument (one group, every heliostat active:
     heliostat h owns primitive h)."""

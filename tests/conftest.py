@@ -38,6 +38,15 @@ def golden():
     return load
 
 
+KINEMATICS_CASES = ["blocking", "paint"]              # linear actuators (6 heliostats) / ideal actuators (2)
+
+
+def kinematics_case(d, tag, sfx):
+    """The rigid-body fixture `kin_<tag>_<sfx>_*` of tests/golden/kinematics.npz as a dict without the prefix."""
+    pre = f"kin_{tag}_{sfx}_"
+    return {k[len(pre):]: v for k, v in d.items() if k.startswith(pre)}
+
+
 STAGE_CASES = ["small_deg3", "small_deg2_tilted", "small_offtarget", "mid_256"]
 BLOCKING_CASES = ["small_blocking", "mid_blocking"]   # blocking_active=True (artist/raytracing/blocking.py)
 # the reference's own scenario files (tests/data/scenarios/*.h5) through its loader, kinematics and ray tracer

@@ -510,6 +510,72 @@ REAL_CASES = {
 }
 
 
+def kinematics_fixture():
+    """Rigid-body kinematics of the reference (kinematics_rigid_body.py:194-634) on its own scenario files - linear
+    actuators with fitted parameters, real deviation parameters: orientation matrices, motor positions and the
+    Jacobians of the orientations w.r.t. the rotation / translation deviations and the optimisable actuator parameters
+    (torch.autograd.functional.jacobian), in fp32 and fp64; plus the calibration path (orientations from given motor
+    positions)."""
+    import h5py
+    out = {}
+    cases = [("blocking", "test_blocking.h5", [f"heliostat_{i}" for i in range(6)], "target_0", [0.0, 1.0, 0.0, 0.0]),
+             ("paint", "test_scenario_paint_four_heliostats.h5", ["AA28", "AA31", "AA39", "AC43"], "receiver", [0.2, 0.9, -0.39, 0.0])]
+    for tag, filename, names, target, sun in cases:
+        for dtype, sfx in ((torch.float32, "f32"), (torch.float64, "f64")):
+            torch.set_default_dtype(dtype)
+            with h5py.File(pathlib.Path(REFERENCE) / "tests/data/scenarios" / filename, "r") as scenario_file:
+                scenario = Scenario.load_scenario_from_hdf5(
+                    scenario_file=scenario_file, number_of_surface_points_per_facet=torch.tensor([4, 4]), device=CPU)
+            group = scenario.heliostat_field.heliostat_groups[0]
+            kin = group.kinematics
+            mapping = [(n_, target, torch.nn.functional.normalize(torch.tensor(sun, dtype=dtype), dim=0)) for n_ in names]
+            mask, target_idx, incident = scenario.index_mapping(heliostat_group=group, string_mapping=mapping, device=CPU)
+            group.activate_heliostats(active_heliostats_mask=mask, device=CPU)
+            aim = scenario.solar_tower.get_centers_of_target_areas(target_area_indices=target_idx, device=CPU).to(dtype)
+            incident = incident.to(dtype)
+            # cast every parameter tensor of the kinematics to the run's dtype (the loader builds float32 tensors)
+            for obj, attrs in ((kin, ["active_heliostat_positions", "active_rotation_deviation_parameters",
+                                      "active_translation_deviation_parameters", "initial_orientation_offsets",
+                                      "kinematics_standard_orientation", "homogeneous_origin"]),
+                               (kin.actuators, ["active_non_optimizable_parameters", "active_optimizable_parameters"])):
+                for a_ in attrs:
+                    setattr(obj, a_, getattr(obj, a_).detach().to(dtype))
+            rot0 = kin.active_rotation_deviation_parameters.clone()
+            trans0 = kin.active_translation_deviation_parameters.clone()
+            opt0 = kin.actuators.active_optimizable_parameters.clone()
+
+            def _ori(rot, trans, opt):
+                kin.active_rotation_deviation_parameters, kin.active_translation_deviation_parameters = rot, trans
+                kin.actuators.active_optimizable_parameters = opt
+                return kin.incident_ray_directions_to_orientations(incident_ray_directions=incident, aim_points=aim, device=CPU)
+
+            ori = _ori(rot0, trans0, opt0)
+            motor = kin.active_motor_positions.detach().clone()
+            has_opt = opt0.numel() > 0
+            if has_opt:
+                jr, jt, jo = torch.autograd.functional.jacobian(_ori, (rot0, trans0, opt0))
+            else:
+                jr, jt = torch.autograd.functional.jacobian(lambda r_, t_: _ori(r_, t_, opt0), (rot0, trans0))
+                jo = None
+            Hk = ori.shape[0]
+            hh = torch.arange(Hk)
+            kin.active_rotation_deviation_parameters, kin.active_translation_deviation_parameters = rot0, trans0
+            kin.actuators.active_optimizable_parameters = opt0
+            motor_given = motor + torch.arange(2 * Hk, dtype=dtype).reshape(Hk, 2) * (500.0 if has_opt else 0.01)
+            ori_motor = kin.motor_positions_to_orientations(motor_positions=motor_given, device=CPU)
+            pre = f"kin_{tag}_{sfx}_"
+            out.update({pre + "positions": npy(kin.active_heliostat_positions), pre + "rot_dev": npy(rot0),
+                        pre + "trans_dev": npy(trans0), pre + "act_nonopt": npy(kin.actuators.active_non_optimizable_parameters),
+                        pre + "act_opt": npy(opt0), pre + "offsets": npy(kin.initial_orientation_offsets[0]),
+                        pre + "incident": npy(incident), pre + "aim": npy(aim), pre + "orientation": npy(ori.detach()),
+                        pre + "motor": npy(motor), pre + "jac_rot": npy(jr[hh, :, :, hh]), pre + "jac_trans": npy(jt[hh, :, :, hh]),
+                        pre + "motor_given": npy(motor_given), pre + "orientation_from_motor": npy(ori_motor.detach())})
+            if jo is not None:
+                out[pre + "jac_opt"] = npy(jo[hh, :, :, hh])
+            torch.set_default_dtype(torch.float32)
+    save("kinematics", out)
+
+
 def save_interop_check():
     """Duck-typing check of the drop-in classes against the REFERENCE's own objects (no kernel runs: there is no GPU
     here): ``artist_amd.HeliostatRayTracer`` is constructed on ARTIST's ``Scenario`` / ``HeliostatGroupRigidBody``
@@ -928,6 +994,8 @@ def main():
         save(name + "_f64", arrs64)
     if only is None or "interop" in only:
         save_interop_check()
+    if only is None or "kinematics" in only:
+        kinematics_fixture()
     # config 1 / config 2: inputs regenerate from the recipe (seeded torch CPU RNG); store outputs only.
     keep = {"flux", "intercept", "on_target", "blocking", "per_target", "control_points", "orientation",
             "aligned_points", "aligned_normals", "incident", "target_idx", "target_centers", "target_normals",

@@ -10,7 +10,8 @@ import pytest
 import torch
 
 import oracle
-from conftest import BLOCKING_CASES, CYL_CASES, REAL_CASES, STAGE_CASES, rel_l2, sun_distortions
+from conftest import (BLOCKING_CASES, CYL_CASES, KINEMATICS_CASES, REAL_CASES, STAGE_CASES, kinematics_case, rel_l2,
+                      sun_distortions)
 
 pytestmark = pytest.mark.gpu
 
@@ -1048,3 +1049,125 @@ def test_extreme_bitmap_shapes(golden, res):
                              float(d["reflectivity"]))
     if np.linalg.norm(go) > 0:
         assert rel_l2(n(inp["origins"].grad), go) < 5e-3, rel_l2(n(inp["origins"].grad), go)
+
+
+# ---------------------------------------------------------------- rigid-body kinematics
+def _rigid_body(c, requires_grad=False):
+    from artist_amd.kinematics import RigidBody
+    H = c["positions"].shape[0]
+    kin = RigidBody(number_of_heliostats=H, heliostat_positions=t(c["positions"], torch.float32),
+                    initial_orientations=torch.zeros((H, 4), device=DEV),
+                    translation_deviation_parameters=t(c["trans_dev"], torch.float32).requires_grad_(requires_grad),
+                    rotation_deviation_parameters=t(c["rot_dev"], torch.float32).requires_grad_(requires_grad),
+                    actuator_parameters_non_optimizable=t(c["act_nonopt"], torch.float32),
+                    actuator_parameters_optimizable=(t(c["act_opt"], torch.float32).requires_grad_(requires_grad)
+                                                     if c["act_opt"].size else torch.tensor([])), device=DEV)
+    kin.activate_all()
+    return kin
+
+
+@pytest.mark.parametrize("tag", KINEMATICS_CASES)
+def test_rigid_body_orientations(golden, tag):
+    """art_rigid_body_fwd on the reference's scenario files (linear actuators with fitted parameters / ideal
+    actuators) against the reference's fp32 run, its fp64 run and the CPU restatement."""
+    c = kinematics_case(golden("kinematics"), tag, "f32")
+    c64 = kinematics_case(golden("kinematics"), tag, "f64")
+    kin = _rigid_body(c)
+    np.testing.assert_array_equal(n(kin.initial_orientation_offsets[0]), c["offsets"])   # host-side constant, bit-exact
+    ori = n(kin.incident_ray_directions_to_orientations(t(c["incident"]), t(c["aim"])))
+    motor = n(kin.active_motor_positions)
+    o_ori, o_motor, _ = oracle.rigid_body_orientations(c["positions"], c["rot_dev"], c["trans_dev"], c["act_nonopt"],
+                                                       c["act_opt"], c["offsets"], incident=c["incident"], aim=c["aim"])
+    # fp32 yardstick: how far the reference's own fp32 run is from its fp64 run
+    yard = np.abs(c["orientation"] - c64["orientation"]).max()
+    assert np.abs(ori - c64["orientation"]).max() <= 4 * yard + 1e-6
+    np.testing.assert_allclose(ori, c["orientation"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(ori, o_ori, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(motor, c["motor"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(motor, o_motor, rtol=1e-4, atol=1e-4)
+    # calibration path: orientations from measured motor positions (kinematics_rigid_body.py:510-538)
+    ori_m = n(kin.motor_positions_to_orientations(t(c["motor_given"], torch.float32)))
+    np.testing.assert_allclose(ori_m, c["orientation_from_motor"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", KINEMATICS_CASES)
+def test_rigid_body_gradients_equal_reference_jacobians(golden, tag):
+    """art_rigid_body_bwd (forward-mode replay of the iteration) against torch.autograd.functional.jacobian of the
+    reference: d(orientation[h,i,j]) / d(rotation deviations, translation deviations, optimisable actuator
+    parameters), fp32 reference and fp64 reference."""
+    c = kinematics_case(golden("kinematics"), tag, "f32")
+    c64 = kinematics_case(golden("kinematics"), tag, "f64")
+    kin = _rigid_body(c, requires_grad=True)
+    H = c["positions"].shape[0]
+    params = [("jac_rot", kin.active_rotation_deviation_parameters), ("jac_trans", kin.active_translation_deviation_parameters)]
+    if c["act_opt"].size:
+        params.append(("jac_opt", kin.actuators.active_optimizable_parameters))
+    ori = kin.incident_ray_directions_to_orientations(t(c["incident"]), t(c["aim"]))
+    jac = {k: np.zeros((H, 4, 4) + tuple(p.shape[1:]), np.float32) for k, p in params}
+    for i in range(4):
+        for j in range(4):
+            seed = torch.zeros_like(ori)
+            seed[:, i, j] = 1.0
+            grads = torch.autograd.grad(ori, [p for _, p in params], grad_outputs=seed, retain_graph=True)
+            for (k, _), g in zip(params, grads):
+                jac[k][:, i, j] = n(g)
+    for k, _ in params:
+        ref32, ref64 = c[k], c64[k]
+        scale = max(1.0, float(np.abs(ref64).max()))
+        yard = np.abs(ref32 - ref64).max()
+        assert np.abs(jac[k] - ref64).max() <= 4 * yard + 1e-5 * scale, k
+        np.testing.assert_allclose(jac[k], ref32, rtol=0, atol=2e-3 * scale, err_msg=k)
+
+
+def test_rigid_body_motor_path_gradients_vs_finite_differences(golden):
+    """Calibration path: gradients of a scalar of the orientations from GIVEN motor positions against central
+    differences of the fp64 restatement."""
+    c = kinematics_case(golden("kinematics"), "blocking", "f32")
+    c64 = kinematics_case(golden("kinematics"), "blocking", "f64")
+    kin = _rigid_body(c, requires_grad=True)
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal(c["orientation"].shape)
+    ori = kin.motor_positions_to_orientations(t(c["motor_given"], torch.float32))
+    (ori * t(w, torch.float32)).sum().backward()
+
+    def scalar(**over):
+        a = dict(c64, **over)
+        return float((oracle.rigid_body_orientations(a["positions"], a["rot_dev"], a["trans_dev"], a["act_nonopt"], a["act_opt"],
+                                                     a["offsets"], motor_positions=c64["motor_given"])[0] * w).sum())
+
+    for key, param in (("rot_dev", kin.rotation_deviation_parameters), ("trans_dev", kin.translation_deviation_parameters),
+                       ("act_opt", kin.actuators.optimizable_parameters)):
+        g = n(param.grad).reshape(-1)
+        base = c64[key]
+        fd = np.zeros(base.size)
+        for q in range(base.size):
+            step = 1e-6 * max(1.0, abs(float(base.reshape(-1)[q])))
+            plus, minus = base.copy().reshape(-1), base.copy().reshape(-1)
+            plus[q] += step
+            minus[q] -= step
+            fd[q] = (scalar(**{key: plus.reshape(base.shape)}) - scalar(**{key: minus.reshape(base.shape)})) / (2 * step)
+        assert rel_l2(g, fd) < 1e-3, (key, rel_l2(g, fd))
+
+
+def test_rigid_body_field_scale_and_stopping_rule():
+    """2000 heliostats (more than one pass of the single workgroup), ideal actuators: every heliostat's result equals
+    the restatement's, including the FIELD-WIDE stopping rule - one slow heliostat keeps everybody iterating."""
+    from artist_amd.kinematics import initial_orientation_offsets, rigid_body_orientations
+    rng = np.random.default_rng(11)
+    H = 2000
+    pos = np.concatenate([rng.uniform(-100, 100, (H, 2)), rng.uniform(0, 3, (H, 1)), np.ones((H, 1))], 1).astype(np.float32)
+    rot = rng.normal(0, 0.01, (H, 4)).astype(np.float32)
+    trans = rng.normal(0, 0.05, (H, 9)).astype(np.float32)
+    nonopt = np.zeros((H, 4, 2), np.float32)
+    nonopt[:, 2], nonopt[:, 3] = -10.0, 10.0
+    inc = np.tile(np.array([0.2, 0.9, -0.39, 0.0], np.float32) / np.linalg.norm([0.2, 0.9, -0.39]), (H, 1)).astype(np.float32)
+    aim = np.tile(np.array([0.0, -5.0, 50.0, 1.0], np.float32), (H, 1))
+    off = n(initial_orientation_offsets(DEV))[0]
+    for max_iter, eps in ((4, 1e-4), (10, 1e-3), (10, 1e-30), (1, 1e-4)):
+        ori, motor = rigid_body_orientations(1, t(pos), t(rot), t(trans), t(nonopt), None, t(off), t(inc), t(aim), None, max_iter, eps)
+        o_ori, o_motor, evals = oracle.rigid_body_orientations(pos, rot, trans, nonopt, None, off, incident=inc, aim=aim,
+                                                               max_iter=max_iter, min_eps=eps)
+        np.testing.assert_allclose(n(ori), o_ori, rtol=0, atol=5e-5, err_msg=f"{max_iter} {eps}")
+        np.testing.assert_allclose(n(motor), o_motor, rtol=0, atol=5e-5)
+    assert rigid_body_orientations(1, t(pos[:0]), t(rot[:0]), t(trans[:0]), t(nonopt[:0]), None, t(off), t(inc[:0]), t(aim[:0]),
+                                   None, 4, 1e-4)[0].shape == (0, 4, 4)

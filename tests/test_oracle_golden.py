@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import BLOCKING_CASES, CYL_CASES, REAL_CASES, STAGE_CASES, rel_l2, sun_distortions
+from conftest import (BLOCKING_CASES, CYL_CASES, KINEMATICS_CASES, REAL_CASES, STAGE_CASES, kinematics_case, rel_l2,
+                      sun_distortions)
 
 
 # ---- reference's own known answers -----------------------------------------------------------
@@ -467,3 +468,67 @@ def test_real_scenarios(golden, name):
                 np.testing.assert_allclose(fac[row], dd[key], rtol=0, atol=1.5 / rays)
     if name == "real_blocking":
         assert d["blocking"].min() < 0.01 and (d["blocking"] == 1).any()      # from fully blocked to free
+
+
+# ---------------------------------------------------------------- rigid-body kinematics
+def _kin_args(c):
+    return (c["positions"], c["rot_dev"], c["trans_dev"], c["act_nonopt"], c["act_opt"], c["offsets"])
+
+
+@pytest.mark.parametrize("tag", KINEMATICS_CASES)
+def test_rigid_body_fp64_equals_reference(golden, tag):
+    """Reference scenario files, every tensor cast to fp64: orientations, motor positions and the number of iterations
+    of the restatement equal RigidBody's to rounding (kinematics_rigid_body.py:540-634), and so does the calibration
+    path (motor positions -> orientations, :510-538)."""
+    c = kinematics_case(golden("kinematics"), tag, "f64")
+    ori, motor, evals = oracle.rigid_body_orientations(*_kin_args(c), incident=c["incident"], aim=c["aim"])
+    assert evals == 4                                      # the reference never converges earlier on these scenes
+    np.testing.assert_allclose(ori, c["orientation"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(motor, c["motor"], rtol=1e-12, atol=1e-9)
+    ori_m, motor_m, evals_m = oracle.rigid_body_orientations(*_kin_args(c), motor_positions=c["motor_given"])
+    assert evals_m == 1
+    np.testing.assert_allclose(ori_m, c["orientation_from_motor"], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(motor_m, c["motor_given"])
+
+
+@pytest.mark.parametrize("tag", KINEMATICS_CASES)
+def test_rigid_body_fp32(golden, tag):
+    """fp32: the law-of-cosines actuator (acos of a ratio near its clamp) amplifies rounding; 1e-4 on the orientation
+    entries is 5x what the restatement shows against the reference's own fp32 run."""
+    c = kinematics_case(golden("kinematics"), tag, "f32")
+    c64 = kinematics_case(golden("kinematics"), tag, "f64")
+    ori, motor, _ = oracle.rigid_body_orientations(*_kin_args(c), incident=c["incident"], aim=c["aim"])
+    np.testing.assert_allclose(ori, c["orientation"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(motor, c["motor"], rtol=1e-4, atol=1e-4)
+    # and fp32 is no further from the fp64 truth than the reference's fp32 run is (x4 + 1e-6)
+    ours, theirs = np.abs(ori - c64["orientation"]).max(), np.abs(c["orientation"] - c64["orientation"]).max()
+    assert ours <= 4 * theirs + 1e-6
+    ori_m, _, _ = oracle.rigid_body_orientations(*_kin_args(c), motor_positions=c["motor_given"])
+    np.testing.assert_allclose(ori_m, c["orientation_from_motor"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", KINEMATICS_CASES)
+def test_rigid_body_jacobians_by_finite_differences(golden, tag):
+    """The reference's autograd Jacobians d(orientation)/d(deviation and actuator parameters) against central
+    differences of the fp64 restatement - pins the restatement's dependence on every learnable parameter."""
+    c = kinematics_case(golden("kinematics"), tag, "f64")
+    names = [("rot_dev", "jac_rot", 1e-6), ("trans_dev", "jac_trans", 1e-6)]
+    if c["act_opt"].size:
+        names.append(("act_opt", "jac_opt", 1e-7))
+
+    def run(**over):
+        a = dict(c, **over)
+        return oracle.rigid_body_orientations(*_kin_args(a), incident=c["incident"], aim=c["aim"])[0]
+
+    for key, jac_key, h in names:
+        base = c[key]
+        jac = c[jac_key].reshape(base.shape[0], 4, 4, -1)
+        flat = base.reshape(base.shape[0], -1)
+        for q in range(flat.shape[1]):
+            step = h * max(1.0, float(np.abs(flat[:, q]).max()))
+            plus, minus = flat.copy(), flat.copy()
+            plus[:, q] += step
+            minus[:, q] -= step
+            fd = (run(**{key: plus.reshape(base.shape)}) - run(**{key: minus.reshape(base.shape)})) / (2 * step)
+            scale = max(1.0, float(np.abs(jac[..., q]).max()))
+            np.testing.assert_allclose(fd, jac[..., q], rtol=0, atol=2e-5 * scale, err_msg=f"{key}[{q}]")
