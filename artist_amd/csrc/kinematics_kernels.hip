@@ -5,8 +5,8 @@
 // (artist/field/actuators_ideal.py:87-111, actuators_linear.py:105-370).  The reference evaluates them as ~60 small
 // batched ATen ops per iteration ([H,4,4] matmuls, trigonometry, clamps); here one thread owns one heliostat and
 // keeps its 4x4 chain in registers.  The only coupling between heliostats is the stopping rule of the iterative
-// alignment - "stop when NO heliostat's loss moved by more than min_eps" (:618-626) - which is why the forward
-// runs as ONE workgroup: the decision is a __syncthreads_and per iteration.
+// alignment - "stop when NO heliostat's loss moved by more than min_eps" (:618-626): one launch per evaluation,
+// the field-wide answer handed from launch to launch through a flag in HBM (see rigid_body_eval_kernel).
 //
 // Backward = forward-mode differentiation: the same templated code runs on dual numbers (value, derivative), one
 // thread per (heliostat, parameter) seeds its parameter and contracts d(orientation) with dL/d(orientation).  17
@@ -250,47 +250,45 @@ template <typename T> __device__ __forceinline__ Params<T> load_params(const Kin
     return p;
 }
 
-// One workgroup; thread <-> heliostats h = tid, tid + blockDim, ...  `scratch` [H] holds the previous loss.
-__global__ __launch_bounds__(1024) void rigid_body_fwd_kernel(KinArgs a, float* __restrict__ motor /*[H,2] in/out*/,
-                                                              float* __restrict__ orientations, float* __restrict__ scratch,
-                                                              int* __restrict__ evals_out)
+// One launch per forward-kinematics evaluation `it`, thread <-> heliostat.  The reference's loop is
+//   evaluate -> loss -> "did ANY heliostat's loss move by more than min_eps?" -> if not: stop, else new motor positions,
+// so the motor update of evaluation it-1 is done at the start of launch `it`, once the field-wide answer of launch
+// it-1 (flags[it-1], written by any thread that has not converged) is visible through stream order.  A launch whose
+// predecessors found the field converged returns at once: max_iter launches are always enqueued, no host round trip.
+//   flags[j] (j >= 1) = 1 when some heliostat had not converged at evaluation j; evals_out = evaluations made.
+__global__ __launch_bounds__(64) void rigid_body_eval_kernel(KinArgs a, int it, float* __restrict__ motor /*[H,2] in/out*/,
+                                                             float* __restrict__ orientations, float* __restrict__ last_loss,
+                                                             int* __restrict__ flags, int* __restrict__ evals_out)
 {
-    int evals = 0;
-    const int iters = a.mode == 1 ? a.max_iter : 1;
-    if (a.mode == 1)
-        for (int h = threadIdx.x; h < a.H; h += blockDim.x) { motor[2 * h] = 0.0f; motor[2 * h + 1] = 0.0f; }
-    for (int it = 0; it < iters; ++it) {
-        int converged = it > 0;
-        for (int h = threadIdx.x; h < a.H; h += blockDim.x) {
-            const Params<float> p = load_params<float>(a, h, -1);
-            const Mat4<float> ori = kin_forward(p, motor[2 * h], motor[2 * h + 1]);
-            if (a.mode == 1) {
-                float dn[4], loss;
-                desired_normal(ori, a.incident + 4 * h, a.aim + 4 * h, dn, loss);
-                if (it > 0 && !(fabsf(scratch[h] - loss) <= a.min_eps)) converged = 0;
-                scratch[h] = loss;
-            }
-            // final result of this evaluation (overwritten by the next one): orientation @ initial offsets (:634)
-            Mat4<float> off;
-            for (int k = 0; k < 16; ++k) off.m[k] = a.offsets[k];
-            const Mat4<float> r = m_mul(ori, off);
-            for (int k = 0; k < 16; ++k) orientations[16 * (int64_t)h + k] = r.m[k];
-        }
-        ++evals;
-        const int all_converged = __syncthreads_and(converged);
-        if (a.mode != 1 || all_converged) break;
-        for (int h = threadIdx.x; h < a.H; h += blockDim.x) {            // next motor positions (:630-632)
-            const Params<float> p = load_params<float>(a, h, -1);
-            const Mat4<float> ori = kin_forward(p, motor[2 * h], motor[2 * h + 1]);
-            float dn[4], loss;
-            desired_normal(ori, a.incident + 4 * h, a.aim + 4 * h, dn, loss);
-            float m0, m1;
-            kin_inverse(p, dn, m0, m1);
-            motor[2 * h] = m0; motor[2 * h + 1] = m1;
-        }
-        __syncthreads();
+    for (int j = 1; j < it; ++j)
+        if (flags[j] == 0) return;                                      // converged at evaluation j: nothing more to do
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= a.H) return;
+    const Params<float> p = load_params<float>(a, h, -1);
+    float m0, m1;
+    if (it == 0) {
+        m0 = a.mode == 1 ? 0.0f : motor[2 * h];
+        m1 = a.mode == 1 ? 0.0f : motor[2 * h + 1];
+    } else {                                                            // next motor positions (:630-632)
+        const Mat4<float> prev = kin_forward(p, motor[2 * h], motor[2 * h + 1]);
+        float dn[4], loss;
+        desired_normal(prev, a.incident + 4 * h, a.aim + 4 * h, dn, loss);
+        kin_inverse(p, dn, m0, m1);
     }
-    if (threadIdx.x == 0) *evals_out = evals;
+    motor[2 * h] = m0; motor[2 * h + 1] = m1;
+    if (it == a.max_iter) return;          // the reference updates the motor positions once more after its last evaluation
+    const Mat4<float> ori = kin_forward(p, m0, m1);
+    if (a.mode == 1) {
+        float dn[4], loss;
+        desired_normal(ori, a.incident + 4 * h, a.aim + 4 * h, dn, loss);
+        if (it > 0 && !(fabsf(last_loss[h] - loss) <= a.min_eps)) flags[it] = 1;
+        last_loss[h] = loss;
+    }
+    Mat4<float> off;                                                    // orientation @ initial offsets (:634)
+    for (int k = 0; k < 16; ++k) off.m[k] = a.offsets[k];
+    const Mat4<float> r = m_mul(ori, off);
+    for (int k = 0; k < 16; ++k) orientations[16 * (int64_t)h + k] = r.m[k];
+    if (h == 0) *evals_out = it + 1;
 }
 
 // thread <-> (heliostat, parameter): the chain of the forward with the recorded number of evaluations, on dual numbers
@@ -350,7 +348,7 @@ static bool kin_fill(KinArgs& a, int mode, const float* positions, const float* 
     if (mode == 1 && (!incident || !aim || max_iter < 1)) return false;
     a.positions = positions; a.rot_dev = rot_dev; a.trans_dev = trans_dev; a.act_nonopt = act_nonopt; a.act_opt = act_opt;
     a.offsets = offsets; a.incident = incident; a.aim = aim;
-    a.act_rows = (int)act_rows; a.H = (int)H; a.mode = mode; a.max_iter = max_iter; a.min_eps = (float)min_eps;
+    a.act_rows = (int)act_rows; a.H = (int)H; a.mode = mode; a.max_iter = mode == 1 ? max_iter : 1; a.min_eps = (float)min_eps;
     return true;
 }
 
@@ -362,12 +360,18 @@ extern "C" int art_rigid_body_fwd(int mode, const float* positions, const float*
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KinArgs a;
+    if (H == 0) return ART_OK;                       // an empty group: nothing to read, nothing to write
     if (!motor_positions || !orientations || !scratch || !evaluations ||
         !kin_fill(a, mode, positions, rot_dev, trans_dev, act_nonopt, act_rows, act_opt, offsets, incident, aim, H, max_iter, min_eps))
         return ART_EINVAL;
-    if (H == 0) return ART_OK;
-    hipLaunchKernelGGL(rigid_body_fwd_kernel, dim3(1), dim3(1024), 0, stream, a, motor_positions, orientations, scratch,
-                       evaluations);
+    // scratch = [H] previous losses, then max_iter + 1 int flags
+    float* last_loss = scratch;
+    int* flags = reinterpret_cast<int*>(scratch + H);
+    const int evaluations_max = mode == 1 ? max_iter : 1;
+    ART_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)(evaluations_max + 1), stream));
+    for (int it = 0; it < evaluations_max + (mode == 1 ? 1 : 0); ++it)   // mode 1: + the trailing motor update
+        hipLaunchKernelGGL(rigid_body_eval_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, stream, a, it, motor_positions,
+                           orientations, last_loss, flags, evaluations);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }
@@ -380,10 +384,10 @@ extern "C" int art_rigid_body_bwd(int mode, const float* positions, const float*
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KinArgs a;
+    if (H == 0) return ART_OK;
     if (!grad_orientations || !grad_rot_dev || !grad_trans_dev || !motor_positions || (mode == 1 && !evaluations) ||
         !kin_fill(a, mode, positions, rot_dev, trans_dev, act_nonopt, act_rows, act_opt, offsets, incident, aim, H, 1, 0.0))
         return ART_EINVAL;
-    if (H == 0) return ART_OK;
     const int64_t n = H * 17;
     hipLaunchKernelGGL(rigid_body_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, motor_positions,
                        evaluations, grad_orientations, grad_rot_dev, grad_trans_dev, grad_act_opt);

@@ -4,8 +4,8 @@ Drop-in for ``artist.field.kinematics_rigid_body.RigidBody`` (artist/field/kinem
 its ideal and linear actuators (artist/field/actuators_ideal.py, actuators_linear.py): same constructor, same
 attributes (``active_*`` tables set by ``HeliostatGroup.activate_heliostats``, heliostat_group.py:273-315), same
 two methods.  The whole chain - actuator geometry, the two joints' 4x4 transforms, the iterative alignment with
-its field-wide stopping rule - runs as ONE kernel launch (``art_rigid_body_fwd``) instead of ~60 ATen ops per
-iteration, and its gradients w.r.t. the deviation parameters and the optimisable actuator parameters (what the
+its field-wide stopping rule - runs as one small kernel per evaluation (``art_rigid_body_fwd``, no host round trip
+for the stopping rule) instead of ~60 ATen ops per iteration, and its gradients w.r.t. the deviation parameters and the optimisable actuator parameters (what the
 kinematics reconstructor learns) come from ``art_rigid_body_bwd``.
 """
 from __future__ import annotations
@@ -55,7 +55,7 @@ class RigidBodyOrientations(torch.autograd.Function):
                 raise ValueError("motor_positions must be [number_of_active_heliostats, 2]")
             motor = _f32c(motor_positions).clone()
         orientations = torch.empty((H, 4, 4), dtype=torch.float32, device=dev)
-        scratch = torch.empty((max(H, 1),), dtype=torch.float32, device=dev)
+        scratch = torch.empty((H + int(max_iter) + 1,), dtype=torch.float32, device=dev)
         evaluations = torch.zeros((1,), dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().art_rigid_body_fwd(

@@ -128,8 +128,9 @@ class HeliostatGroup:
     (artist/field/heliostat_group.py:133-222)."""
 
     def __init__(self, names, positions, surface_points, surface_normals, canting, facet_translations,
-                 nurbs_control_points, nurbs_degrees, device: torch.device | None = None) -> None:
+                 nurbs_control_points, nurbs_degrees, device: torch.device | None = None, kinematics=None) -> None:
         self.names = names
+        self.kinematics = kinematics        # artist_amd.kinematics.RigidBody, or None = the ideal mount above
         self.number_of_heliostats = len(names)
         self.number_of_facets_per_heliostat = canting.shape[1]
         self.positions = positions
@@ -159,18 +160,46 @@ class HeliostatGroup:
         self.active_facet_translations = rep(self.facet_translations)
         self.active_nurbs_control_points = rep(self.nurbs_control_points)
         self.active_positions = rep(self.positions)
+        kin = self.kinematics
+        if kin is not None:                                              # heliostat_group.py:273-315
+            kin.number_of_active_heliostats = self.number_of_active_heliostats
+            kin.active_heliostat_positions = rep(kin.heliostat_positions)
+            kin.active_initial_orientations = rep(kin.initial_orientations)
+            kin.active_translation_deviation_parameters = rep(kin.translation_deviation_parameters)
+            kin.active_rotation_deviation_parameters = rep(kin.rotation_deviation_parameters)
+            kin.active_motor_positions = rep(kin.motor_positions)
+            kin.actuators.active_non_optimizable_parameters = rep(kin.actuators.non_optimizable_parameters)
+            if kin.actuators.optimizable_parameters.numel() > 0:
+                kin.actuators.active_optimizable_parameters = rep(kin.actuators.optimizable_parameters)
+            else:
+                kin.actuators.active_optimizable_parameters = torch.tensor([], requires_grad=True)
 
-    def align_surfaces_with_incident_ray_directions(self, aim_points, incident_ray_directions,
-                                                    active_heliostats_mask, device=None) -> None:
-        """``points @ orientation^T`` (artist/field/heliostat_group_rigid_body.py:169-222) with the ideal
-        mount above instead of the rigid-body kinematics."""
-        assert torch.equal(self.active_heliostats_mask, active_heliostats_mask), \
-            "Some heliostats were not activated and cannot be aligned."
-        orientations = ideal_orientations(self.active_positions, aim_points, incident_ray_directions)
+    def _align(self, orientations) -> None:
         self.active_orientations = orientations
         from .ops import align_surfaces
         self.active_surface_points, self.active_surface_normals = align_surfaces(
             self.active_surface_points, self.active_surface_normals, orientations)
+
+    def align_surfaces_with_incident_ray_directions(self, aim_points, incident_ray_directions,
+                                                    active_heliostats_mask, device=None) -> None:
+        """``points @ orientation^T`` (artist/field/heliostat_group_rigid_body.py:169-222): orientations from the
+        rigid-body kinematics (``artist_amd.kinematics.RigidBody``) when the group has one, else the ideal mount."""
+        assert torch.equal(self.active_heliostats_mask, active_heliostats_mask), \
+            "Some heliostats were not activated and cannot be aligned."
+        if self.kinematics is not None:
+            orientations = self.kinematics.incident_ray_directions_to_orientations(
+                incident_ray_directions=incident_ray_directions, aim_points=aim_points, device=device)
+        else:
+            orientations = ideal_orientations(self.active_positions, aim_points, incident_ray_directions)
+        self._align(orientations)
+
+    def align_surfaces_with_motor_positions(self, motor_positions, active_heliostats_mask, device=None) -> None:
+        """artist/field/heliostat_group_rigid_body.py:224-270 - the calibration path."""
+        assert torch.equal(self.active_heliostats_mask, active_heliostats_mask), \
+            "Some heliostats were not activated and cannot be aligned."
+        if self.kinematics is None:
+            raise ValueError("aligning with motor positions needs a group with rigid-body kinematics")
+        self._align(self.kinematics.motor_positions_to_orientations(motor_positions=motor_positions, device=device))
 
 
 class HeliostatField:

@@ -224,7 +224,8 @@ int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B,
  *   positions [H,4]; rot_dev [H,4]; trans_dev [H,9]; act_nonopt [H,act_rows,2] with act_rows 4 (ideal) or
  *   7 (linear: + increment, offset, pivot radius); act_opt [H,2,2] (linear; NULL for ideal);
  *   offsets [4,4] = RigidBody.initial_orientation_offsets; incident, aim [H,4] (mode 1; may be NULL in mode 0).
- *   orientations [H,4,4] out (already multiplied by offsets); scratch [H] floats; evaluations [1] int32 out =
+ *   orientations [H,4,4] out (already multiplied by offsets); scratch [H + max_iter + 1] 4-byte words;
+ *   evaluations [1] int32 out =
  *   number of forward-kinematics evaluations made (what the backward replays).
  * art_rigid_body_bwd - its autograd w.r.t. rot_dev, trans_dev and act_opt by forward-mode differentiation of the
  *   same chain (the gradients torch.autograd gives the reference): grad_orientations [H,4,4] in;

@@ -417,11 +417,24 @@ def run_scenario_file(filename, mapping, n_rays, points_per_facet, blocking, res
     string_mapping = [(h, t_, torch.nn.functional.normalize(torch.tensor(d, dtype=dtype), dim=-1)) for h, t_, d in mapping]
     mask, target_idx, incident = scenario.index_mapping(heliostat_group=group, string_mapping=string_mapping, device=CPU)
     group.activate_heliostats(active_heliostats_mask=mask, device=CPU)
+    # the learnable kinematic parameters become leaves, so that the backward below also yields the END-TO-END gradients
+    # flux -> aligned surfaces -> orientations -> kinematics (what the kinematics reconstructor optimises)
+    kin = group.kinematics
+    kin_rot = kin.active_rotation_deviation_parameters.detach().clone().requires_grad_(True)
+    kin_trans = kin.active_translation_deviation_parameters.detach().clone().requires_grad_(True)
+    kin_opt = kin.actuators.active_optimizable_parameters.detach().clone()
+    if kin_opt.numel():
+        kin_opt.requires_grad_(True)
+    kin.active_rotation_deviation_parameters, kin.active_translation_deviation_parameters = kin_rot, kin_trans
+    kin.actuators.active_optimizable_parameters = kin_opt
+    surface_points, surface_normals = group.active_surface_points.detach().clone(), group.active_surface_normals.detach().clone()
+    aim_points = scenario.solar_tower.get_centers_of_target_areas(target_area_indices=target_idx, device=CPU)
     group.align_surfaces_with_incident_ray_directions(
-        aim_points=scenario.solar_tower.get_centers_of_target_areas(target_area_indices=target_idx, device=CPU),
-        incident_ray_directions=incident, active_heliostats_mask=mask, device=CPU)
-    apts = group.active_surface_points.detach().to(dtype).clone().requires_grad_(True)
-    anrm = group.active_surface_normals.detach().to(dtype).clone().requires_grad_(True)
+        aim_points=aim_points, incident_ray_directions=incident, active_heliostats_mask=mask, device=CPU)
+    apts = group.active_surface_points.to(dtype)
+    anrm = group.active_surface_normals.to(dtype)
+    apts.retain_grad()
+    anrm.retain_grad()
     group.active_surface_points, group.active_surface_normals = apts, anrm
     scenario.set_number_of_rays(number_of_rays=n_rays)
     captured = []
@@ -460,7 +473,13 @@ def run_scenario_file(filename, mapping, n_rays, points_per_facet, blocking, res
         ray_magnitude=np.float64(float(rt.ray_magnitude)), extinction=np.float64(0.0), reflectivity=np.float64(0.935),
         flux=npy(flux), intercept=npy(intercept), on_target=npy(on_target), blocking=npy(unblocked),
         loss_weights=npy(weights), grad_aligned_points=npy(apts.grad), grad_aligned_normals=npy(anrm.grad),
-        control_points=npy(group.nurbs_control_points), positions=npy(group.positions))
+        control_points=npy(group.nurbs_control_points), positions=npy(group.positions),
+        surface_points=npy(surface_points), surface_normals=npy(surface_normals), aim_points=npy(aim_points),
+        kin_positions=npy(kin.active_heliostat_positions), kin_rot_dev=npy(kin_rot), kin_trans_dev=npy(kin_trans),
+        kin_act_nonopt=npy(kin.actuators.active_non_optimizable_parameters), kin_act_opt=npy(kin_opt),
+        grad_kin_rot_dev=npy(kin_rot.grad), grad_kin_trans_dev=npy(kin_trans.grad))
+    if kin_opt.numel():
+        out.update(grad_kin_act_opt=npy(kin_opt.grad))
     if blocking:
         c_, s_, n_ = captured[-1]
         out.update(blocking_surfaces=npy(rt.blocking_heliostat_surfaces_active), prim_corners=npy(c_), prim_spans=npy(s_),
