@@ -1,12 +1,13 @@
-"""A read-only stand-in for the few h5py calls ARTIST's scenario loader makes - TEST INFRASTRUCTURE ONLY.
+"""A small read-only HDF5 reader for ARTIST scenario files, used when ``h5py`` is not installed.
 
-h5py is not installed in this image, so the reference cannot open its own scenario files
-(``/root/reference/tests/data/scenarios/*.h5``).  Those files use the oldest HDF5 layout (superblock version 0,
-symbol-table groups, contiguous or compact uncompressed datasets), which this module parses from the published
-HDF5 file-format specification: enough for ``File(path, "r")`` as a context manager, ``group[key]`` (also with
-``a/b/c`` paths), ``key in group``, ``.keys()``, ``.items()``, ``.values()``, ``len()``, iteration, ``.name``,
-``dataset[()]``, ``dataset[...]``, ``.shape``, ``.dtype``.  ``tests/golden/generate_golden.py`` installs it as
-``sys.modules["h5py"]`` before importing the reference; nothing in the product or on the GPU box uses it.
+ARTIST's scenario files (``artist/scenario/h5_scenario_generator.py`` writes them with h5py's defaults) use the
+oldest HDF5 layout - superblock version 0, symbol-table groups, contiguous or compact uncompressed datasets - which
+this module parses from the published HDF5 file-format specification.  It offers the few h5py calls a scenario
+loader makes: ``File(path, "r")`` as a context manager, ``group[key]`` (also with ``a/b/c`` paths), ``key in group``,
+``.get()``, ``.keys()``, ``.items()``, ``.values()``, ``len()``, iteration, ``.name``, ``.attrs``, ``dataset[()]``,
+``dataset[...]``, ``.shape``, ``.dtype``.  ``artist_amd.scenario.open_scenario_file`` falls back to it;
+``tests/golden/generate_golden.py`` also installs it as ``sys.modules["h5py"]`` so that the reference can read its own
+files in an image without h5py.  Chunked / compressed datasets and newer superblocks raise ``OSError``.
 """
 from __future__ import annotations
 
@@ -287,7 +288,7 @@ class Group:
 class File(Group):
     def __init__(self, path, mode="r", **_kwargs):
         if mode != "r":
-            raise OSError("mini_h5 is read-only")
+            raise OSError("h5lite is read-only")
         r = _Reader(str(path))
         e = r.root_entry
         _name_off, header, cache_type = r.u("QQI", e)

@@ -102,9 +102,7 @@ class HeliostatRayTracer:
             self.blocking_heliostat_surfaces = torch.cat(
                 [group.surface_points for group in self.scenario.heliostat_field.heliostat_groups])
             self.blocking_heliostat_surfaces_active = torch.cat(surfaces)
-            # largest scatter angle of the (fixed) distortion dataset: bounds every heliostat's ray cone
-            ds = self.distortions_dataset
-            self._max_scatter_angle = float(torch.maximum(ds.distortions_u.abs().max(), ds.distortions_e.abs().max()))
+            self._scatter_angle_cache = (None, 0.0)
         #: reproduce which rectangles the reference's LBVH can reach (see artist_amd/blocking.py); False = every
         #: rectangle whose box is hit, as ``lbvh_filter_blocking_planes`` documents
         self.lbvh_compat = True
@@ -193,7 +191,17 @@ class HeliostatRayTracer:
         owner = torch.nonzero(active_heliostats_mask, as_tuple=True)[0]
         if idx is not None:
             owner = owner.index_select(0, idx.to(owner.device))
-        return corners, spans, normals, owner, self._max_scatter_angle, self.lbvh_compat
+        return corners, spans, normals, owner, self._max_scatter_angle(), self.lbvh_compat
+
+    def _max_scatter_angle(self) -> float:
+        """Largest scatter angle of the distortion dataset: bounds every heliostat's ray cone for the blocking cull.
+        Computed once per dataset (one reduction + host read), again if a caller swaps the dataset's tensors."""
+        ds = self.distortions_dataset
+        key = (ds.distortions_u.data_ptr(), ds.distortions_e.data_ptr(), tuple(ds.distortions_u.shape))
+        if self._scatter_angle_cache[0] != key:
+            value = float(torch.maximum(ds.distortions_u.abs().max(), ds.distortions_e.abs().max()))
+            self._scatter_angle_cache = (key, value)
+        return self._scatter_angle_cache[1]
 
     def trace_rays_per_target(self, incident_ray_directions, active_heliostats_mask, target_area_indices,
                               ray_extinction_factor: float = 0.0, mirror_reflectivity: float = 0.935,

@@ -100,9 +100,18 @@ class SolarTower:
         self.target_name_to_index = {n: i for i, n in enumerate(names)}
 
     def get_centers_of_target_areas(self, target_area_indices: torch.Tensor, device=None) -> torch.Tensor:
-        """Centres by GLOBAL target index, planar first, cylindrical second (artist/field/solar_tower.py:133-185)."""
-        tables = [t.centers for t in self.target_areas if t.number_of_target_areas > 0]
-        return torch.cat(tables)[target_area_indices]
+        """Aim points by GLOBAL target index, planar first, cylindrical second: a planar area's centre; for a cylinder
+        the point of its mantle in the middle of the opening sector, centre + radius * normal
+        (artist/field/solar_tower.py:129-188)."""
+        tables = []
+        if self.target_areas[0].number_of_target_areas > 0:
+            tables.append(self.target_areas[0].centers)
+        cyl = self.target_areas[1]
+        if cyl.number_of_target_areas > 0:
+            tables.append(cyl.centers + cyl.radii.reshape(-1, 1) * cyl.normals)
+        centers = torch.cat(tables)[target_area_indices.long()].clone()
+        centers[:, 3] = 1.0
+        return centers
 
 
 def ideal_orientations(positions: torch.Tensor, aim_points: torch.Tensor, incident: torch.Tensor) -> torch.Tensor:

@@ -50,7 +50,7 @@ def kinematics_case(d, tag, sfx):
 STAGE_CASES = ["small_deg3", "small_deg2_tilted", "small_offtarget", "mid_256"]
 BLOCKING_CASES = ["small_blocking", "mid_blocking"]   # blocking_active=True (artist/raytracing/blocking.py)
 # the reference's own scenario files (tests/data/scenarios/*.h5) through its loader, kinematics and ray tracer
-REAL_CASES = ["real_blocking", "real_paint_mixed"]
+REAL_CASES = ["real_blocking", "real_paint_mixed", "real_stral_single"]
 CYL_CASES = ["small_cyl_mixed", "mid_cyl"]   # cylindrical receivers (ill-conditioned in fp32: see test_oracle_golden.py)
 
 

@@ -52,10 +52,10 @@ def _import_reference():
             pass
 
     stub("colorlog", ColoredFormatter=_Fmt)
-    # h5py is absent: tests/golden/mini_h5.py reads the reference's own scenario files (superblock-0 HDF5)
-    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
-    import mini_h5
-    stub("h5py", File=mini_h5.File, Group=mini_h5.Group, Dataset=mini_h5.Dataset)
+    # h5py is absent: artist_amd/h5lite.py reads the reference's own scenario files (superblock-0 HDF5)
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
+    from artist_amd import h5lite
+    stub("h5py", File=h5lite.File, Group=h5lite.Group, Dataset=h5lite.Dataset)
     stub("torchvision")
     stub("torchvision.transforms")
     stub("paint")
@@ -526,6 +526,13 @@ REAL_CASES = {
         resolution=[96, 64],
         mapping=[("AA28", "receiver", [0.3, 0.8, -0.52, 0.0]), ("AA31", "multi_focus_tower", [0.3, 0.8, -0.52, 0.0]),
                  ("AA39", "receiver", [0.3, 0.8, -0.52, 0.0]), ("AC43", "solar_tower_juelich_upper", [0.3, 0.8, -0.52, 0.0])]),
+    # tests/field/test_integration_alignment.py:13-22: ONE heliostat built from the prototypes (STRAL surface, ideal
+    # actuators), activated four times with the sun in the south, west, east and zenith
+    "real_stral_single": dict(
+        filename="test_scenario_stral_single_heliostat.h5", n_rays=6, points_per_facet=[12, 12], blocking=False,
+        resolution=[64, 64],
+        mapping=[("heliostat_1", "receiver", [0.0, 1.0, 0.0, 0.0]), ("heliostat_1", "receiver", [-1.0, 0.0, 0.0, 0.0]),
+                 ("heliostat_1", "receiver", [1.0, 0.0, 0.0, 0.0]), ("heliostat_1", "receiver", [0.0, 0.0, -1.0, 0.0])]),
 }
 
 

@@ -1,5 +1,7 @@
 """CPU suite: host-side logic of the drop-in classes (no kernels): sampler partition, knot vectors and span
 search of the NURBS mirror, helper constructors, the distortion recipe, tracer bookkeeping and error behaviour."""
+import pathlib
+
 import numpy as np
 import pytest
 import torch
@@ -122,7 +124,7 @@ def test_tracer_bookkeeping_and_errors():
     assert rtb.blocking_active and rtb.blocking_heliostat_surfaces_active.shape == (4, 8, 4)
     assert torch.equal(rtb.blocking_heliostat_surfaces_active[1], g.surface_points[1] + g.positions[1])
     assert torch.equal(rtb.blocking_heliostat_surfaces_active[[0, 2, 3]], g.active_surface_points)
-    assert rtb._max_scatter_angle == float(max(rtb.distortions_dataset.distortions_u.abs().max(),
+    assert rtb._max_scatter_angle() == float(max(rtb.distortions_dataset.distortions_u.abs().max(),
                                                rtb.distortions_dataset.distortions_e.abs().max()))
     g.activate_heliostats(torch.tensor([2, 0, 1, 1], dtype=torch.int32))
     # heliostat_ray_tracer.py:185-203: ray magnitude from dni
@@ -154,3 +156,87 @@ def test_interop_record_with_the_reference_objects():
     assert rec["owner"] == [0, 1, 2, 3, 4, 5] and "no CPU fallback" in rec["cpu_trace"]
     # radius x opening angle and height for the cylindrical areas (artist/flux/bitmap.py:183-216)
     assert rec["target_dimensions"][2] == pytest.approx([4.14 * 1.0471976, 5.2291923], rel=1e-6)
+
+
+# ---------------------------------------------------------------- scenario files
+SCENARIOS = pathlib.Path(__file__).resolve().parent / "golden" / "scenarios"
+SCENARIO_CASES = {"real_blocking": "test_blocking.h5", "real_paint_mixed": "test_scenario_paint_four_heliostats.h5"}
+
+
+@pytest.mark.parametrize("fixture", SCENARIO_CASES)
+def test_scenario_tables_equal_the_reference_loader(golden, fixture):
+    """The reference's own scenario files, read by artist_amd (built-in HDF5 reader): every table equals, bit for
+    bit, what ARTIST's loader produced when the fixture was generated (target areas, kinematic deviations, actuator
+    tables incl. the initial-angle offset, positions, fitted control points)."""
+    from artist_amd import scenario
+    d = golden(fixture)
+    with scenario.open_scenario_file(SCENARIOS / SCENARIO_CASES[fixture]) as f:
+        tables = scenario.read_scenario_tables(f)
+    assert float(tables["version"]) == 1.0 and tables["power_plant_position"].shape == (3,)
+    for ours, key in (("centers", "target_centers"), ("normals", "target_normals"), ("dimensions", "target_dims")):
+        np.testing.assert_array_equal(tables["planar"][ours], d[key])
+    for ours, key in (("centers", "cyl_centers"), ("normals", "cyl_normals"), ("axes", "cyl_axes"), ("radii", "cyl_radii"),
+                      ("heights", "cyl_heights"), ("opening_angles", "cyl_opening")):
+        np.testing.assert_array_equal(tables["cylindrical"][ours], d[key])
+    assert tables["light_sources"][0]["number_of_rays"] == 10
+    assert tables["light_sources"][0]["distribution_parameters"] == dict(distribution_type="normal", mean=0.0, covariance=4.3681e-06)
+    first = tables["heliostats"][0]["actuators"]["type"]               # the fixture holds the FIRST group
+    members = [h for h in tables["heliostats"] if h["actuators"]["type"] == first]
+    stack = lambda f_: np.stack([f_(h) for h in members])  # noqa: E731
+    np.testing.assert_array_equal(stack(lambda h: h["position"]), d["kin_positions"])
+    np.testing.assert_array_equal(stack(lambda h: h["kinematics"]["translation"]), d["kin_trans_dev"])
+    np.testing.assert_array_equal(stack(lambda h: h["kinematics"]["rotation"]), d["kin_rot_dev"])
+    np.testing.assert_array_equal(stack(lambda h: h["actuators"]["non_optimizable"]), d["kin_act_nonopt"])
+    np.testing.assert_array_equal(stack(lambda h: h["actuators"]["optimizable"]).reshape(d["kin_act_opt"].shape), d["kin_act_opt"])
+    np.testing.assert_array_equal(stack(lambda h: h["surface"]["control_points"]), d["control_points"])
+
+
+def test_index_mapping_and_aim_points(golden):
+    """Scenario.index_mapping (scenario.py:261-418) and SolarTower.get_centers_of_target_areas (solar_tower.py:129-188,
+    cylinder aim point = centre + radius * normal) on CPU tensors against the reference's results in the fixture."""
+    from artist_amd import scene, scenario
+    d = golden("real_paint_mixed")
+    t = torch.from_numpy
+    tower = scene.SolarTower([scene.TowerTargetAreasPlanar(["multi_focus_tower", "solar_tower_juelich_lower", "solar_tower_juelich_upper"],
+                                                           t(d["target_centers"]), t(d["target_normals"]), t(d["target_dims"])),
+                              scene.TowerTargetAreasCylindrical(["receiver"], t(d["cyl_centers"]), t(d["cyl_normals"]), t(d["cyl_axes"]),
+                                                                t(d["cyl_radii"]), t(d["cyl_heights"]), t(d["cyl_opening"]))])
+    sc = scenario.Scenario(power_plant_position=None, solar_tower=tower, light_sources=None, heliostat_field=None)
+
+    class Group:                                             # the fixture's group: the two heliostats with ideal actuators
+        names = ["AA28", "AC43"]
+        positions = torch.zeros((2, 4))
+
+    sun = torch.nn.functional.normalize(torch.tensor([0.3, 0.8, -0.52, 0.0]), dim=0)
+    mapping = [("AA28", "receiver", sun), ("AA31", "multi_focus_tower", sun), ("AA39", "receiver", sun),
+               ("AC43", "solar_tower_juelich_upper", sun)]
+    mask, targets, incident = sc.index_mapping(Group, mapping, device="cpu")
+    np.testing.assert_array_equal(mask.numpy(), d["active_mask"])
+    np.testing.assert_array_equal(targets.numpy(), d["target_idx"])
+    np.testing.assert_array_equal(incident.numpy(), d["incident"])
+    np.testing.assert_array_equal(tower.get_centers_of_target_areas(targets).numpy(), d["aim_points"])
+    # repeats stay adjacent in group order; other groups' heliostats are ignored
+    mask, targets, incident = sc.index_mapping(Group, [("AC43", "receiver", sun), ("AA28", "multi_focus_tower", sun),
+                                                       ("AC43", "multi_focus_tower", sun)], device="cpu")
+    assert mask.tolist() == [1, 2] and targets.tolist() == [0, 3, 0]
+    with pytest.raises(ValueError, match="Invalid target 'nowhere'"):
+        sc.index_mapping(Group, [("AA28", "nowhere", sun)], device="cpu")
+    with pytest.raises(ValueError, match="Invalid incident ray direction"):
+        sc.index_mapping(Group, [("AA28", "receiver", 2 * sun)], device="cpu")
+    mask, targets, incident = sc.index_mapping(Group, device="cpu", single_target_area_index=2)
+    assert mask.tolist() == [1, 1] and targets.tolist() == [2, 2] and incident.tolist() == [[0.0, 1.0, 0.0, 0.0]] * 2
+    with pytest.raises(ValueError, match="single target area index is invalid"):
+        sc.index_mapping(Group, device="cpu", single_target_area_index=4)
+
+
+def test_h5lite_reads_groups_datasets_and_attributes():
+    from artist_amd import h5lite
+    with h5lite.File(SCENARIOS / "test_scenario_stral_single_heliostat.h5") as f:
+        assert float(f.attrs["version"]) == 1.0
+        assert "heliostats" in f and "nothing" not in f and f.get("nothing") is None
+        assert f["power_plant/position"][()].shape == (3,) and f["power_plant"]["position"].dtype in (np.float32, np.float64)
+        assert f["lightsources/sun_1/type"][()] == b"sun"
+        names = list(f["heliostats"].keys())
+        assert len(names) == 1 and f["heliostats"][names[0]]["position"].shape == (4,)
+    with pytest.raises(OSError):
+        h5lite.File(pathlib.Path(__file__), "r")

@@ -427,7 +427,7 @@ def test_flux_crop_and_losses_vs_reference_autograd(golden, tag, dt, tol):
 
 
 # ---------------------------------------------------------------------------------------------
-# The reference's own scenario files (HDF5, read by tests/golden/mini_h5.py in the generator): fitted NURBS surfaces,
+# The reference's own scenario files (HDF5, read by artist_amd/h5lite.py in the generator): fitted NURBS surfaces,
 # rigid-body kinematics with real actuators, planar and cylindrical target areas, blocking between six heliostats.
 # ---------------------------------------------------------------------------------------------
 def _real_case_blocking(d):
