@@ -12,6 +12,11 @@
 // rectangles art_blocking_filter selected, template parameter BLOCKING), :482-487 (intensities),
 // :489-494 + :610-778 (bilinear_splatting), :498-506 (factors), :563-608 (per-target sums, mode 1).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -127,6 +132,41 @@ struct Window {
     float carry;          // sign * 2^32 / S    (value of one cell wrap)
 };
 
+// Wave reductions on the DPP network (VALU ops, a few cycles each) instead of __shfl_xor (ds_bpermute through the LDS
+// crossbar, ~100 cycles each): the window phase reduces 13 quantities per wave and was 2 us of shuffles.
+enum { kMin, kMax, kSum };
+template <int OP> __device__ __forceinline__ float red_op(float x, float y)
+{
+    if constexpr (OP == kMin) return fminf(x, y);
+    else if constexpr (OP == kMax) return fmaxf(x, y);
+    else return x + y;
+}
+template <int OP> __device__ __forceinline__ float red_identity() { return OP == kMin ? 3.0e38f : (OP == kMax ? -3.0e38f : 0.0f); }
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f32(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xF, false));
+}
+// reduction over the 16 lanes of each DPP row; every lane of a row ends with its row's result
+template <int OP> __device__ __forceinline__ float row_reduce(float v)
+{
+    const float id = red_identity<OP>();
+    v = red_op<OP>(v, dpp_f32<0xB1, 0xF>(id, v));     // quad_perm [1,0,3,2]
+    v = red_op<OP>(v, dpp_f32<0x4E, 0xF>(id, v));     // quad_perm [2,3,0,1]
+    v = red_op<OP>(v, dpp_f32<0x141, 0xF>(id, v));    // row_half_mirror
+    v = red_op<OP>(v, dpp_f32<0x140, 0xF>(id, v));    // row_mirror
+    return v;
+}
+// reduction over the wave; the (wave-uniform) result is returned to every lane
+template <int OP> __device__ __forceinline__ float wave_reduce(float v)
+{
+    const float id = red_identity<OP>();
+    v = row_reduce<OP>(v);
+    v = red_op<OP>(v, dpp_f32<0x142, 0xA>(id, v));    // row_bcast15: rows 1, 3 take in rows 0, 2
+    v = red_op<OP>(v, dpp_f32<0x143, 0xC>(id, v));    // row_bcast31: rows 2, 3 take in lane 31 (rows 0 + 1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ float wave_min_f32(float v)
 {
 #pragma unroll
@@ -184,10 +224,14 @@ __device__ __forceinline__ void resolve_carries(const PendingSplat& ps, float* _
 // Phase 1 of the windowed kernels: bounding box (in un-flipped bitmap coordinates) of where the
 // workgroup's rays can land, clipped to `tile_cap` pixels, plus the fixed-point scale of the forward
 // accumulator.  Result is left in *s_win after a __syncthreads().
+// A thread's first surface point and its first distortion sample, loaded by the caller ahead of phase 1.
+struct FirstPoint { float4 o, n; float u, e; };
+
 template <bool INTERLEAVED, bool CYL>
 __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& pl, const Cyl& cy, const float4 inc,
                                                const float4* __restrict__ org, const float4* __restrict__ nrm,
-                                               int p0, int p1, int64_t dbase, float (*s_red)[16], Window* s_win)
+                                               int p0, int p1, int64_t dbase, float (*s_red)[16], Window* s_win,
+                                               const FirstPoint* first = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     // ke / ku: metres of hit-point travel along world E / U per radian of scatter, |t| sqrt(1 + (r_E/a)^2):
@@ -195,8 +239,9 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
     float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, ke = 0.0f, ku = 0.0f, angmax = 0.0f;
     float dmax2 = 0.0f, esum = 0.0f, usum = 0.0f, cnt = 0.0f, esq = 0.0f, usq = 0.0f;
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
-        const float4 o = org[p];
-        const float4 n = nrm[p];
+        const bool pre = first != nullptr && p == p0 + tid;       // this thread's first point came with the caller
+        const float4 o = pre ? first->o : org[p];
+        const float4 n = pre ? first->n : nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
         dmax2 = fmaxf(dmax2, d.x * d.x + d.y * d.y + d.z * d.z);
@@ -224,27 +269,33 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             ku = fmaxf(ku, hku);
         }
         float u, e;
-        load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e);
+        if (pre) { u = first->u; e = first->e; }
+        else load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e);
         angmax = fmaxf(angmax, fmaxf(fabsf(u), fabsf(e)));
     }
-    emin = wave_min_f32(emin); emax = wave_max_f32(emax); umin = wave_min_f32(umin); umax = wave_max_f32(umax);
-    ke = wave_max_f32(ke); ku = wave_max_f32(ku); angmax = wave_max_f32(angmax); dmax2 = wave_max_f32(dmax2);
-    esum = wave_sum_all_f32(esum); usum = wave_sum_all_f32(usum); cnt = wave_sum_all_f32(cnt);
-    esq = wave_sum_all_f32(esq); usq = wave_sum_all_f32(usq);
+    emin = wave_reduce<kMin>(emin); emax = wave_reduce<kMax>(emax); umin = wave_reduce<kMin>(umin); umax = wave_reduce<kMax>(umax);
+    ke = wave_reduce<kMax>(ke); ku = wave_reduce<kMax>(ku); angmax = wave_reduce<kMax>(angmax); dmax2 = wave_reduce<kMax>(dmax2);
+    esum = wave_reduce<kSum>(esum); usum = wave_reduce<kSum>(usum); cnt = wave_reduce<kSum>(cnt);
+    esq = wave_reduce<kSum>(esq); usq = wave_reduce<kSum>(usq);
     if (lane == 0) {
         s_red[8][wave] = esum; s_red[9][wave] = usum; s_red[10][wave] = cnt; s_red[11][wave] = esq; s_red[12][wave] = usq;
         s_red[0][wave] = emin; s_red[1][wave] = emax; s_red[2][wave] = umin; s_red[3][wave] = umax;
         s_red[4][wave] = ke; s_red[5][wave] = ku; s_red[6][wave] = angmax; s_red[7][wave] = dmax2;
     }
     __syncthreads();
+    if (wave == 0) {
+        // the (at most 16) wave partials sit in the lanes of DPP row 0: one row reduction per quantity
+        const bool has = lane < nwaves;
+        const int w = has ? lane : 0;
+        emin = row_reduce<kMin>(has ? s_red[0][w] : 3.0e38f); emax = row_reduce<kMax>(has ? s_red[1][w] : -3.0e38f);
+        umin = row_reduce<kMin>(has ? s_red[2][w] : 3.0e38f); umax = row_reduce<kMax>(has ? s_red[3][w] : -3.0e38f);
+        ke = row_reduce<kMax>(has ? s_red[4][w] : -3.0e38f); ku = row_reduce<kMax>(has ? s_red[5][w] : -3.0e38f);
+        angmax = row_reduce<kMax>(has ? s_red[6][w] : -3.0e38f); dmax2 = row_reduce<kMax>(has ? s_red[7][w] : -3.0e38f);
+        esum = row_reduce<kSum>(has ? s_red[8][w] : 0.0f); usum = row_reduce<kSum>(has ? s_red[9][w] : 0.0f);
+        cnt = row_reduce<kSum>(has ? s_red[10][w] : 0.0f); esq = row_reduce<kSum>(has ? s_red[11][w] : 0.0f);
+        usq = row_reduce<kSum>(has ? s_red[12][w] : 0.0f);
+    }
     if (tid == 0) {
-        for (int w = 1; w < nwaves; ++w) {
-            emin = fminf(emin, s_red[0][w]); emax = fmaxf(emax, s_red[1][w]);
-            umin = fminf(umin, s_red[2][w]); umax = fmaxf(umax, s_red[3][w]);
-            ke = fmaxf(ke, s_red[4][w]); ku = fmaxf(ku, s_red[5][w]); angmax = fmaxf(angmax, s_red[6][w]);
-            dmax2 = fmaxf(dmax2, s_red[7][w]);
-            esum += s_red[8][w]; usum += s_red[9][w]; cnt += s_red[10][w]; esq += s_red[11][w]; usq += s_red[12][w];
-        }
         Window win = {0, 0, 0, 0, 0, 1, 1.0f, 1.0f, 0.0f};
         if (emax >= emin) {
             // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
@@ -311,6 +362,18 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
 }
 
 // Blocking rectangles of one heliostat in LDS (empty when the kernel is instantiated without blocking).
+#ifdef ART_DEBUG_TIMELINE   // diagnostic build (tools/timeline.sh): phase time stamps of every forward workgroup
+constexpr int kTimelineSlots = 16384;
+__device__ unsigned long long g_timeline[8 * kTimelineSlots];
+__device__ __forceinline__ void timeline_mark(int slot, int k)
+{
+    if (threadIdx.x == 0 && slot < kTimelineSlots) g_timeline[8 * slot + k] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+}
+#define ART_TIMELINE(k) timeline_mark(bid, k)
+#else
+#define ART_TIMELINE(k)
+#endif
+
 template <bool BLOCKING> struct PrimTable { Prim prim[kMaxCand]; int id[kMaxCand]; float grad[kMaxCand * 12]; };
 template <> struct PrimTable<false> { Prim prim[1]; int id[1]; float grad[1]; };
 
@@ -330,9 +393,36 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
     return n;
 }
 
+// Work items of the windowed kernels.  A CU holds one workgroup (the window fills its LDS), so the grid is one
+// PERSISTENT workgroup per CU that pulls (heliostat, point block, sample chunk) items from a counter in global memory:
+//   * no dispatcher between two items (measured with tools/timeline.sh: 5 us mean, 30 % of the hand-overs > 5 us),
+//   * the eight XCDs share one queue (the hardware deals every eighth workgroup to an XCD, whatever their length),
+//   * the last n_tail items are dealt as two halves of their sample range: the kernel ends within half an item.
+// Item numbering: [0, n_base - n_tail) whole items, then 2 n_tail halves.
+struct WorkItem { int h, pblock, r0, r1; };
+__device__ __forceinline__ int work_item_count(const TraceArgs& a) { return a.H * a.n_pblocks * a.n_rchunks + a.n_tail; }
+__device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int item)
+{
+    const int n_whole = a.H * a.n_pblocks * a.n_rchunks - a.n_tail;
+    int base = item, half = -1;
+    if (item >= n_whole) { base = n_whole + ((item - n_whole) >> 1); half = (item - n_whole) & 1; }
+    WorkItem w;
+    const int rchunk = base % a.n_rchunks;
+    w.pblock = (base / a.n_rchunks) % a.n_pblocks;
+    w.h = base / (a.n_rchunks * a.n_pblocks);
+    w.r0 = rchunk * a.r_chunk;
+    w.r1 = min(w.r0 + a.r_chunk, a.R);
+    if (half >= 0) {
+        const int mid = min(w.r0 + (((w.r1 - w.r0) / 2 + 3) & ~3), w.r1);      // whole groups of four samples first
+        if (half == 0) w.r1 = mid; else w.r0 = mid;
+    }
+    return w;
+}
+
 template <bool INTERLEAVED, bool CYL, bool BLOCKING>
-__global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float* __restrict__ flux,
-                                                             unsigned int* __restrict__ counts)
+__device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
+                                               const int bid, const WorkItem item, unsigned int* __restrict__ work_counter,
+                                               int* s_next)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned tile[];
     __shared__ float s_red[13][16];    // per-wave partials: emin, emax, umin, umax, ke, ku, angmax, dmax2, sums
@@ -340,14 +430,15 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     __shared__ unsigned s_cnt[3];
     __shared__ PrimTable<BLOCKING> s_tab;
 
-    const int bid = blockIdx.x;
-    const int rchunk = bid % a.n_rchunks;
-    const int pblock = (bid / a.n_rchunks) % a.n_pblocks;
-    const int h = bid / (a.n_rchunks * a.n_pblocks);
+    const int pblock = item.pblock;
+    const int h = item.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    if ((t >= a.T) != CYL) return;    // workgroup-uniform: the other instantiation's launch owns this heliostat
+    if ((t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: the other instantiation's launch owns this heliostat
+        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+        return;
+    }
     Plane pl; Cyl cy;
     if constexpr (CYL) cy = load_cyl(a.cyl_centers, a.cyl_normals, a.cyl_axes, a.cyl_radii, a.cyl_heights, a.cyl_opening,
                                      t - a.T, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
@@ -357,17 +448,49 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     const float4 inc = a.incident[h];
     const int p0 = pblock * a.p_block;
     const int p1 = min(p0 + a.p_block, a.P);
-    const int r0 = rchunk * a.r_chunk;
-    const int r1 = min(r0 + a.r_chunk, a.R);
+    const int r0 = item.r0;
+    const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
     // ---- phase 1: window ---------------------------------------------------------------------
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |   // XCC_ID
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                         // HW_ID
+#endif
+    ART_TIMELINE(1);
+#ifdef ART_DEBUG_TIMELINE
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();       // shader clock
+#endif
     if (tid < 3) s_cnt[tid] = 0;
+    // This thread's first point and its first four distortion samples are requested before anything else, and the
+    // tile is cleared while they are in flight: a CU holds ONE workgroup (the window fills its LDS), so every
+    // microsecond of latency in this prologue is a microsecond of idle VALUs (tools/timeline.sh).
+    const int pf = p0 + tid;
+    const int nr_all = r1 - r0;
+    FirstPoint fp = {{0.0f, 0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f, 0.0f}, 0.0f, 0.0f};
+    float fu1 = 0.0f, fe1 = 0.0f, fu2 = 0.0f, fe2 = 0.0f, fu3 = 0.0f, fe3 = 0.0f;
+    if (pf < p1) {
+        fp.o = org[pf]; fp.n = nrm[pf];
+        const float* __restrict__ bu_ = a.dist_u + dbase;
+        const float* __restrict__ be_ = a.dist_e + dbase;
+        const int lane_off = pf * (int)a.sp;
+        load_dist_row<INTERLEAVED>(bu_, be_, lane_off, fp.u, fp.e);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr_all - 1) * a.sr, be_ + (int64_t)min(1, nr_all - 1) * a.sr, lane_off, fu1, fe1);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr_all - 1) * a.sr, be_ + (int64_t)min(2, nr_all - 1) * a.sr, lane_off, fu2, fe2);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr_all - 1) * a.sr, be_ + (int64_t)min(3, nr_all - 1) * a.sr, lane_off, fu3, fe3);
+    }
+    {   // 16-byte stores (tile_cap is a multiple of 256 cells) + the two spare cells behind the window
+        uint4* t4 = reinterpret_cast<uint4*>(tile);
+        for (int i = tid; i < a.tile_cap / 4; i += blockDim.x) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 2) tile[a.tile_cap + tid] = 0u;
+    }
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
-    compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
+    compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
+    ART_TIMELINE(2);
     const unsigned twm1 = (unsigned)(win.tw - 1), uthm1 = (unsigned)(win.th - 1);
     const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
     const float Wf = (float)a.W, Hf = (float)a.Hh;
@@ -384,9 +507,12 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     const bool first = pass == 0;
     unsigned n_valid = 0, n_int = 0;     // rays with I0 > 0 / I > 0 among the valid ones (wave totals)
     unsigned n_free = 0;                 // rays with blocked < 1e-3 (heliostat_ray_tracer.py:501-503)
-    const int npx = win.tw * pth;
-    for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
-    __syncthreads();
+    if (!first) {                          // pass 0 starts on the tile cleared in the prologue
+        const int npx = win.tw * pth;
+        for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
+        __syncthreads();
+    }
+    ART_TIMELINE(3);
 
     // ---- phase 2: trace ----------------------------------------------------------------------
     // Every ray issues its four LDS adds unconditionally: rays that are off the bitmap or outside the
@@ -394,8 +520,9 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
     // in-bitmap-but-outside-window ray goes to global memory.
     PendingSplat ps = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
-        const float4 o = org[p];
-        const float4 n = nrm[p];
+        const bool pre = first && p == pf;                 // loaded in the prologue
+        const float4 o = pre ? fp.o : org[p];
+        const float4 n = pre ? fp.n : nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
         float numer = 0.0f; CylPoint cp;
@@ -511,11 +638,18 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
         const float* __restrict__ bu_ = a.dist_u + dbase;     // wave-uniform
         const float* __restrict__ be_ = a.dist_e + dbase;
         float cu0, ce0, cu1, ce1, cu2, ce2, cu3, ce3;
-        load_dist_row<INTERLEAVED>(bu_, be_, lane_off, cu0, ce0);
-        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr - 1) * a.sr, be_ + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
-        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr - 1) * a.sr, be_ + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
-        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr - 1) * a.sr, be_ + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
+        if (pre) {
+            cu0 = fp.u; ce0 = fp.e; cu1 = fu1; ce1 = fe1; cu2 = fu2; ce2 = fe2; cu3 = fu3; ce3 = fe3;
+        } else {
+            load_dist_row<INTERLEAVED>(bu_, be_, lane_off, cu0, ce0);
+            load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr - 1) * a.sr, be_ + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
+            load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr - 1) * a.sr, be_ + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
+            load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr - 1) * a.sr, be_ + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
+        }
         for (int k = 0; k < nr; k += 4) {
+#ifdef ART_DEBUG_TIMELINE
+            if (k == 4 && p == p0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)"); ART_TIMELINE(4); }   // first group traced
+#endif
             float nu0, ne0, nu1, ne1, nu2, ne2, nu3, ne3;
             const int64_t o4 = (int64_t)min(k + 4, nr - 1) * a.sr, o5 = (int64_t)min(k + 5, nr - 1) * a.sr;
             const int64_t o6 = (int64_t)min(k + 6, nr - 1) * a.sr, o7 = (int64_t)min(k + 7, nr - 1) * a.sr;
@@ -551,6 +685,10 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
 #endif
     }
     __syncthreads();
+    ART_TIMELINE(5);
+    // the next work item is requested now and published after the flush: the counter's round trip hides behind it
+    unsigned next_item = 0u;
+    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
 
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
     for (int row = wave; row < pth; row += nwaves) {
@@ -565,9 +703,30 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float*
 #endif
         }
     }
+    if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();   // the band is flushed before the next pass re-zeroes the tile
+    ART_TIMELINE(6);
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots) g_timeline[8 * bid + 7] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
   }
     if (tid < 3 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
+}
+
+template <bool INTERLEAVED, bool CYL, bool BLOCKING>
+__global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float* __restrict__ flux,
+                                                             unsigned int* __restrict__ counts,
+                                                             unsigned int* __restrict__ work_counter)
+{
+    __shared__ int s_next;
+    const int n_items = work_item_count(a);
+    int item = blockIdx.x;                       // the first gridDim.x items need no counter
+    while (item < n_items) {                     // workgroup-uniform: `item` comes from LDS
+        trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(a, flux, counts, item, decode_work_item(a, item), work_counter, &s_next);
+        __syncthreads();
+        item = s_next;
+        __syncthreads();                         // everybody has read s_next before the next item may overwrite it
+    }
 }
 
 // counts (uint32, rows 0,1 of factors) -> fractions (heliostat_ray_tracer.py:498-506).
@@ -1046,6 +1205,7 @@ struct FwdConfig {
     int min_chunk;      // fewest samples per workgroup worth a window build + flush
     int p_block;        // target points per workgroup, forward
     int p_block_bwd;    // ... backward (gathers are cheaper than atomics when a ray strays: larger blocks pay)
+    bool p_block_fixed, p_block_bwd_fixed;   // set by the environment: no adaptation to the grid size
     int multipass_ratio;
     int min_rays;       // rays per workgroup worth a window build + flush
 };
@@ -1066,6 +1226,8 @@ static FwdConfig fwd_config()
     c.min_rays = env_int("ARTIST_HIP_FWD_MINRAYS", 100000);
     c.multipass_ratio = env_int("ARTIST_HIP_FWD_MULTIPASS", 2);
     if (c.multipass_ratio < 1) c.multipass_ratio = 1;
+    c.p_block_fixed = getenv("ARTIST_HIP_FWD_PBLOCK") != nullptr;
+    c.p_block_bwd_fixed = getenv("ARTIST_HIP_BWD_PBLOCK") != nullptr;
     c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
     if (c.p_block < 64) c.p_block = 64;
     c.p_block_bwd = env_int("ARTIST_HIP_BWD_PBLOCK", 2048);
@@ -1073,10 +1235,68 @@ static FwdConfig fwd_config()
     return c;
 }
 
-// Launch geometry of the windowed kernels.  p_block: a multiple of the block size close to
+static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_target);
+
+// Work counters of the persistent kernels: 4 KB of device memory per GPU, allocated on the first trace call and kept
+// for the life of the process.  Each launch takes the next of 1024 slots and zeroes it on its stream.
+static unsigned* next_work_counter(hipStream_t stream)
+{
+    constexpr int kSlots = 1024, kMaxDevices = 64;
+    static unsigned* base[kMaxDevices] = {};
+    static std::atomic<unsigned> seq{0};
+    static std::mutex lock;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    {
+        std::lock_guard<std::mutex> guard(lock);
+        if (base[dev] == nullptr && hipMalloc(reinterpret_cast<void**>(&base[dev]), sizeof(unsigned) * kSlots) != hipSuccess) {
+            base[dev] = nullptr;
+            return nullptr;
+        }
+    }
+    unsigned* slot = base[dev] + (seq.fetch_add(1) % kSlots);
+    if (hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return nullptr;
+    return slot;
+}
+
+// Workgroups that run at once: one per CU (a window fills the CU's LDS).
+static int resident_workgroups()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0)
+            cus = 256;
+        n = cus;
+    }
+    return n;
+}
+
+// Launch geometry of the windowed kernels.  The configured point-block size is the best one for a field that fills the
+// chip many times over; for a small share of a field (one of eight ranks: 125 heliostats) the number of ROUNDS of
+// resident workgroups decides: 625 workgroups of 2048 points are 2.44 rounds on 256 CUs and cost 3, 1250 of 1024
+// points are 4.88 rounds and cost 5 of half the length.  Model: rounds x (rays per workgroup + window build and flush,
+// worth ~1.5e4 rays); candidates = the configured size and half of it.
+static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_target, bool fixed)
+{
+    window_geometry_for(a, cfg, p_block_target);
+    if (fixed || p_block_target / 2 < cfg.block) return;
+    auto cost = [&](const TraceArgs& g) {
+        const int64_t wgs = (int64_t)g.H * g.n_pblocks * g.n_rchunks;
+        const int64_t rounds = (wgs + resident_workgroups() - 1) / resident_workgroups();
+        const int points = (g.P + g.n_pblocks - 1) / g.n_pblocks;
+        return (double)rounds * ((double)points * g.r_chunk + 1.5e4);
+    };
+    TraceArgs half = a;
+    window_geometry_for(half, cfg, p_block_target / 2);
+    if (cost(half) < 0.97 * cost(a)) a = half;
+}
+
+// Geometry for one point-block size.  p_block: a multiple of the block size close to
 // P / ceil(P / 2048) so that point blocks are balanced; samples are chunked only as far as needed to
 // fill the chip (each chunk pays a window build + flush).
-static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_target)
+static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_target)
 {
     const int bs = cfg.block;
     // a window build + flush costs about as much as 1e4 rays: keep >= ~1e5 rays per workgroup when the sun has
@@ -1097,6 +1317,9 @@ static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_targ
     if (chunk > a.R) chunk = a.R;
     a.r_chunk = chunk;
     a.n_rchunks = (a.R + chunk - 1) / chunk;
+    // the last items of the queue are dealt in halves (decode_work_item) when a chunk has samples to split
+    const int64_t n_base = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
+    a.n_tail = chunk >= 8 ? (int)std::min<int64_t>(n_base, resident_workgroups()) : 0;
 }
 
 }  // namespace art
@@ -1142,10 +1365,10 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     FwdConfig cfg = fwd_config();
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
-        window_geometry(a, cfg, cfg.p_block);
-        const int64_t base = (int64_t)a.H * a.n_pblocks;
-        const int64_t blocks = base * a.n_rchunks;
-        if (blocks > 2147483647LL) return ART_EINVAL;
+        window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
+        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
+        if (items > 2147483647LL - 65536) return ART_EINVAL;
+        const int64_t blocks = std::min<int64_t>(items, resident_workgroups());      // persistent: one workgroup per CU
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
         // exits at once (the type is only known on the device)
@@ -1153,8 +1376,10 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         do {                                                                                                     \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL>),        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            unsigned* work_counter = next_work_counter(stream);                                                  \
+            if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
             hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL>), dim3((unsigned)blocks), dim3(cfg.block), lds, \
-                               stream, a, flux, counts);                                                         \
+                               stream, a, flux, counts, work_counter);                                           \
         } while (0)
 #define ART_LAUNCH_FWD_TYPE(CY)                                                                                  \
         do {                                                                                                     \
@@ -1182,6 +1407,15 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     hipLaunchKernelGGL(finalize_factors_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, factors,
                        (int)H, (float)(R * P), blocking ? 1 : 0);
     ART_HIP(hipGetLastError());
+#ifdef ART_DEBUG_TIMELINE
+    if (const char* out = getenv("ART_TIMELINE_OUT")) {     // the last call's records: [blocks][8] u64, raw
+        const int64_t n = std::min<int64_t>((int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail, kTimelineSlots);
+        std::vector<unsigned long long> host(8 * n);
+        ART_HIP(hipStreamSynchronize(stream));
+        ART_HIP(hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * n));
+        if (FILE* f = fopen(out, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
+    }
+#endif
     return ART_OK;
 }
 
@@ -1225,7 +1459,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     FwdConfig cfg = fwd_config();
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
-        window_geometry(a, cfg, cfg.p_block_bwd);
+        window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         const int64_t blocks = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (blocks > 2147483647LL) return ART_EINVAL;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float);

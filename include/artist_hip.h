@@ -76,6 +76,8 @@ int art_last_hip_error(void);
  *                     1: flux is [T+Tc,Hh,W] (summed per target area)
  *   flux              output, zero-filled then accumulated; rows already up-down flipped
  *   factors           output [3,H]: intercept, on_target, blocking fractions
+ * Device memory: every buffer is the caller's, except 4 KB per GPU that the library allocates on the first trace
+ * call and keeps (work counters of its persistent workgroups, one slot per launch, zeroed on the launch stream).
  * ------------------------------------------------------------------------------------------- */
 int art_trace_fwd(const float *origins, const float *normals, const float *incident,
                   const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
