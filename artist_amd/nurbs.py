@@ -11,6 +11,23 @@ import torch
 from . import ops
 
 
+_KNOT_CACHE: dict = {}
+_DEGREE_CACHE: dict = {}
+
+
+def _host_degrees(degrees: torch.Tensor) -> tuple[int, int]:
+    """``(p, q)`` as Python ints.  Reading a device tensor is a stream synchronisation, which would stop the host
+    from running ahead of the GPU once per epoch: the values are remembered per (storage, version)."""
+    if degrees.device.type == "cpu":
+        return int(degrees[0]), int(degrees[1])
+    key = (degrees.data_ptr(), degrees._version, str(degrees.device))
+    if key not in _DEGREE_CACHE:
+        if len(_DEGREE_CACHE) > 256:
+            _DEGREE_CACHE.clear()
+        _DEGREE_CACHE[key] = (int(degrees[0]), int(degrees[1]))
+    return _DEGREE_CACHE[key]
+
+
 class NURBSSurfaces(torch.nn.Module):
     """See ``artist/nurbs/surfaces.py:8-96`` for the attribute documentation.
 
@@ -27,7 +44,7 @@ class NURBSSurfaces(torch.nn.Module):
         self.uniform = uniform
         self.number_of_surfaces = self.control_points.shape[0]
         self.number_of_facets_per_surface = self.control_points.shape[1]
-        self._degrees_host = (int(degrees[0]), int(degrees[1]))
+        self._degrees_host = _host_degrees(degrees)
         self.knot_vectors_u = self.calculate_uniform_knot_vectors(direction=0, device=device)
         self.knot_vectors_v = self.calculate_uniform_knot_vectors(direction=1, device=device)
         # torch.unique(knot_vectors, dim=2) of the reference (surfaces.py:199) counted analytically for
@@ -40,9 +57,16 @@ class NURBSSurfaces(torch.nn.Module):
         (artist/nurbs/surfaces.py:98-155)."""
         degree = self._degrees_host[direction]
         n = self.control_points.shape[2 + direction]
-        knot_vector = torch.zeros(n + degree + 1, device=device)
-        knot_vector[degree:-degree] = torch.linspace(0, 1, n - degree + 1, device=device)
-        knot_vector[-degree:] = 1
+        key = (n, degree, str(device))
+        knot_vector = _KNOT_CACHE.get(key)
+        if knot_vector is None:
+            # a reconstruction loop builds a NURBSSurfaces per epoch (surface_reconstructor.py:516-531): the knots
+            # depend on the sizes only, so they are built once per (size, degree, device) - five tiny kernels less
+            # per direction and epoch.  The cached tensor is shared: replace the attribute, never write into it.
+            knot_vector = torch.zeros(n + degree + 1, device=device)
+            knot_vector[degree:-degree] = torch.linspace(0, 1, n - degree + 1, device=device)
+            knot_vector[-degree:] = 1
+            _KNOT_CACHE[key] = knot_vector
         # expand() instead of repeat(): identical values, no H*F copies in HBM
         return knot_vector.unsqueeze(0).unsqueeze(0).expand(
             self.number_of_surfaces, self.number_of_facets_per_surface, -1)

@@ -9,8 +9,8 @@ step     : one surface-reconstruction epoch over the whole field
            NURBS points+normals (HIP) -> alignment (HIP) -> trace_rays (HIP) -> per-target sum ->
            [N>1: RCCL all_reduce of the [T,256,256] flux] -> crop around the centre of mass (HIP) -> PixelLoss
            vs fixed measured bitmaps (HIP) -> backward (loss, crop, trace_bwd, alignment, nurbs_bwd: all HIP)
-           -> [N>1: RCCL all_reduce of the
-           control-point gradients, like surface_reconstructor.py:767-777].
+           -> [N>1: RCCL exchange of the control-point gradients (surface_reconstructor.py:767-777; the shards are
+           row-disjoint, so the reference's all_reduce(SUM) is issued as an all-gather)] -> Adam step (:779).
            Inputs (control points, orientations, distortions) are resident in HBM before timing.
 N GPUs   : heliostats are sharded over ranks exactly like RestrictedDistributedSampler
            (heliostat i -> rank i mod N); total work is fixed  => "scaling": "strong".
@@ -114,7 +114,7 @@ def main():
             dist.init_process_group(backend)
 
     from artist_amd import HeliostatRayTracer, NURBSSurfaces
-    from artist_amd.distributed import all_reduce_sum, all_reduce_sum_async, owned_heliostats
+    from artist_amd.distributed import all_reduce_sum_async, gather_owned_rows, owned_heliostats
     from artist_amd.scene import build_synthetic_scenario
 
     H_total, R, n_eval = args.heliostats, args.rays, args.n_eval
@@ -159,8 +159,7 @@ def main():
         return flux, factors
 
     def step(backward=True):
-        if cp.grad is not None:
-            cp.grad = None
+        optimizer.zero_grad(set_to_none=True)
         with torch.set_grad_enabled(backward):
             flux, _ = forward()
             per_target = ops.per_target_sum(flux.detach(), tix, T)
@@ -171,13 +170,20 @@ def main():
                 cropped = FluxCrop.apply(flux, crop_dims, 6.0, 6.0)
                 loss = pixel_loss(cropped, target, reduction_dimensions=(1, 2)).sum()
                 loss.backward()
-                full = torch.zeros_like(cp_all)
-                full[own_t] = cp.grad
-                all_reduce_sum(full)                             # surface_reconstructor.py:767-777
+                # surface_reconstructor.py:767-777: every rank ends with the field's gradient.  The shards are
+                # row-disjoint, so the reference's all_reduce(SUM) is an all-gather of the own rows (half the bytes)
+                field_grad = gather_owned_rows(cp.grad, H_total)
+                optimizer.step()                                 # :779 - Adam on the rows this rank owns
+                del field_grad
             if pending is not None:
                 pending.wait()
         return per_target
 
+    # the reconstructor's optimiser (surface_reconstructor.py:452-455); a small rate keeps the workload stationary
+    try:
+        optimizer = torch.optim.Adam([cp], lr=1e-6, fused=True)
+    except (RuntimeError, TypeError):
+        optimizer = torch.optim.Adam([cp], lr=1e-6)
     crop_dims = planar.dimensions.index_select(0, tix.long()).contiguous()
     pixel_loss = PixelLoss()
     with torch.no_grad():

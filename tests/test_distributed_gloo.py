@@ -27,7 +27,7 @@ def _free_port():
 def _worker(rank, world, port, case, out_dir):
     import oracle
     from artist_amd import RestrictedDistributedSampler
-    from artist_amd.distributed import all_reduce_sum, owned_heliostats, reduce_flux_per_target
+    from artist_amd.distributed import all_reduce_sum, gather_owned_rows, owned_heliostats, reduce_flux_per_target
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -70,6 +70,11 @@ def _worker(rank, world, port, case, out_dir):
         g[own] = torch.arange(H, dtype=torch.float32)[own, None] + 1
         all_reduce_sum(g)
         assert torch.equal(g, (torch.arange(H, dtype=torch.float32) + 1)[:, None].expand(H, 3))
+        # ... which gather_owned_rows exploits (even shards: all-gather; ragged: the all-reduce above)
+        for n_rows in (world * 4, world * 4 + 1):
+            want = (torch.arange(n_rows, dtype=torch.float32) + 1)[:, None, None].expand(n_rows, 2, 3)
+            got = gather_owned_rows(want[owned_heliostats(n_rows, world, rank)].contiguous(), n_rows)
+            assert torch.equal(got, want), (n_rows, got[:, 0, 0])
         (out_dir / f"ok_{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
