@@ -397,9 +397,10 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
 // PERSISTENT workgroup per CU that pulls (heliostat, point block, sample chunk) items from a counter in global memory:
 //   * no dispatcher between two items (measured with tools/timeline.sh: 5 us mean, 30 % of the hand-overs > 5 us),
 //   * the eight XCDs share one queue (the hardware deals every eighth workgroup to an XCD, whatever their length),
-//   * the last n_tail items are dealt as two halves of their sample range: the kernel ends within half an item.
+//   * optionally (ARTIST_HIP_TAIL=1) the last n_tail items are dealt as two halves of their sample range, so that the
+//     kernel ends within half an item; neutral on the metric field, off by default.
 // Item numbering: [0, n_base - n_tail) whole items, then 2 n_tail halves.
-struct WorkItem { int h, pblock, r0, r1; };
+struct WorkItem { int h, pblock, r0, r1; bool half; };   // half: one of the two halves of a tail item
 __device__ __forceinline__ int work_item_count(const TraceArgs& a) { return a.H * a.n_pblocks * a.n_rchunks + a.n_tail; }
 __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int item)
 {
@@ -412,6 +413,7 @@ __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int ite
     w.h = base / (a.n_rchunks * a.n_pblocks);
     w.r0 = rchunk * a.r_chunk;
     w.r1 = min(w.r0 + a.r_chunk, a.R);
+    w.half = half >= 0;
     if (half >= 0) {
         const int mid = min(w.r0 + (((w.r1 - w.r0) / 2 + 3) & ~3), w.r1);      // whole groups of four samples first
         if (half == 0) w.r1 = mid; else w.r0 = mid;
@@ -874,25 +876,28 @@ __device__ __attribute__((noinline)) void block_adjoint(const Prim* __restrict__
 // (The cylinder and blocking instantiations keep ~60 more live values per ray; they run 512-thread workgroups =
 // 256 VGPRs.)
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
-__global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
-                                                             float4* __restrict__ grad_origins,
-                                                             float4* __restrict__ grad_normals,
-                                                             float* __restrict__ g_corners, float* __restrict__ g_spans,
-                                                             float* __restrict__ g_pnormals)
+__device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* __restrict__ grad_flux,
+                                               float4* __restrict__ grad_origins, float4* __restrict__ grad_normals,
+                                               float* __restrict__ g_corners, float* __restrict__ g_spans,
+                                               float* __restrict__ g_pnormals, const WorkItem item,
+                                               unsigned int* __restrict__ work_counter, int* s_next)
 {
     extern __shared__ __attribute__((aligned(16))) float gtile[];
     __shared__ float s_red[13][16];
     __shared__ Window s_win;
     __shared__ PrimTable<BLOCKING> s_tab;
 
-    const int bid = blockIdx.x;
-    const int rchunk = bid % a.n_rchunks;
-    const int pblock = (bid / a.n_rchunks) % a.n_pblocks;
-    const int h = bid / (a.n_rchunks * a.n_pblocks);
+    const int pblock = item.pblock;
+    const int h = item.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    // the two halves of a tail item add their gradients to rows the host has zeroed
+    const bool atomic_item = ATOMIC_OUT || item.half;
 
     const int t = a.target_idx[h];
-    if ((t >= a.T) != CYL) return;    // workgroup-uniform: the other instantiation's launch owns this heliostat
+    if ((t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: the other instantiation's launch owns this heliostat
+        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+        return;
+    }
     Plane pl; Cyl cy;
     if constexpr (CYL) cy = load_cyl(a.cyl_centers, a.cyl_normals, a.cyl_axes, a.cyl_radii, a.cyl_heights, a.cyl_opening,
                                      t - a.T, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
@@ -901,8 +906,8 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
     const float4 inc = a.incident[h];
     const int p0 = pblock * a.p_block;
     const int p1 = min(p0 + a.p_block, a.P);
-    const int r0 = rchunk * a.r_chunk;
-    const int r1 = min(r0 + a.r_chunk, a.R);
+    const int r0 = item.r0;
+    const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
@@ -910,10 +915,13 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
+    unsigned next_item = 0u;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
     const int pth = min(win.ths, win.u0 + win.th - pu0);
     const bool first = pass == 0;
+    // the next work item is requested at the start of the last pass and published at its end
+    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
     // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped
     for (int row = wave; row < pth; row += nwaves) {
         const float* g = G + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
@@ -1108,7 +1116,7 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
         const int64_t idx = (int64_t)h * a.P + p;
-        if constexpr (ATOMIC_OUT) {
+        if (atomic_item) {
             float* po = reinterpret_cast<float*>(grad_origins + idx);
             float* pn = reinterpret_cast<float*>(grad_normals + idx);
             atomicAdd(po + 0, go.x); atomicAdd(po + 1, go.y); atomicAdd(po + 2, go.z);
@@ -1122,8 +1130,10 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
             grad_normals[idx] = make_float4(n0.x + gn.x, n0.y + gn.y, n0.z + gn.z, n0.w + gn.w);
         }
     }
+    if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();   // every wave is done with this band before it is overwritten
   }
+    if (win.npass < 1 && tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));   // (never: npass >= 1)
     if constexpr (BLOCKING) {      // rectangle gradients of this workgroup -> the primitive tables
         for (int c = tid; c < n_prims * 12; c += blockDim.x) {
             const float v = s_tab.grad[c];
@@ -1136,6 +1146,27 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
                                    : g_pnormals + 4 * id + comp;
             atomicAdd(dst, v);
         }
+    }
+}
+
+// Persistent workgroups over the work-item queue, like the forward kernel.
+template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
+__global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
+                                                             float4* __restrict__ grad_origins,
+                                                             float4* __restrict__ grad_normals,
+                                                             float* __restrict__ g_corners, float* __restrict__ g_spans,
+                                                             float* __restrict__ g_pnormals,
+                                                             unsigned int* __restrict__ work_counter)
+{
+    __shared__ int s_next;
+    const int n_items = work_item_count(a);
+    int item = blockIdx.x;
+    while (item < n_items) {
+        trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
+                                                               g_pnormals, decode_work_item(a, item), work_counter, &s_next);
+        __syncthreads();
+        item = s_next;
+        __syncthreads();
     }
 }
 
@@ -1319,7 +1350,8 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     a.n_rchunks = (a.R + chunk - 1) / chunk;
     // the last items of the queue are dealt in halves (decode_work_item) when a chunk has samples to split
     const int64_t n_base = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
-    a.n_tail = chunk >= 8 ? (int)std::min<int64_t>(n_base, resident_workgroups()) : 0;
+    // (measured neutral on the metric field - 1000 and 125 heliostats - so it is off unless ARTIST_HIP_TAIL=1)
+    a.n_tail = chunk >= 8 && env_int("ARTIST_HIP_TAIL", 0) != 0 ? (int)std::min<int64_t>(n_base, resident_workgroups()) : 0;
 }
 
 }  // namespace art
@@ -1368,7 +1400,8 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
-        const int64_t blocks = std::min<int64_t>(items, resident_workgroups());      // persistent: one workgroup per CU
+        // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
+        const int64_t blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items, resident_workgroups()) : items;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
         // exits at once (the type is only known on the device)
@@ -1460,22 +1493,32 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
-        const int64_t blocks = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
-        if (blocks > 2147483647LL) return ART_EINVAL;
+        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
+        if (items > 2147483647LL - 65536) return ART_EINVAL;
+        const int64_t blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float);
         const bool atomic_out = a.n_rchunks > 1;
         if (atomic_out) {
             ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
             ART_HIP(hipMemsetAsync(grad_normals, 0, sizeof(float) * 4 * H * P, stream));
+        } else if (a.n_tail > 0) {
+            // the tail items are dealt as two halves that ADD their gradients: zero the rows of their points - the
+            // suffix of the arrays that starts at the first tail item's (heliostat, point block)
+            const int64_t first_tail = (int64_t)a.H * a.n_pblocks - a.n_tail;
+            const int64_t start = (first_tail / a.n_pblocks) * P + (first_tail % a.n_pblocks) * a.p_block;
+            ART_HIP(hipMemsetAsync(grad_origins + 4 * start, 0, sizeof(float) * 4 * (H * P - start), stream));
+            ART_HIP(hipMemsetAsync(grad_normals + 4 * start, 0, sizeof(float) * 4 * (H * P - start), stream));
         }
 #define ART_LAUNCH_BWD(IL, AT, CY, BL)                                                                           \
         do {                                                                                                     \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            unsigned* work_counter = next_work_counter(stream);                                                  \
+            if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
             hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL>), dim3((unsigned)blocks),                   \
                                dim3((CY || BL) && cfg.block > 512 ? 512 : cfg.block), lds, stream, a, grad_flux, \
                                go, gn,                                                                           \
-                               grad_prim_corners, grad_prim_spans, grad_prim_normals);                           \
+                               grad_prim_corners, grad_prim_spans, grad_prim_normals, work_counter);             \
         } while (0)
 #define ART_LAUNCH_BWD_BL(CY, BL)                                                                                \
         do {                                                                                                     \

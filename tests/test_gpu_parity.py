@@ -1302,3 +1302,29 @@ def test_scenario_file_to_flux(golden, name):
         np.testing.assert_allclose(n(got), d[key], rtol=0, atol=max(5e-3, 2.5 / rays))
     if run["blocking"]:
         np.testing.assert_array_equal(n(tracer.filtered_blocking_primitive_indices), d["filter_indices"])
+
+
+@pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_TAIL="1"), dict(ARTIST_HIP_PERSISTENT="0"), dict(ARTIST_HIP_PERSISTENT="0", ARTIST_HIP_TAIL="1")])
+def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
+    """The windowed kernels hand out (heliostat, point block, sample chunk) items through a work queue: persistent
+    workgroups (default), one workgroup per item, and the tail items split into two halves (whose gradients are added
+    with atomics onto rows the host zeroes).  Every variant must produce the default's bitmaps (integer accumulation:
+    bit-exact but for the stray rays' float atomics) and gradients."""
+    from artist_amd import trace_rays
+    d = golden("mid_256")
+
+    def run():
+        inp = trace_inputs(d)
+        inp["origins"].requires_grad_(True)
+        inp["normals"].requires_grad_(True)
+        flux, fac = trace_rays(**inp)[:2]
+        (flux * t(d["loss_weights"])).sum().backward()
+        return n(flux), n(fac), n(inp["origins"].grad), n(inp["normals"].grad)
+
+    base = run()
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    other = run()
+    assert rel_l2(other[0], base[0]) < 1e-6
+    np.testing.assert_array_equal(other[1], base[1])
+    assert rel_l2(other[2], base[2]) < 1e-5 and rel_l2(other[3], base[3]) < 1e-5
