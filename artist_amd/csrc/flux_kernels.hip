@@ -144,21 +144,34 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_bwd_com_kernel(const f
     const float* __restrict__ f = flux + (int64_t)b * Hh * W;
     const float* __restrict__ g = grad_out + (int64_t)b * Hh * W;
     double gx = 0.0, gy = 0.0;
-    int j = threadIdx.x % W, i = threadIdx.x / W;
-    const int dj = blockDim.x % W, di = blockDim.x / W;
-    for (int k = threadIdx.x; k < Hh * W; k += blockDim.x, j += dj, i += di) {
-        if (j >= W) { j -= W; ++i; }
-        const float ix = m.ix(j), iy = m.iy(i);
-        const float x0f = floorf(ix), y0f = floorf(iy);
-        const float tx = ix - x0f, ty = iy - y0f;
-        const int x0 = (int)x0f, y0 = (int)y0f;
-        const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W;
-        const bool ya = y0 >= 0 && y0 < Hh, yb = y0 + 1 >= 0 && y0 + 1 < Hh;
-        const float v00 = ya && xa ? f[y0 * W + x0] : 0.0f, v01 = ya && xb ? f[y0 * W + x0 + 1] : 0.0f;
-        const float v10 = yb && xa ? f[(y0 + 1) * W + x0] : 0.0f, v11 = yb && xb ? f[(y0 + 1) * W + x0 + 1] : 0.0f;
-        const float go = g[k];
-        gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
-        gy += (double)(go * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
+    // Four pixels per trip, their twenty loads issued before the first is used: one workgroup per bitmap leaves the
+    // memory system nearly idle on a small field, so the loop lives on loads in flight (47 -> 20 us for 125 bitmaps).
+    // The per-thread summation order is that of the one-pixel loop: results do not change.
+    constexpr int U = 4;
+    const int npx = Hh * W;
+    for (int k0 = threadIdx.x; k0 < npx; k0 += U * blockDim.x) {
+        float v00[U], v01[U], v10[U], v11[U], go[U], tx[U], ty[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int k = k0 + q * blockDim.x;
+            const bool live = k < npx;
+            const int i = live ? k / W : 0, j = live ? k - i * W : 0;
+            const float ix = m.ix(j), iy = m.iy(i);
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            tx[q] = ix - x0f; ty[q] = iy - y0f;
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const bool xa = live && x0 >= 0 && x0 < W, xb = live && x0 + 1 >= 0 && x0 + 1 < W;
+            const bool ya = y0 >= 0 && y0 < Hh, yb = y0 + 1 >= 0 && y0 + 1 < Hh;
+            v00[q] = ya && xa ? f[y0 * W + x0] : 0.0f; v01[q] = ya && xb ? f[y0 * W + x0 + 1] : 0.0f;
+            v10[q] = yb && xa ? f[(y0 + 1) * W + x0] : 0.0f; v11[q] = yb && xb ? f[(y0 + 1) * W + x0 + 1] : 0.0f;
+            go[q] = live ? g[k] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (k0 + q * (int)blockDim.x >= npx) break;
+            gx += (double)(go[q] * ((v01[q] - v00[q]) * (1.0f - ty[q]) + (v11[q] - v10[q]) * ty[q]));
+            gy += (double)(go[q] * ((v10[q] - v00[q]) * (1.0f - tx[q]) + (v11[q] - v01[q]) * tx[q]));
+        }
     }
     gx = block_sum(gx, s_red);
     gy = block_sum(gy, s_red);
