@@ -15,7 +15,7 @@ _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ArtistHipError(RuntimeError):
@@ -46,7 +46,7 @@ SIGNATURES = {
     "art_rigid_body_fwd": [_c_int, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_dbl,
                            _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_rigid_body_bwd": [_c_int, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _ptr,
-                           _ptr, _ptr, _ptr, _ptr],
+                           _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_blocking_workspace_bytes": [_c_i64, _c_i64],
     "art_blocking_filter": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                             _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_dbl,

@@ -296,14 +296,15 @@ __global__ __launch_bounds__(256) void rigid_body_bwd_kernel(KinArgs a, const fl
                                                              const int* __restrict__ evals_in,
                                                              const float* __restrict__ grad_orientations,
                                                              float* __restrict__ grad_rot, float* __restrict__ grad_trans,
-                                                             float* __restrict__ grad_opt)
+                                                             float* __restrict__ grad_opt, float* __restrict__ grad_motor)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_par = 17;
+    const int n_par = 19;                     // 4 rotation + 9 translation + 4 actuator parameters + 2 motor positions
     if (idx >= a.H * n_par) return;
     const int h = idx / n_par, q = idx % n_par;
     const bool has_opt = a.act_rows >= 7 && grad_opt != nullptr;
-    if (q >= 13 && !has_opt) return;
+    if (q >= 13 && q < 17 && !has_opt) return;
+    if (q >= 17 && (a.mode != 0 || grad_motor == nullptr)) return;      // given motor positions: the calibration path only
     const Params<Dual> p = load_params<Dual>(a, h, q);
     Dual m0 = {0.0f, 0.0f}, m1 = {0.0f, 0.0f};
     Mat4<Dual> ori;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void rigid_body_bwd_kernel(KinArgs a, const fl
             kin_inverse(p, dn, m0, m1);
         }
     } else {
-        m0 = {motor_in[2 * h], 0.0f}; m1 = {motor_in[2 * h + 1], 0.0f};
+        m0 = {motor_in[2 * h], q == 17 ? 1.0f : 0.0f}; m1 = {motor_in[2 * h + 1], q == 18 ? 1.0f : 0.0f};
         ori = kin_forward(p, m0, m1);
     }
     // d(orientation @ offsets) . dL/d(orientation)
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(256) void rigid_body_bwd_kernel(KinArgs a, const fl
         }
     if (q < 4) grad_rot[4 * h + q] = acc;
     else if (q < 13) grad_trans[9 * h + (q - 4)] = acc;
-    else grad_opt[4 * h + (q < 15 ? q - 13 : 2 + (q - 15))] = acc;
+    else if (q < 17) grad_opt[4 * h + (q < 15 ? q - 13 : 2 + (q - 15))] = acc;
+    else grad_motor[2 * h + (q - 17)] = acc;
 }
 
 }  // namespace art
@@ -380,7 +382,7 @@ extern "C" int art_rigid_body_bwd(int mode, const float* positions, const float*
                                   const float* act_nonopt, int64_t act_rows, const float* act_opt, const float* offsets,
                                   const float* incident, const float* aim, int64_t H, const float* motor_positions,
                                   const int32_t* evaluations, const float* grad_orientations, float* grad_rot_dev,
-                                  float* grad_trans_dev, float* grad_act_opt, void* stream_)
+                                  float* grad_trans_dev, float* grad_act_opt, float* grad_motor_positions, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KinArgs a;
@@ -388,9 +390,9 @@ extern "C" int art_rigid_body_bwd(int mode, const float* positions, const float*
     if (!grad_orientations || !grad_rot_dev || !grad_trans_dev || !motor_positions || (mode == 1 && !evaluations) ||
         !kin_fill(a, mode, positions, rot_dev, trans_dev, act_nonopt, act_rows, act_opt, offsets, incident, aim, H, 1, 0.0))
         return ART_EINVAL;
-    const int64_t n = H * 17;
+    const int64_t n = H * 19;
     hipLaunchKernelGGL(rigid_body_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, motor_positions,
-                       evaluations, grad_orientations, grad_rot_dev, grad_trans_dev, grad_act_opt);
+                       evaluations, grad_orientations, grad_rot_dev, grad_trans_dev, grad_act_opt, grad_motor_positions);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

@@ -23,7 +23,9 @@ ACTUATOR_ROWS_LINEAR = 7      # ... + increment, offset, pivot radius
 
 class RigidBodyOrientations(torch.autograd.Function):
     """``mode`` 0: motor positions -> orientations; 1: incident ray directions + aim points -> orientations.
-    Returns (orientations [H,4,4], motor_positions [H,2]); only ``orientations`` is differentiable."""
+    Returns (orientations [H,4,4], motor_positions [H,2]); only ``orientations`` is differentiable - w.r.t. the
+    deviation parameters, the optimisable actuator parameters and, in mode 0, the given motor positions (what
+    ``AimPointOptimizer`` learns, artist/optim/aim_point_optimizer.py:384-405)."""
 
     @staticmethod
     def forward(ctx, mode, positions, rot_dev, trans_dev, act_nonopt, act_opt, offsets, incident, aim, motor_positions,
@@ -82,15 +84,17 @@ class RigidBodyOrientations(torch.autograd.Function):
         grad_rot = torch.empty_like(rot_dev)
         grad_trans = torch.empty_like(trans_dev)
         grad_opt = torch.empty_like(act_opt) if linear else None
+        grad_motor = torch.empty_like(motor) if ctx.mode == 0 and ctx.needs_input_grad[9] else None
         with torch.cuda.device(dev):
             rc = _lib.lib().art_rigid_body_bwd(
                 ctx.mode, positions.data_ptr(), rot_dev.data_ptr(), trans_dev.data_ptr(), act_nonopt.data_ptr(), ctx.rows,
                 act_opt.data_ptr() if linear else None, offsets.data_ptr(),
                 incident.data_ptr() if ctx.mode == 1 else None, aim.data_ptr() if ctx.mode == 1 else None, H,
                 motor.data_ptr(), evaluations.data_ptr(), grad_orientations.data_ptr(), grad_rot.data_ptr(),
-                grad_trans.data_ptr(), grad_opt.data_ptr() if linear else None, _stream(dev))
+                grad_trans.data_ptr(), grad_opt.data_ptr() if linear else None,
+                grad_motor.data_ptr() if grad_motor is not None else None, _stream(dev))
         _lib.check(rc, "art_rigid_body_bwd")
-        return None, None, grad_rot, grad_trans, None, grad_opt, None, None, None, None, None, None
+        return None, None, grad_rot, grad_trans, None, grad_opt, None, None, None, grad_motor, None, None
 
 
 def rigid_body_orientations(mode, positions, rot_dev, trans_dev, act_nonopt, act_opt, offsets, incident=None, aim=None,

@@ -233,6 +233,8 @@ int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B,
  *   same chain (the gradients torch.autograd gives the reference): grad_orientations [H,4,4] in;
  *   grad_rot_dev [H,4], grad_trans_dev [H,9], grad_act_opt [H,2,2] (NULL for ideal actuators) out, fully written.
  *   motor_positions is the forward's input in mode 0 and ignored in mode 1; evaluations as written by the forward.
+ *   grad_motor_positions [H,2] out (mode 0 only, may be NULL): the gradient the aim-point optimiser needs
+ *   (artist/optim/aim_point_optimizer.py:384-405 learns motor positions through align_surfaces_with_motor_positions).
  * ------------------------------------------------------------------------------------------- */
 int art_rigid_body_fwd(int mode, const float *positions, const float *rot_dev, const float *trans_dev,
                        const float *act_nonopt, int64_t act_rows, const float *act_opt, const float *offsets,
@@ -243,7 +245,7 @@ int art_rigid_body_bwd(int mode, const float *positions, const float *rot_dev, c
                        const float *act_nonopt, int64_t act_rows, const float *act_opt, const float *offsets,
                        const float *incident, const float *aim, int64_t H, const float *motor_positions,
                        const int32_t *evaluations, const float *grad_orientations, float *grad_rot_dev,
-                       float *grad_trans_dev, float *grad_act_opt, void *stream);
+                       float *grad_trans_dev, float *grad_act_opt, float *grad_motor_positions, void *stream);
 
 #ifdef __cplusplus
 }

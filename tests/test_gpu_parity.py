@@ -1127,16 +1127,17 @@ def test_rigid_body_motor_path_gradients_vs_finite_differences(golden):
     kin = _rigid_body(c, requires_grad=True)
     rng = np.random.default_rng(3)
     w = rng.standard_normal(c["orientation"].shape)
-    ori = kin.motor_positions_to_orientations(t(c["motor_given"], torch.float32))
+    motor = t(c["motor_given"], torch.float32).requires_grad_(True)      # what AimPointOptimizer learns
+    ori = kin.motor_positions_to_orientations(motor)
     (ori * t(w, torch.float32)).sum().backward()
 
     def scalar(**over):
         a = dict(c64, **over)
         return float((oracle.rigid_body_orientations(a["positions"], a["rot_dev"], a["trans_dev"], a["act_nonopt"], a["act_opt"],
-                                                     a["offsets"], motor_positions=c64["motor_given"])[0] * w).sum())
+                                                     a["offsets"], motor_positions=a["motor_given"])[0] * w).sum())
 
     for key, param in (("rot_dev", kin.rotation_deviation_parameters), ("trans_dev", kin.translation_deviation_parameters),
-                       ("act_opt", kin.actuators.optimizable_parameters)):
+                       ("act_opt", kin.actuators.optimizable_parameters), ("motor_given", motor)):
         g = n(param.grad).reshape(-1)
         base = c64[key]
         fd = np.zeros(base.size)
