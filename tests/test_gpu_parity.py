@@ -1329,3 +1329,110 @@ def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     assert rel_l2(other[0], base[0]) < 1e-6
     np.testing.assert_array_equal(other[1], base[1])
     assert rel_l2(other[2], base[2]) < 1e-5 and rel_l2(other[3], base[3]) < 1e-5
+
+
+def test_kinematics_reconstruction_loop_converges():
+    """Acceptance run in the shape of tutorials/04 (kinematics reconstruction through ray tracing), entirely on
+    artist_amd: scenario file -> measured flux with the true parameters -> perturbed deviation and actuator parameters
+    -> with the measured motor positions (the calibration path) Adam on the kinematics' learnable tensors through
+    kinematics, alignment, trace and pixel loss.  The loss must
+    fall five-fold and every focal spot move back towards the measured one.  (The parameters themselves
+    are not identifiable from one sun position - a joint tilt and an actuator's initial angle move the spot alike.)"""
+    import pathlib
+
+    from artist_amd import HeliostatRayTracer, PixelLoss
+    from artist_amd.scenario import Scenario, open_scenario_file
+    path = pathlib.Path(__file__).resolve().parent / "golden" / "scenarios" / "test_blocking.h5"
+    with open_scenario_file(path) as scenario_file:
+        scenario = Scenario.load_scenario_from_hdf5(scenario_file=scenario_file,
+                                                    number_of_surface_points_per_facet=torch.tensor([12, 12]), device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    kin = group.kinematics
+    sun = torch.nn.functional.normalize(torch.tensor([0.1, 1.0, -0.2, 0.0]), dim=0)
+    mapping = [(name, "target_3", sun) for name in group.names if name != "heliostat_3"]     # heliostat_3 stands behind the target
+    mask, targets, incident = scenario.index_mapping(heliostat_group=group, string_mapping=mapping, device=DEV)
+    scenario.set_number_of_rays(number_of_rays=20)
+
+    # calibration data: the motor positions the TRUE kinematics drives to for this sun and aim point
+    group.activate_heliostats(active_heliostats_mask=mask, device=DEV)
+    group.align_surfaces_with_incident_ray_directions(
+        aim_points=scenario.solar_tower.get_centers_of_target_areas(target_area_indices=targets, device=DEV),
+        incident_ray_directions=incident, active_heliostats_mask=mask, device=DEV)
+    motors = kin.active_motor_positions.detach().clone()
+
+    def flux_now():
+        group.activate_heliostats(active_heliostats_mask=mask, device=DEV)
+        group.align_surfaces_with_motor_positions(motor_positions=motors, active_heliostats_mask=mask, device=DEV)
+        tracer = HeliostatRayTracer(scenario=scenario, heliostat_group=group, blocking_active=False,
+                                    bitmap_resolution=torch.tensor([128, 128]))
+        return tracer.trace_rays(incident_ray_directions=incident, active_heliostats_mask=mask,
+                                 target_area_indices=targets, device=DEV)[0]
+
+    def spots(flux):                      # centre of mass of every bitmap, pixels
+        ys, xs = torch.meshgrid(torch.arange(128.0, device=DEV), torch.arange(128.0, device=DEV), indexing="ij")
+        total = flux.sum((1, 2))
+        return torch.stack(((flux * xs).sum((1, 2)) / total, (flux * ys).sum((1, 2)) / total), dim=1)
+
+    with torch.no_grad():
+        measured = flux_now().clone()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    kin.rotation_deviation_parameters = (kin.rotation_deviation_parameters
+                                         + 3e-3 * torch.randn((6, 4), generator=g).to(DEV)).requires_grad_(True)
+    kin.actuators.optimizable_parameters = kin.actuators.optimizable_parameters.detach().clone().requires_grad_(True)
+    optimizer = torch.optim.Adam([kin.rotation_deviation_parameters, kin.actuators.optimizable_parameters], lr=5e-4)
+    loss_fn = PixelLoss()
+    history, spot_error = [], []
+    for _ in range(250):
+        optimizer.zero_grad()
+        flux = flux_now()
+        loss = loss_fn(flux, measured, reduction_dimensions=(1, 2)).sum()
+        loss.backward()
+        optimizer.step()
+        history.append(float(loss))
+        spot_error.append(float((spots(flux.detach()) - spots(measured)).norm(dim=1).mean()))
+    assert min(history[-5:]) < 0.2 * history[0], (history[0], history[-5:])
+    assert spot_error[0] > 3.0 and min(spot_error[-5:]) < 0.3 * spot_error[0], (spot_error[0], spot_error[-5:])
+
+
+def test_surface_reconstruction_loop_converges():
+    """Acceptance run in the shape of tutorials/03 / SurfaceReconstructor's epoch (surface_reconstructor.py:452-779): the
+    measured flux comes from surfaces with deflections, the model starts from flat control nets, and Adam on the
+    control points through NURBS, alignment, trace, crop and pixel loss brings the flux back."""
+    from artist_amd import NURBSSurfaces, PixelLoss, ops, scene
+    from artist_amd.flux import FluxCrop
+    H, R, n_eval = 4, 20, 24
+    P = 4 * n_eval * n_eval
+    scenario, uv = scene.build_synthetic_scenario(H, n_rays=R, n_cp=(6, 6), n_eval=n_eval, z_noise=4e-4, device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    group.activate_heliostats(torch.ones(H, dtype=torch.int32, device=DEV))
+    targets = torch.zeros(H, dtype=torch.long, device=DEV)
+    incident = torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=DEV).repeat(H, 1)
+    planar = scenario.solar_tower.target_areas[0]
+    orientation = scene.ideal_orientations(group.active_positions, scenario.solar_tower.get_centers_of_target_areas(targets), incident)
+    dist_u, dist_e = scenario.light_sources.light_source_list[0].get_distortions(P, H)
+    dims = planar.dimensions.index_select(0, targets).contiguous()
+
+    def flux_of(cp):
+        pts, nrm = NURBSSurfaces(group.nurbs_degrees, cp, device=DEV).calculate_surface_points_and_normals(
+            uv, group.active_canting, group.active_facet_translations)
+        ap, an = ops.align_surfaces(pts.reshape(H, P, 4), nrm.reshape(H, P, 4), orientation)
+        flux = ops.trace_rays(ap, an, incident, dist_u, dist_e, targets, planar.centers, planar.normals, planar.dimensions,
+                              1.0, 0.0, 0.935, (128, 128))[0]
+        return FluxCrop.apply(flux, dims, 6.0, 6.0)
+
+    true_cp = group.active_nurbs_control_points
+    with torch.no_grad():
+        measured = flux_of(true_cp).clone()
+    cp = true_cp.clone()
+    cp[..., 2] = 0.0                                        # the model starts from ideal (flat) facets
+    cp.requires_grad_(True)
+    optimizer = torch.optim.Adam([cp], lr=2e-5)
+    loss_fn = PixelLoss()
+    history = []
+    for _ in range(150):
+        optimizer.zero_grad()
+        loss = loss_fn(flux_of(cp), measured, reduction_dimensions=(1, 2)).sum()
+        loss.backward()
+        optimizer.step()
+        history.append(float(loss))
+    assert min(history[-5:]) < 0.3 * history[0], (history[0], history[-5:])
