@@ -118,57 +118,132 @@ def _actuators(config, owner) -> dict:
     return dict(type=kind, non_optimizable=nonopt, optimizable=opt)
 
 
-def read_scenario_tables(scenario_file) -> dict:
-    """Everything a scenario file holds, as numpy arrays on the host (no GPU needed)."""
-    out = dict(version=scenario_file.attrs.get("version") if hasattr(scenario_file, "attrs") else None)
-    out["power_plant_position"] = np.asarray(scenario_file["power_plant"]["position"][()], dtype=np.float64)
-
-    planar = scenario_file["target_areas_planar"]
+def read_planar_target_areas(config_file) -> dict:
+    """artist/field/tower_target_areas_planar.py:75-143 (names in sorted order)."""
+    planar = config_file["target_areas_planar"]
     names = sorted(planar.keys())
-    out["planar"] = dict(names=names,
-                         centers=np.stack([_f32(planar[k]["position_center"]).reshape(4) for k in names]).reshape(-1, 4),
-                         normals=np.stack([_f32(planar[k]["normal_vector"]).reshape(4) for k in names]).reshape(-1, 4),
-                         dimensions=np.array([[float(planar[k]["plane_e"][()]), float(planar[k]["plane_u"][()])] for k in names],
-                                             dtype=np.float32).reshape(-1, 2))
-    cyl = scenario_file["target_areas_cylindrical"]
+    return dict(names=names,
+                centers=np.stack([_f32(planar[k]["position_center"]).reshape(4) for k in names]).reshape(-1, 4),
+                normals=np.stack([_f32(planar[k]["normal_vector"]).reshape(4) for k in names]).reshape(-1, 4),
+                dimensions=np.array([[float(planar[k]["plane_e"][()]), float(planar[k]["plane_u"][()])] for k in names],
+                                    dtype=np.float32).reshape(-1, 2))
+
+
+def read_cylindrical_target_areas(config_file) -> dict:
+    """artist/field/tower_target_areas_cylindrical.py:103-193."""
+    cyl = config_file["target_areas_cylindrical"]
     names = sorted(cyl.keys())
-    vec = lambda key: np.stack([_f32(cyl[k][key]).reshape(4) for k in names]).reshape(-1, 4) if names else np.zeros((0, 4), np.float32)  # noqa: E731
+    vec = lambda key: (np.stack([_f32(cyl[k][key]).reshape(4) for k in names]).reshape(-1, 4) if names  # noqa: E731
+                       else np.zeros((0, 4), np.float32))
     sca = lambda key: np.array([np.float32(cyl[k][key][()]) for k in names], dtype=np.float32)  # noqa: E731
-    out["cylindrical"] = dict(names=names, centers=vec("cylinder_center"), normals=vec("cylinder_normal"), axes=vec("cylinder_axis"),
-                              radii=sca("cylinder_radius"), heights=sca("cylinder_height"),
-                              opening_angles=sca("cylinder_opening_angle"))
+    return dict(names=names, centers=vec("cylinder_center"), normals=vec("cylinder_normal"), axes=vec("cylinder_axis"),
+                radii=sca("cylinder_radius"), heights=sca("cylinder_height"), opening_angles=sca("cylinder_opening_angle"))
 
-    sources = []
-    for key in sorted(scenario_file["lightsources"].keys()):
-        cfg = scenario_file["lightsources"][key]
-        kind = _text(cfg["type"])
-        if kind != "sun":
-            raise KeyError(f"Currently the selected light source: {kind} is not supported.")
-        params = dict(distribution_type=_text(cfg["distribution_parameters"]["distribution_type"]))
-        for name in ("mean", "covariance"):
-            if name in cfg["distribution_parameters"].keys():
-                params[name] = float(cfg["distribution_parameters"][name][()])
-        sources.append(dict(name=key, number_of_rays=int(cfg["number_of_rays"][()]), distribution_parameters=params))
-    out["light_sources"] = sources
 
-    proto = scenario_file["prototypes"]
-    prototype_surface = _surface(proto["surface"]["facets"])
-    prototype_kinematics = _kinematics(proto["kinematics"], None)
-    prototype_actuators = _actuators(proto["actuator"], None)
+def read_light_source(config, name=None) -> dict:
+    """One light source group (artist/scene/sun.py:121-197)."""
+    kind = _text(config["type"])
+    if kind != "sun":
+        raise KeyError(f"Currently the selected light source: {kind} is not supported.")
+    params = dict(distribution_type=_text(config["distribution_parameters"]["distribution_type"]))
+    for key in ("mean", "covariance"):
+        if key in config["distribution_parameters"].keys():
+            params[key] = float(config["distribution_parameters"][key][()])
+    return dict(name=name, number_of_rays=int(config["number_of_rays"][()]), distribution_parameters=params)
 
+
+def read_light_sources(config_file) -> list:
+    """artist/scene/light_source_array.py:48-98 (sorted by name)."""
+    return [read_light_source(config_file["lightsources"][key], key) for key in sorted(config_file["lightsources"].keys())]
+
+
+def read_prototypes(config_file) -> dict:
+    """The prototype surface, kinematics and actuators (scenario.py:159-236)."""
+    proto = config_file["prototypes"]
+    return dict(surface=_surface(proto["surface"]["facets"]), kinematics=_kinematics(proto["kinematics"], None),
+                actuators=_actuators(proto["actuator"], None))
+
+
+def read_heliostats(config_file, prototype_surface=None, prototype_kinematics=None, prototype_actuators=None) -> list:
+    """Per-heliostat tables, prototypes filled in where a heliostat has no entry of its own
+    (artist/field/heliostat_field.py:137-262, same errors)."""
     heliostats = []
-    for name in scenario_file["heliostats"].keys():
-        cfg = scenario_file["heliostats"][name]
+    for name in config_file["heliostats"].keys():
+        cfg = config_file["heliostats"][name]
         keys = list(cfg.keys())
+        if "surface" not in keys and prototype_surface is None:
+            raise ValueError("If the heliostat does not have individual surface parameters, a surface prototype must be provided!")
+        if "kinematics" not in keys and prototype_kinematics is None:
+            raise ValueError("If the heliostat does not have an individual kinematics, a kinematics prototype must be provided!")
+        if "actuator" not in keys and prototype_actuators is None:
+            raise ValueError("If the heliostat does not have individual actuators, an actuator prototype must be provided!")
         heliostats.append(dict(
             name=name, position=_f32(cfg["position"]),
             surface=_surface(cfg["surface"]["facets"]) if "surface" in keys else prototype_surface,
             kinematics=_kinematics(cfg["kinematics"], name) if "kinematics" in keys else prototype_kinematics,
             actuators=_actuators(cfg["actuator"], name) if "actuator" in keys else prototype_actuators))
-    out["heliostats"] = heliostats
+    return heliostats
+
+
+def read_scenario_tables(scenario_file) -> dict:
+    """Everything a scenario file holds, as numpy arrays on the host (no GPU needed)."""
+    out = dict(version=scenario_file.attrs.get("version") if hasattr(scenario_file, "attrs") else None)
+    out["power_plant_position"] = np.asarray(scenario_file["power_plant"]["position"][()], dtype=np.float64)
+    out["planar"] = read_planar_target_areas(scenario_file)
+    out["cylindrical"] = read_cylindrical_target_areas(scenario_file)
+    out["light_sources"] = read_light_sources(scenario_file)
+    prototypes = read_prototypes(scenario_file)
+    out["heliostats"] = read_heliostats(scenario_file, prototypes["surface"], prototypes["kinematics"], prototypes["actuators"])
     if "number_of_heliostat_groups" in scenario_file.keys():
         out["number_of_heliostat_groups"] = int(scenario_file["number_of_heliostat_groups"][()])
     return out
+
+
+def _to_device(array, device) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(array)).to(device)
+
+
+def build_solar_tower(planar: dict, cylindrical: dict, device) -> "scene.SolarTower":
+    t = lambda a: _to_device(a, device)  # noqa: E731
+    return scene.SolarTower(target_areas=[
+        scene.TowerTargetAreasPlanar(names=planar["names"], centers=t(planar["centers"]), normals=t(planar["normals"]),
+                                     dimensions=t(planar["dimensions"])),
+        scene.TowerTargetAreasCylindrical(names=cylindrical["names"], centers=t(cylindrical["centers"]),
+                                          normals=t(cylindrical["normals"]), axes=t(cylindrical["axes"]),
+                                          radii=t(cylindrical["radii"]), heights=t(cylindrical["heights"]),
+                                          opening_angles=t(cylindrical["opening_angles"]))], device=device)
+
+
+def build_heliostat_field(heliostats: list, number_of_surface_points_per_facet, change_number_of_control_points_per_facet,
+                          device) -> "scene.HeliostatField":
+    """Group by (kinematics, actuator) type in order of first appearance and put each group on the GPU
+    (artist/field/heliostat_field.py:263-435)."""
+    t = lambda a: _to_device(a, device)  # noqa: E731
+    grouped = defaultdict(list)
+    for h in heliostats:
+        grouped[f"{h['kinematics']['type']}_{h['actuators']['type']}"].append(h)
+    groups = []
+    for key, members in grouped.items():
+        points, normals, canting, translations, control_points, degrees = _sample_surfaces(
+            members, number_of_surface_points_per_facet, change_number_of_control_points_per_facet, device)
+        positions = t(np.stack([m["position"] for m in members]))
+        initial_orientations = t(np.stack([m["kinematics"]["initial_orientation"] for m in members]))
+        kinematics = RigidBody(
+            number_of_heliostats=len(members), heliostat_positions=positions, initial_orientations=initial_orientations,
+            translation_deviation_parameters=t(np.stack([m["kinematics"]["translation"] for m in members])),
+            rotation_deviation_parameters=t(np.stack([m["kinematics"]["rotation"] for m in members])),
+            actuator_parameters_non_optimizable=t(np.stack([m["actuators"]["non_optimizable"] for m in members])),
+            actuator_parameters_optimizable=t(np.stack([m["actuators"]["optimizable"] for m in members])), device=device)
+        group = scene.HeliostatGroup(names=[m["name"] for m in members], positions=positions, surface_points=points,
+                                     surface_normals=normals, canting=canting, facet_translations=translations,
+                                     nurbs_control_points=control_points, nurbs_degrees=degrees, device=device,
+                                     kinematics=kinematics)
+        group.initial_orientations = initial_orientations
+        group.group_type = key
+        groups.append(group)
+        log.info(f"Added a heliostat group with kinematics type: {members[0]['kinematics']['type']}, and actuator type: "
+                 f"{members[0]['actuators']['type']}, to the heliostat field.")
+    return scene.HeliostatField(heliostat_groups=groups, device=device)
 
 
 def _sample_surfaces(members, number_of_surface_points_per_facet, change_control_points, device):
@@ -223,44 +298,14 @@ class Scenario(scene.Scenario):
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         tables = read_scenario_tables(scenario_file)
         log.info(f"Loading an ARTIST scenario HDF5 file. This scenario file is version {tables['version']}.")
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-        p, c = tables["planar"], tables["cylindrical"]
-        planar = scene.TowerTargetAreasPlanar(names=p["names"], centers=t(p["centers"]), normals=t(p["normals"]),
-                                              dimensions=t(p["dimensions"]))
-        cylindrical = scene.TowerTargetAreasCylindrical(names=c["names"], centers=t(c["centers"]), normals=t(c["normals"]),
-                                                        axes=t(c["axes"]), radii=t(c["radii"]), heights=t(c["heights"]),
-                                                        opening_angles=t(c["opening_angles"]))
-        solar_tower = scene.SolarTower(target_areas=[planar, cylindrical], device=dev)
+        solar_tower = build_solar_tower(tables["planar"], tables["cylindrical"], dev)
         light_sources = scene.LightSourceArray([scene.Sun(number_of_rays=s["number_of_rays"],
                                                           distribution_parameters=s["distribution_parameters"], device=dev)
                                                 for s in tables["light_sources"]])
-        grouped = defaultdict(list)                           # insertion order = order of first appearance, as in ARTIST
-        for h in tables["heliostats"]:
-            grouped[f"{h['kinematics']['type']}_{h['actuators']['type']}"].append(h)
-        groups = []
-        for key, members in grouped.items():
-            points, normals, canting, translations, control_points, degrees = _sample_surfaces(
-                members, number_of_surface_points_per_facet, change_number_of_control_points_per_facet, dev)
-            positions = t(np.stack([m["position"] for m in members]))
-            initial_orientations = t(np.stack([m["kinematics"]["initial_orientation"] for m in members]))
-            kinematics = RigidBody(
-                number_of_heliostats=len(members), heliostat_positions=positions, initial_orientations=initial_orientations,
-                translation_deviation_parameters=t(np.stack([m["kinematics"]["translation"] for m in members])),
-                rotation_deviation_parameters=t(np.stack([m["kinematics"]["rotation"] for m in members])),
-                actuator_parameters_non_optimizable=t(np.stack([m["actuators"]["non_optimizable"] for m in members])),
-                actuator_parameters_optimizable=t(np.stack([m["actuators"]["optimizable"] for m in members])), device=dev)
-            group = scene.HeliostatGroup(names=[m["name"] for m in members], positions=positions, surface_points=points,
-                                         surface_normals=normals, canting=canting, facet_translations=translations,
-                                         nurbs_control_points=control_points, nurbs_degrees=degrees, device=dev,
-                                         kinematics=kinematics)
-            group.initial_orientations = initial_orientations
-            group.group_type = key.split("_", 2)[-1]
-            groups.append(group)
-            log.info(f"Added a heliostat group with kinematics type: rigid_body, and actuator type: "
-                     f"{members[0]['actuators']['type']}, to the heliostat field.")
+        heliostat_field = build_heliostat_field(tables["heliostats"], number_of_surface_points_per_facet,
+                                                change_number_of_control_points_per_facet, dev)
         return cls(power_plant_position=torch.tensor(tables["power_plant_position"], dtype=torch.float64, device=dev),
-                   solar_tower=solar_tower, light_sources=light_sources,
-                   heliostat_field=scene.HeliostatField(heliostat_groups=groups, device=dev))
+                   solar_tower=solar_tower, light_sources=light_sources, heliostat_field=heliostat_field)
 
     def index_mapping(self, heliostat_group, string_mapping=None, single_incident_ray_direction: torch.Tensor | None = None,
                       single_target_area_index: int = 0, device: torch.device | None = None):

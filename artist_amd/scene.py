@@ -34,6 +34,13 @@ class Sun:
         cov = torch.tensor([[params["covariance"], 0], [0, params["covariance"]]], dtype=torch.float, device=device)
         self.distribution = torch.distributions.MultivariateNormal(mean, cov)
 
+    @classmethod
+    def from_hdf5(cls, config_file, light_source_name: str | None = None, device: torch.device | None = None) -> "Sun":
+        """artist/scene/sun.py:121-197 (``config_file`` = the light source's own group)."""
+        from . import scenario
+        t = scenario.read_light_source(config_file, light_source_name)
+        return cls(number_of_rays=t["number_of_rays"], distribution_parameters=t["distribution_parameters"], device=device)
+
     def get_distortions(self, number_of_points: int, number_of_active_heliostats: int, random_seed: int = 7):
         torch.manual_seed(random_seed)
         if torch.cuda.is_available():
@@ -56,6 +63,13 @@ class LightSourceArray:
     def __init__(self, light_source_list) -> None:
         self.light_source_list = light_source_list
 
+    @classmethod
+    def from_hdf5(cls, config_file, device: torch.device | None = None) -> "LightSourceArray":
+        """artist/scene/light_source_array.py:48-98."""
+        from . import scenario
+        return cls([Sun(number_of_rays=s["number_of_rays"], distribution_parameters=s["distribution_parameters"], device=device)
+                    for s in scenario.read_light_sources(config_file)])
+
 
 class TowerTargetAreasPlanar:
     def __init__(self, names, centers, normals, dimensions) -> None:
@@ -64,6 +78,14 @@ class TowerTargetAreasPlanar:
         self.normals = normals
         self.dimensions = dimensions
         self.number_of_target_areas = len(names)
+
+    @classmethod
+    def from_hdf5(cls, config_file, device: torch.device | None = None) -> "TowerTargetAreasPlanar":
+        """artist/field/tower_target_areas_planar.py:75-143."""
+        from . import scenario
+        t = scenario.read_planar_target_areas(config_file)
+        to = lambda a: scenario._to_device(a, device)  # noqa: E731
+        return cls(names=t["names"], centers=to(t["centers"]), normals=to(t["normals"]), dimensions=to(t["dimensions"]))
 
 
 class TowerTargetAreasCylindrical:
@@ -79,6 +101,15 @@ class TowerTargetAreasCylindrical:
         self.heights = heights
         self.opening_angles = opening_angles
         self.number_of_target_areas = len(names)
+
+    @classmethod
+    def from_hdf5(cls, config_file, device: torch.device | None = None) -> "TowerTargetAreasCylindrical":
+        """artist/field/tower_target_areas_cylindrical.py:103-193."""
+        from . import scenario
+        t = scenario.read_cylindrical_target_areas(config_file)
+        to = lambda a: scenario._to_device(a, device)  # noqa: E731
+        return cls(names=t["names"], centers=to(t["centers"]), normals=to(t["normals"]), axes=to(t["axes"]),
+                   radii=to(t["radii"]), heights=to(t["heights"]), opening_angles=to(t["opening_angles"]))
 
 
 class _NoCylinders:
@@ -98,6 +129,12 @@ class SolarTower:
             [t.number_of_target_areas for t in self.target_areas], device=device)
         names = [n for t in self.target_areas for n in t.names]
         self.target_name_to_index = {n: i for i, n in enumerate(names)}
+
+    @classmethod
+    def from_hdf5(cls, config_file, device: torch.device | None = None) -> "SolarTower":
+        """artist/field/solar_tower.py:93-127: planar areas first, cylindrical second."""
+        return cls(target_areas=[TowerTargetAreasPlanar.from_hdf5(config_file, device),
+                                 TowerTargetAreasCylindrical.from_hdf5(config_file, device)], device=device)
 
     def get_centers_of_target_areas(self, target_area_indices: torch.Tensor, device=None) -> torch.Tensor:
         """Aim points by GLOBAL target index, planar first, cylindrical second: a planar area's centre; for a cylinder
@@ -214,6 +251,24 @@ class HeliostatGroup:
 class HeliostatField:
     def __init__(self, heliostat_groups, device=None) -> None:
         self.heliostat_groups = list(heliostat_groups)
+
+    @classmethod
+    def from_hdf5(cls, config_file, prototype_surface=None, prototype_kinematics=None, prototype_actuators=None,
+                  number_of_surface_points_per_facet: torch.Tensor = torch.tensor([50, 50]),
+                  change_number_of_control_points_per_facet: torch.Tensor | None = None,
+                  device: torch.device | None = None) -> "HeliostatField":
+        """artist/field/heliostat_field.py:80-435.  The prototypes are the tables ``artist_amd.scenario.read_prototypes``
+        returns (``surface``, ``kinematics``, ``actuators``); when none is given they are read from ``config_file``."""
+        from . import scenario
+        if prototype_surface is None and prototype_kinematics is None and prototype_actuators is None and \
+                "prototypes" in config_file.keys():
+            prototypes = scenario.read_prototypes(config_file)
+            prototype_surface, prototype_kinematics, prototype_actuators = (prototypes["surface"], prototypes["kinematics"],
+                                                                            prototypes["actuators"])
+        heliostats = scenario.read_heliostats(config_file, prototype_surface, prototype_kinematics, prototype_actuators)
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        return scenario.build_heliostat_field(heliostats, number_of_surface_points_per_facet,
+                                              change_number_of_control_points_per_facet, dev)
 
 
 class Scenario:

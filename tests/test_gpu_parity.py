@@ -1487,3 +1487,29 @@ def test_aim_point_optimisation_loop_converges():
         optimizer.step()
         history.append(float(loss))
     assert min(history[-5:]) < 0.2 * history[0], (history[0], history[-5:])
+
+
+def test_from_hdf5_classmethods_equal_the_scenario_loader():
+    """SolarTower / target areas / LightSourceArray / Sun / HeliostatField.from_hdf5 (the reference's per-class loaders)
+    give the objects Scenario.load_scenario_from_hdf5 assembles."""
+    import pathlib
+
+    from artist_amd import scene
+    from artist_amd.scenario import Scenario, open_scenario_file
+    path = pathlib.Path(__file__).resolve().parent / "golden" / "scenarios" / "test_scenario_paint_four_heliostats.h5"
+    points = torch.tensor([6, 6])
+    with open_scenario_file(path) as f:
+        whole = Scenario.load_scenario_from_hdf5(scenario_file=f, number_of_surface_points_per_facet=points, device=DEV)
+        tower = scene.SolarTower.from_hdf5(config_file=f, device=DEV)
+        lights = scene.LightSourceArray.from_hdf5(config_file=f, device=DEV)
+        sun = scene.Sun.from_hdf5(config_file=f["lightsources"]["sun_1"], light_source_name="sun_1", device=DEV)
+        field = scene.HeliostatField.from_hdf5(config_file=f, number_of_surface_points_per_facet=points, device=DEV)
+    assert tower.target_name_to_index == whole.solar_tower.target_name_to_index
+    assert torch.equal(tower.target_areas[0].centers, whole.solar_tower.target_areas[0].centers)
+    assert torch.equal(tower.target_areas[1].radii, whole.solar_tower.target_areas[1].radii)
+    assert len(lights.light_source_list) == 1 and lights.light_source_list[0].number_of_rays == sun.number_of_rays == 10
+    assert sun.distribution_parameters == whole.light_sources.light_source_list[0].distribution_parameters
+    assert [g.names for g in field.heliostat_groups] == [["AA28", "AC43"], ["AA31", "AA39"]]      # ideal, then linear actuators
+    for ours, ref in zip(field.heliostat_groups, whole.heliostat_field.heliostat_groups):
+        assert torch.equal(ours.surface_points, ref.surface_points) and torch.equal(ours.surface_normals, ref.surface_normals)
+        assert torch.equal(ours.kinematics.actuators.non_optimizable_parameters, ref.kinematics.actuators.non_optimizable_parameters)
