@@ -238,10 +238,10 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
     // the footprint of an oblique beam is stretched by the obliquity along the projection of the ray only.
     float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, ke = 0.0f, ku = 0.0f, angmax = 0.0f;
     float dmax2 = 0.0f, esum = 0.0f, usum = 0.0f, cnt = 0.0f, esq = 0.0f, usq = 0.0f;
-    for (int p = p0 + tid; p < p1; p += blockDim.x) {
-        const bool pre = first != nullptr && p == p0 + tid;       // this thread's first point came with the caller
-        const float4 o = pre ? first->o : org[p];
-        const float4 n = pre ? first->n : nrm[p];
+    // One point per trip, the NEXT point's loads issued before the current one is worked on: a workgroup that owns
+    // many points per thread (one sun sample per point at field scale: 10 trips) is otherwise a chain of exposed
+    // HBM round trips (30 us of a 77 us workgroup, tools/timeline.sh).
+    auto consume = [&](const float4 o, const float4 n, const float u, const float e) {
         float4 d; float s;
         reflect(inc, n, d, s);
         dmax2 = fmaxf(dmax2, d.x * d.x + d.y * d.y + d.z * d.z);
@@ -268,10 +268,26 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             ke = fmaxf(ke, hke);
             ku = fmaxf(ku, hku);
         }
-        float u, e;
-        if (pre) { u = first->u; e = first->e; }
-        else load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e);
         angmax = fmaxf(angmax, fmaxf(fabsf(u), fabsf(e)));
+    };
+    {
+        int p = p0 + tid;
+        bool have = p < p1;
+        float4 o = {0.0f, 0.0f, 0.0f, 1.0f}, n = {0.0f, 0.0f, 1.0f, 0.0f};
+        float u = 0.0f, e = 0.0f;
+        if (have) {
+            if (first != nullptr) { o = first->o; n = first->n; u = first->u; e = first->e; }      // came with the caller
+            else { o = org[p]; n = nrm[p]; load_dist<INTERLEAVED>(a, dbase + (int64_t)p * a.sp, u, e); }
+        }
+        while (have) {
+            const int pn = p + (int)blockDim.x;
+            const bool have_n = pn < p1;
+            float4 o2 = o, n2 = n;
+            float u2 = 0.0f, e2 = 0.0f;
+            if (have_n) { o2 = org[pn]; n2 = nrm[pn]; load_dist<INTERLEAVED>(a, dbase + (int64_t)pn * a.sp, u2, e2); }
+            consume(o, n, u, e);
+            o = o2; n = n2; u = u2; e = e2; p = pn; have = have_n;
+        }
     }
     emin = wave_reduce<kMin>(emin); emax = wave_reduce<kMax>(emax); umin = wave_reduce<kMin>(umin); umax = wave_reduce<kMax>(umax);
     ke = wave_reduce<kMax>(ke); ku = wave_reduce<kMax>(ku); angmax = wave_reduce<kMax>(angmax); dmax2 = wave_reduce<kMax>(dmax2);
@@ -467,22 +483,14 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime();       // shader clock
 #endif
     if (tid < 3) s_cnt[tid] = 0;
-    // This thread's first point and its first four distortion samples are requested before anything else, and the
-    // tile is cleared while they are in flight: a CU holds ONE workgroup (the window fills its LDS), so every
-    // microsecond of latency in this prologue is a microsecond of idle VALUs (tools/timeline.sh).
+    // This thread's first point and its first distortion sample are requested before anything else, and the tile is
+    // cleared while they are in flight: a CU holds ONE workgroup (the window fills its LDS), so every microsecond of
+    // latency in this prologue is a microsecond of idle VALUs (tools/timeline.sh).
     const int pf = p0 + tid;
-    const int nr_all = r1 - r0;
     FirstPoint fp = {{0.0f, 0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f, 0.0f}, 0.0f, 0.0f};
-    float fu1 = 0.0f, fe1 = 0.0f, fu2 = 0.0f, fe2 = 0.0f, fu3 = 0.0f, fe3 = 0.0f;
     if (pf < p1) {
         fp.o = org[pf]; fp.n = nrm[pf];
-        const float* __restrict__ bu_ = a.dist_u + dbase;
-        const float* __restrict__ be_ = a.dist_e + dbase;
-        const int lane_off = pf * (int)a.sp;
-        load_dist_row<INTERLEAVED>(bu_, be_, lane_off, fp.u, fp.e);
-        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr_all - 1) * a.sr, be_ + (int64_t)min(1, nr_all - 1) * a.sr, lane_off, fu1, fe1);
-        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr_all - 1) * a.sr, be_ + (int64_t)min(2, nr_all - 1) * a.sr, lane_off, fu2, fe2);
-        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr_all - 1) * a.sr, be_ + (int64_t)min(3, nr_all - 1) * a.sr, lane_off, fu3, fe3);
+        load_dist_row<INTERLEAVED>(a.dist_u + dbase, a.dist_e + dbase, pf * (int)a.sp, fp.u, fp.e);
     }
     {   // 16-byte stores (tile_cap is a multiple of 256 cells) + the two spare cells behind the window
         uint4* t4 = reinterpret_cast<uint4*>(tile);
@@ -522,9 +530,8 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     // in-bitmap-but-outside-window ray goes to global memory.
     PendingSplat ps = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
-        const bool pre = first && p == pf;                 // loaded in the prologue
-        const float4 o = pre ? fp.o : org[p];
-        const float4 n = pre ? fp.n : nrm[p];
+        const float4 o = org[p];
+        const float4 n = nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
         float numer = 0.0f; CylPoint cp;
@@ -640,14 +647,10 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
         const float* __restrict__ bu_ = a.dist_u + dbase;     // wave-uniform
         const float* __restrict__ be_ = a.dist_e + dbase;
         float cu0, ce0, cu1, ce1, cu2, ce2, cu3, ce3;
-        if (pre) {
-            cu0 = fp.u; ce0 = fp.e; cu1 = fu1; ce1 = fe1; cu2 = fu2; ce2 = fe2; cu3 = fu3; ce3 = fe3;
-        } else {
-            load_dist_row<INTERLEAVED>(bu_, be_, lane_off, cu0, ce0);
-            load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr - 1) * a.sr, be_ + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
-            load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr - 1) * a.sr, be_ + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
-            load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr - 1) * a.sr, be_ + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
-        }
+        load_dist_row<INTERLEAVED>(bu_, be_, lane_off, cu0, ce0);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(1, nr - 1) * a.sr, be_ + (int64_t)min(1, nr - 1) * a.sr, lane_off, cu1, ce1);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr - 1) * a.sr, be_ + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
+        load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr - 1) * a.sr, be_ + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
         for (int k = 0; k < nr; k += 4) {
 #ifdef ART_DEBUG_TIMELINE
             if (k == 4 && p == p0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)"); ART_TIMELINE(4); }   // first group traced
@@ -715,19 +718,38 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     if (tid < 3 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
+// Everything the forward kernel is launched with, as ONE argument: the persistent loop below re-reads what an item
+// needs from the kernarg segment instead of carrying it in registers.
+struct FwdLaunch { TraceArgs a; float* flux; unsigned int* counts; unsigned int* work_counter; };
+
 template <bool INTERLEAVED, bool CYL, bool BLOCKING>
-__global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(TraceArgs a, float* __restrict__ flux,
-                                                             unsigned int* __restrict__ counts,
-                                                             unsigned int* __restrict__ work_counter)
+__global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
     __shared__ int s_next;
-    const int n_items = work_item_count(a);
-    int item = blockIdx.x;                       // the first gridDim.x items need no counter
-    while (item < n_items) {                     // workgroup-uniform: `item` comes from LDS
-        trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(a, flux, counts, item, decode_work_item(a, item), work_counter, &s_next);
+#ifdef ART_FWD_SINGLE_ITEM   // diagnostic build: one workgroup per item, no loop (A/B against the persistent form)
+    if ((int)blockIdx.x < work_item_count(launch.a))
+        trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(launch.a, launch.flux, launch.counts, (int)blockIdx.x,
+                                                   decode_work_item(launch.a, (int)blockIdx.x), launch.work_counter, &s_next);
+    return;
+#endif
+    if (threadIdx.x == 0) s_next = (int)blockIdx.x;          // the first gridDim.x items need no counter
+    __syncthreads();
+    for (;;) {
+        // The trace loop of an item fills the register file (100 SGPRs, 114 VGPRs).  Anything carried across items - the
+        // ~80 argument loads the compiler would hoist out of this loop, even the three pointers - overflows the SGPRs
+        // into VGPR lanes and makes the hot loop spill (measured: 258 scratch accesses per ray group).  So an item starts
+        // from nothing but the kernarg segment pointer, whose origin the empty asm hides from the optimiser: every
+        // field is re-read with scalar loads (cached) where it is needed, and the item number comes from LDS.
+        typedef const FwdLaunch __attribute__((address_space(4))) * KernargPtr;
+        KernargPtr lp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(lp));
+        const FwdLaunch& L = *(const FwdLaunch*)lp;
+        const int item = __builtin_amdgcn_readfirstlane(s_next);
+        __syncthreads();                                     // everybody has read s_next before this item overwrites it
+        if (item >= work_item_count(L.a)) break;             // workgroup-uniform
+        trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item), L.work_counter,
+                                                   &s_next);
         __syncthreads();
-        item = s_next;
-        __syncthreads();                         // everybody has read s_next before the next item may overwrite it
     }
 }
 
@@ -1401,7 +1423,11 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
+#ifdef ART_FWD_SINGLE_ITEM
+        const int64_t blocks = items;
+#else
         const int64_t blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items, resident_workgroups()) : items;
+#endif
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
         // exits at once (the type is only known on the device)
@@ -1411,8 +1437,9 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = next_work_counter(stream);                                                  \
             if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
+            const FwdLaunch launch = {a, flux, counts, work_counter};                                            \
             hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL>), dim3((unsigned)blocks), dim3(cfg.block), lds, \
-                               stream, a, flux, counts, work_counter);                                           \
+                               stream, launch);                                                                  \
         } while (0)
 #define ART_LAUNCH_FWD_TYPE(CY)                                                                                  \
         do {                                                                                                     \
