@@ -727,11 +727,18 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
     __shared__ int s_next;
 #ifdef ART_FWD_SINGLE_ITEM   // diagnostic build: one workgroup per item, no loop (A/B against the persistent form)
-    if ((int)blockIdx.x < work_item_count(launch.a))
-        trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(launch.a, launch.flux, launch.counts, (int)blockIdx.x,
-                                                   decode_work_item(launch.a, (int)blockIdx.x), launch.work_counter, &s_next);
-    return;
+    constexpr bool single_item = true;
+#else
+    // The cylinder and blocking instantiations keep more values alive per ray; inside the persistent loop they spill
+    // enough to lose 5-9 % (tools/blocking_bench.py, same-box A/B), so they take one item per workgroup.
+    constexpr bool single_item = CYL || BLOCKING;
 #endif
+    if constexpr (single_item) {
+        if ((int)blockIdx.x < work_item_count(launch.a))
+            trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(launch.a, launch.flux, launch.counts, (int)blockIdx.x,
+                                                       decode_work_item(launch.a, (int)blockIdx.x), launch.work_counter, &s_next);
+        return;
+    }
     if (threadIdx.x == 0) s_next = (int)blockIdx.x;          // the first gridDim.x items need no counter
     __syncthreads();
     for (;;) {
@@ -1183,6 +1190,12 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
     __shared__ int s_next;
     const int n_items = work_item_count(a);
     int item = blockIdx.x;
+    if constexpr (CYL || BLOCKING) {             // one item per workgroup, as in the forward kernel
+        if (item < n_items)
+            trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
+                                                                   g_pnormals, decode_work_item(a, item), work_counter, &s_next);
+        return;
+    }
     while (item < n_items) {
         trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
                                                                g_pnormals, decode_work_item(a, item), work_counter, &s_next);
@@ -1424,15 +1437,16 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
 #ifdef ART_FWD_SINGLE_ITEM
-        const int64_t blocks = items;
+        const int64_t persistent_blocks = items;
 #else
-        const int64_t blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items, resident_workgroups()) : items;
+        const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items, resident_workgroups()) : items;
 #endif
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
         // exits at once (the type is only known on the device)
 #define ART_LAUNCH_FWD(IL, CY, BL)                                                                               \
         do {                                                                                                     \
+            const int64_t blocks = (CY || BL) ? items : persistent_blocks;     /* see trace_fwd_lds_kernel */    \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL>),        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = next_work_counter(stream);                                                  \
@@ -1522,7 +1536,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
-        const int64_t blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
+        const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float);
         const bool atomic_out = a.n_rchunks > 1;
         if (atomic_out) {
@@ -1538,6 +1552,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         }
 #define ART_LAUNCH_BWD(IL, AT, CY, BL)                                                                           \
         do {                                                                                                     \
+            const int64_t blocks = (CY || BL) ? items : persistent_blocks;                                       \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = next_work_counter(stream);                                                  \
