@@ -6,6 +6,8 @@ not a chain of ATen ops.  Helper constructors follow ``artist/nurbs/utils.py``.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import ops
@@ -17,15 +19,18 @@ _DEGREE_CACHE: dict = {}
 
 def _host_degrees(degrees: torch.Tensor) -> tuple[int, int]:
     """``(p, q)`` as Python ints.  Reading a device tensor is a stream synchronisation, which would stop the host
-    from running ahead of the GPU once per epoch: the values are remembered per (storage, version)."""
+    from running ahead of the GPU once per epoch: the values are remembered for the SAME tensor object (weak
+    reference) at the same version - a new tensor, even at a recycled address, is read again."""
     if degrees.device.type == "cpu":
         return int(degrees[0]), int(degrees[1])
-    key = (degrees.data_ptr(), degrees._version, str(degrees.device))
-    if key not in _DEGREE_CACHE:
-        if len(_DEGREE_CACHE) > 256:
-            _DEGREE_CACHE.clear()
-        _DEGREE_CACHE[key] = (int(degrees[0]), int(degrees[1]))
-    return _DEGREE_CACHE[key]
+    entry = _DEGREE_CACHE.get(id(degrees))
+    if entry is not None and entry[0]() is degrees and entry[1] == degrees._version:
+        return entry[2]
+    if len(_DEGREE_CACHE) > 256:
+        _DEGREE_CACHE.clear()
+    value = (int(degrees[0]), int(degrees[1]))
+    _DEGREE_CACHE[id(degrees)] = (weakref.ref(degrees), degrees._version, value)
+    return value
 
 
 class NURBSSurfaces(torch.nn.Module):

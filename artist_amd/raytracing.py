@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import logging
 
+import weakref
+
 import torch
 
 from . import ops
@@ -197,10 +199,12 @@ class HeliostatRayTracer:
         """Largest scatter angle of the distortion dataset: bounds every heliostat's ray cone for the blocking cull.
         Computed once per dataset (one reduction + host read), again if a caller swaps the dataset's tensors."""
         ds = self.distortions_dataset
-        key = (ds.distortions_u.data_ptr(), ds.distortions_e.data_ptr(), tuple(ds.distortions_u.shape))
-        if self._scatter_angle_cache[0] != key:
-            value = float(torch.maximum(ds.distortions_u.abs().max(), ds.distortions_e.abs().max()))
-            self._scatter_angle_cache = (key, value)
+        u, e = ds.distortions_u, ds.distortions_e
+        cached = self._scatter_angle_cache[0]
+        # valid for the SAME tensor objects at the same versions only: a bound that is too small would change results
+        if cached is None or cached[0]() is not u or cached[1]() is not e or cached[2:] != (u._version, e._version):
+            value = float(torch.maximum(u.abs().max(), e.abs().max()))
+            self._scatter_angle_cache = ((weakref.ref(u), weakref.ref(e), u._version, e._version), value)
         return self._scatter_angle_cache[1]
 
     def trace_rays_per_target(self, incident_ray_directions, active_heliostats_mask, target_area_indices,
