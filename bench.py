@@ -285,7 +285,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "peak_measured_copy": MEASURED_COPY_GBS, "frac_of_measured_copy": achieved / MEASURED_COPY_GBS,
-                         "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"]},
+                         "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"],
+                         # what actually binds the kernel (not one of the contract's two roofs): see DESIGN.md 4.1 / 4.4
+                         "limiter": "fp32 VALU issue - SQ_ACTIVE_INST_VALU is 0.87 of the kernel's cycles "
+                                    "(profiles/r01_pmc_summary.txt), shader clock power-managed to 2.2 GHz (tools/timeline.sh)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np

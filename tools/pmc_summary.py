@@ -5,7 +5,7 @@ tag = sys.argv[1]
 for f in glob.glob(f"gpurun_out/prof_{tag}/*/*_kernel_stats.csv"):
     print("== kernel stats", f)
     for r in list(csv.reader(open(f)))[:14]:
-        print("  %-70s calls=%-5s avg_us=%-12s pct=%s" % (r[0][:70], r[1], r[3][:10], r[4]))
+        print("  %-70s calls=%-5s avg_ns=%-12s pct=%s" % (r[0][:70], r[1], r[3][:10], r[4]))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"gpurun_out/pmc_{tag}_*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
