@@ -941,9 +941,18 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
+#ifdef ART_DEBUG_TIMELINE
+    const int bid = item.h * a.n_pblocks * a.n_rchunks + item.pblock * a.n_rchunks + item.r0 / max(a.r_chunk, 1);
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+    ART_TIMELINE(1);
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
+    ART_TIMELINE(2);
     unsigned next_item = 0u;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
@@ -952,13 +961,44 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     // the next work item is requested at the start of the last pass and published at its end
     if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
     // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped
-    for (int row = wave; row < pth; row += nwaves) {
-        const float* g = G + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
-        float* trow = gtile + row * win.tw;
-        for (int c = lane; c < win.tw; c += 64) trow[c] = g[c];
+    // Four floats per lane (one 16-byte load, 4-byte aligned: a wave covers a 256-pixel row segment in one instruction)
+    // and four rows per trip, all four loads in flight before the first LDS store.  One float and one row at a time
+    // this staging was 48 exposed round trips per wave - 16 us of a 195 us workgroup (tools/timeline.sh), 12 us of it
+    // waiting for memory.
+    {
+        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+        const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;      // flat row k sits at gbase - k W
+        const int64_t dg = (int64_t)nwaves * a.W;
+        const int dt = nwaves * win.tw;
+        const int tw4 = win.tw & ~3;                                         // columns covered by whole 16-byte loads
+        int rb = wave;
+        for (; rb + 3 * nwaves < pth; rb += 4 * nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = 4 * lane; c < tw4; c += 256) {
+                const F4 v0 = *reinterpret_cast<const F4*>(g0 + c), v1 = *reinterpret_cast<const F4*>(g0 + c - dg);
+                const F4 v2 = *reinterpret_cast<const F4*>(g0 + c - 2 * dg), v3 = *reinterpret_cast<const F4*>(g0 + c - 3 * dg);
+                float* t = t0 + c;
+                t[0] = v0.x; t[1] = v0.y; t[2] = v0.z; t[3] = v0.w;
+                t[dt] = v1.x; t[dt + 1] = v1.y; t[dt + 2] = v1.z; t[dt + 3] = v1.w;
+                t[2 * dt] = v2.x; t[2 * dt + 1] = v2.y; t[2 * dt + 2] = v2.z; t[2 * dt + 3] = v2.w;
+                t[3 * dt] = v3.x; t[3 * dt + 1] = v3.y; t[3 * dt + 2] = v3.z; t[3 * dt + 3] = v3.w;
+            }
+            if (lane < 4 * (win.tw - tw4)) {                                  // the last 1-3 columns of the four rows
+                const int q = lane / (win.tw - tw4), c = tw4 + lane % (win.tw - tw4);
+                t0[q * dt + c] = g0[c - q * dg];
+            }
+        }
+        for (; rb < pth; rb += nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = lane; c < win.tw; c += 64) t0[c] = g0[c];
+        }
     }
     if (tid < 2) gtile[a.tile_cap + tid] = 0.0f;
     __syncthreads();
+    ART_TIMELINE(3);
+    ART_TIMELINE(4);
 
     const float kI = (a.mag * a.k_ext) * a.k_refl;
     float sx = 0.0f, sz = 0.0f;
@@ -1161,6 +1201,11 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     }
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();   // every wave is done with this band before it is overwritten
+    ART_TIMELINE(5);
+    ART_TIMELINE(6);
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots) g_timeline[8 * bid + 7] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
   }
     if (win.npass < 1 && tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));   // (never: npass >= 1)
     if constexpr (BLOCKING) {      // rectangle gradients of this workgroup -> the primitive tables
@@ -1575,6 +1620,15 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         } while (0)
         if (T > 0) ART_LAUNCH_BWD_TYPE(false);
         if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
+#ifdef ART_DEBUG_TIMELINE
+        if (const char* out = getenv("ART_TIMELINE_OUT_BWD")) {
+            const int64_t n = std::min<int64_t>(items, kTimelineSlots);
+            std::vector<unsigned long long> host(8 * n);
+            ART_HIP(hipStreamSynchronize(stream));
+            ART_HIP(hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * n));
+            if (FILE* f = fopen(out, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
+        }
+#endif
 #undef ART_LAUNCH_BWD_TYPE
 #undef ART_LAUNCH_BWD_BL
 #undef ART_LAUNCH_BWD

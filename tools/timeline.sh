@@ -8,11 +8,12 @@ cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
 ( cd artist_amd/csrc && for f in trace_kernels blocking_kernels flux_kernels nurbs_kernels align_kernels kinematics_kernels capi; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize \
-      -DART_DEBUG_TIMELINE -c $f.hip -o /tmp/tl_$f.o; done
+      -DART_DEBUG_TIMELINE $ART_EXTRA_DEFS -c $f.hip -o /tmp/tl_$f.o; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libtimeline.so /tmp/tl_*.o )
 exit 0
 fi
 H=${2:-1000}
-ARTIST_HIP_LIB=$PWD/artist_amd/libtimeline.so ART_TIMELINE_OUT=/tmp/timeline.bin timeout -k 10 300 \
-  python bench.py --heliostats $H --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
-python tools/timeline_report.py /tmp/timeline.bin
+ARTIST_HIP_LIB=$PWD/artist_amd/libtimeline.so ART_TIMELINE_OUT=/tmp/timeline.bin ART_TIMELINE_OUT_BWD=/tmp/timeline_bwd.bin \
+  timeout -k 10 300 python bench.py --heliostats $H --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
+echo "forward:"; python tools/timeline_report.py /tmp/timeline.bin
+echo "backward (phases: window, staging of dL/dflux, -, trace, -):"; python tools/timeline_report.py /tmp/timeline_bwd.bin
