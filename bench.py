@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-leve
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--heliostats", type=int, default=1000, help="total heliostats in the field (all ranks)")
     ap.add_argument("--rays", type=int, default=100, help="rays per surface point (Sun.number_of_rays)")
     ap.add_argument("--n-eval", type=int, default=50, help="evaluation points per facet per direction")
