@@ -266,7 +266,7 @@ __device__ __forceinline__ void tap_range(float scale, float centre, int n, int 
 // of a row by its 64 pixels - they are computed once per tile into LDS - and the sum factorises into a horizontal
 // pass (4 global loads per output row and column, kept in LDS) and a vertical pass (4 LDS reads per pixel).  A bitmap
 // whose crop scale needs more than four taps per axis (scale < ~0.6) takes the per-pixel form.
-constexpr int kTileX = 64, kTileY = 16, kTaps = 4, kTileRows = 32;
+constexpr int kTileX = 64, kTileY = 32, kTaps = 4, kTileRows = 64;
 __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* __restrict__ dims, const float* __restrict__ com,
                                                                   const float* __restrict__ gcom,
                                                                   const float* __restrict__ grad_out, int Hh, int W,
