@@ -261,7 +261,7 @@ __device__ __forceinline__ void tap_range(float scale, float centre, int n, int 
     }
 }
 
-// The same gradient organised by tiles of 64 x 16 input pixels: the map is separable, so the
+// The same gradient organised by tiles of 64 x 32 input pixels: the map is separable, so the
 // first output index and the (at most four) weights of a column are shared by the 16 pixels of that column and those
 // of a row by its 64 pixels - they are computed once per tile into LDS - and the sum factorises into a horizontal
 // pass (4 global loads per output row and column, kept in LDS) and a vertical pass (4 LDS reads per pixel).  A bitmap
