@@ -42,6 +42,7 @@ struct TraceArgs {
     int mode;                 // 0: bitmap per heliostat, 1: bitmap per target
     int r_chunk;              // samples per block
     int n_rchunks;            // ceil(R / r_chunk)
+    int reverse_bwd;          // backward queue order (experiment knob; the list order measured best)
     int reverse_items;        // forward queue order: 0 first-to-last, 1 last-to-first, -1 decided on the device (the end
                               // of the list whose heliostat is farther from its target goes first)
     int n_tail;               // windowed kernels: the LAST n_tail (heliostat, point block, sample chunk) items are

@@ -1263,9 +1263,10 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
                                                                    g_pnormals, decode_work_item(a, item), work_counter, &s_next);
         return;
     }
+    const bool reverse = a.reverse_bwd != 0;
     while (item < n_items) {
         trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
-                                                               g_pnormals, decode_work_item(a, item), work_counter, &s_next);
+                                                               g_pnormals, decode_work_item(a, item, reverse), work_counter, &s_next);
         __syncthreads();
         item = s_next;
         __syncthreads();
@@ -1452,6 +1453,7 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     a.n_rchunks = (a.R + chunk - 1) / chunk;
     // the last items of the queue are dealt in halves (decode_work_item) when a chunk has samples to split
     const int64_t n_base = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
+    a.reverse_bwd = env_int("ARTIST_HIP_BWD_REVERSE", 0);
     a.reverse_items = env_int("ARTIST_HIP_REVERSE", -1);       // -1: decided on the device (farther_end_is_last)
     // (measured neutral on the metric field - 1000 and 125 heliostats - so it is off unless ARTIST_HIP_TAIL=1)
     a.n_tail = chunk >= 8 && env_int("ARTIST_HIP_TAIL", 0) != 0 ? (int)std::min<int64_t>(n_base, resident_workgroups()) : 0;
