@@ -1513,3 +1513,65 @@ def test_from_hdf5_classmethods_equal_the_scenario_loader():
     for ours, ref in zip(field.heliostat_groups, whole.heliostat_field.heliostat_groups):
         assert torch.equal(ours.surface_points, ref.surface_points) and torch.equal(ours.surface_normals, ref.surface_normals)
         assert torch.equal(ours.kinematics.actuators.non_optimizable_parameters, ref.kinematics.actuators.non_optimizable_parameters)
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    """One rank of the two-process run below: owns heliostats i = rank (mod world), traces them with the HIP kernels,
+    reduces the per-target flux and gathers the per-point gradients' norms."""
+    import os
+
+    import torch.distributed as dist
+
+    from artist_amd import ops
+    from artist_amd.distributed import all_reduce_sum_async, gather_owned_rows, owned_heliostats
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = dict(np.load(__import__("conftest").GOLDEN / "mid_256.npz"))
+        H = 8
+        rep = lambda x: np.concatenate([x] * (H // x.shape[0]))        # an 8-heliostat field from the 2-heliostat fixture
+        own = owned_heliostats(H, world, rank)
+        sel = lambda x: t(rep(x)[own])
+        inp = dict(origins=sel(d["aligned_points"]).requires_grad_(True), normals=sel(d["aligned_normals"]), incident=sel(d["incident"]),
+                   target_idx=sel(d["target_idx"]), centers=t(d["target_centers"]), plane_normals=t(d["target_normals"]),
+                   dims=t(d["target_dims"]), ray_magnitude=float(d["ray_magnitude"]), extinction=float(d["extinction"]),
+                   reflectivity=float(d["reflectivity"]), resolution=tuple(int(v) for v in d["resolution"]))
+        inp["dist_u"], inp["dist_e"] = interleave(rep(d["distortions_u"])[own], rep(d["distortions_e"])[own])
+        flux = ops.trace_rays(**inp)[0]
+        T = d["target_centers"].shape[0]
+        per_target = ops.per_target_sum(flux.detach(), inp["target_idx"], T)
+        pending = all_reduce_sum_async(per_target)
+        flux.sum().backward()
+        norms = gather_owned_rows(inp["origins"].grad.flatten(1).norm(dim=1, keepdim=True), H)
+        pending.wait()
+        if rank == 0:
+            np.savez(out_dir / "sharded.npz", per_target=n(per_target), norms=n(norms))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_share_the_field(tmp_path):
+    """Two real processes (gloo rendezvous, both on this GPU): sharded trace + flux all-reduce + gradient gather equal
+    the single-process result."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from artist_amd import ops
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, tmp_path), nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+    d = dict(np.load(__import__("conftest").GOLDEN / "mid_256.npz"))
+    rep = lambda x: np.concatenate([x] * 4)
+    inp = dict(origins=t(rep(d["aligned_points"])).requires_grad_(True), normals=t(rep(d["aligned_normals"])), incident=t(rep(d["incident"])),
+               target_idx=t(rep(d["target_idx"])), centers=t(d["target_centers"]), plane_normals=t(d["target_normals"]),
+               dims=t(d["target_dims"]), ray_magnitude=float(d["ray_magnitude"]), extinction=float(d["extinction"]),
+               reflectivity=float(d["reflectivity"]), resolution=tuple(int(v) for v in d["resolution"]))
+    inp["dist_u"], inp["dist_e"] = interleave(rep(d["distortions_u"]), rep(d["distortions_e"]))
+    flux = ops.trace_rays(**inp)[0]
+    flux.sum().backward()
+    want = n(ops.per_target_sum(flux.detach(), inp["target_idx"], d["target_centers"].shape[0]))
+    assert rel_l2(got["per_target"], want) < 1e-6
+    np.testing.assert_allclose(got["norms"], n(inp["origins"].grad.flatten(1).norm(dim=1, keepdim=True)), rtol=1e-5)
