@@ -107,6 +107,7 @@ class HeliostatRayTracer:
             self._scatter_angle_cache = (None, 0.0)
         #: reproduce which rectangles the reference's LBVH can reach (see artist_amd/blocking.py); False = every
         #: rectangle whose box is hit, as ``lbvh_filter_blocking_planes`` documents
+        self._checked_targets = None
         self.lbvh_compat = True
         #: indices of the rectangles the last ``trace_rays`` call filtered (blocking only)
         self.filtered_blocking_primitive_indices = None
@@ -154,7 +155,9 @@ class HeliostatRayTracer:
         """Heliostat ray tracing (:220-508).  Returns ``(flux [H,res_u,res_e], intercept_factor [H],
         on_target_factor [H], blocking_factor [H])`` for the heliostat samples owned by this rank."""
         group = self.heliostat_group
-        assert torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
+        # (the same tensor object needs no device comparison: one host-device synchronisation less per epoch)
+        assert group.active_heliostats_mask is active_heliostats_mask or \
+            torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
             "Some heliostats were not aligned and cannot be raytraced."
 
         points, normals = group.active_surface_points, group.active_surface_normals
@@ -164,15 +167,19 @@ class HeliostatRayTracer:
                 group.preferred_reflection_directions = reflect(incident_ray_directions.unsqueeze(1), normals)
 
         tower = self.scenario.solar_tower
+        # the kernels index the target tables with these: validated on the host, once per tensor object and version
+        checked = self._checked_targets
+        if target_area_indices.numel() > 0 and not (checked is not None and checked[0]() is target_area_indices and
+                                                     checked[1] == target_area_indices._version):
+            lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
+            if lo < 0 or hi >= int(tower.number_of_target_areas_per_type.sum()):
+                raise IndexError("target_area_indices out of range")
+            self._checked_targets = (weakref.ref(target_area_indices), target_area_indices._version)
         idx, dist_u, dist_e = self._local_rows(device)
         if idx is not None:
             points, normals = points.index_select(0, idx), normals.index_select(0, idx)
             incident_ray_directions = incident_ray_directions.index_select(0, idx)
             target_area_indices = target_area_indices.index_select(0, idx)
-        if target_area_indices.numel() > 0:
-            lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
-            if lo < 0 or hi >= int(tower.number_of_target_areas_per_type.sum()):
-                raise IndexError("target_area_indices out of range")
 
         ray_magnitude = float(self.ray_magnitude)
         width, height = self._resolution_host
@@ -215,7 +222,9 @@ class HeliostatRayTracer:
         first, cylindrical second).  Extension of the reference API for field-scale flux prediction
         (configs 3 and 5)."""
         group = self.heliostat_group
-        assert torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
+        # (the same tensor object needs no device comparison: one host-device synchronisation less per epoch)
+        assert group.active_heliostats_mask is active_heliostats_mask or \
+            torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
             "Some heliostats were not aligned and cannot be raytraced."
         points, normals = group.active_surface_points, group.active_surface_normals
         device = points.device if device is None else torch.device(device)
