@@ -1438,7 +1438,8 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     if ((int64_t)p_block_target * a.R < cfg.min_rays) p_block_target = (int)((cfg.min_rays + a.R - 1) / a.R);
     if (p_block_target > a.P) p_block_target = a.P;
     const int nblk = (a.P + p_block_target - 1) / p_block_target;
-    const int pb = ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
+    // (ARTIST_HIP_PBLOCK_EXACT=1: balanced blocks that need not fill every lane - for workgroup sizes that do not divide P)
+    const int pb = env_int("ARTIST_HIP_PBLOCK_EXACT", 0) ? (a.P + nblk - 1) / nblk : ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
     a.p_block = pb;
     a.n_pblocks = (a.P + pb - 1) / pb;
     a.tile_cap = cfg.tile_cap;

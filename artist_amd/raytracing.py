@@ -73,17 +73,21 @@ class HeliostatRayTracer:
         self.batch_size = batch_size   # accepted for API parity; the fused kernel has no per-ray intermediates
 
         self.light_source = scenario.light_sources.light_source_list[0]
-        self.distortions_dataset = DistortionsDataset(
-            light_source=self.light_source,
-            number_of_points_per_heliostat=self.heliostat_group.active_surface_points.shape[1],
-            number_of_active_heliostats=self.heliostat_group.number_of_active_heliostats,
-            random_seed=random_seed,
-        )
+        number_of_samples = int(self.heliostat_group.number_of_active_heliostats)
         self.distortions_sampler = RestrictedDistributedSampler(
-            number_of_samples=len(self.distortions_dataset),
+            number_of_samples=number_of_samples,
             number_of_active_heliostats=int((self.heliostat_group.active_heliostats_mask > 0).sum()),
             world_size=self.world_size,
             rank=self.rank,
+        )
+        # A rank keeps the distortions of the heliostat samples it owns only (the reference samples all [H,R,P] on every
+        # rank, sampling.py:49-53): 8 B per ray of this rank instead of 8 B per ray of the field.
+        self.distortions_dataset = DistortionsDataset(
+            light_source=self.light_source,
+            number_of_points_per_heliostat=self.heliostat_group.active_surface_points.shape[1],
+            number_of_active_heliostats=number_of_samples,
+            random_seed=random_seed,
+            rows=self.distortions_sampler.rank_indices if self.world_size > 1 else None,
         )
         self.bitmap_resolution = bitmap_resolution
         self._resolution_host = (int(bitmap_resolution[0]), int(bitmap_resolution[1]))
@@ -126,25 +130,25 @@ class HeliostatRayTracer:
 
     # ------------------------------------------------------------------------------------------
     def get_sampler_indices(self) -> torch.Tensor:
-        """Indices of the distortions dataset assigned to this rank (:205-218)."""
+        """Indices of the heliostat samples assigned to this rank (:205-218)."""
         return torch.tensor(self.distortions_sampler.rank_indices, device=self.distortions_dataset.distortions_u.device)
 
     def _local_rows(self, device):
-        """(index tensor or None, dist_u, dist_e) for the rows this rank owns."""
+        """(index tensor of the owned heliostat samples or None when this rank owns all, dist_u, dist_e of those rows)."""
         if self._local_cache is not None and self._local_cache[0] == device:
             return self._local_cache[1:]
-        du, de = self.distortions_dataset.distortions_u, self.distortions_dataset.distortions_e
+        ds = self.distortions_dataset
+        du, de = ds.distortions_u, ds.distortions_e
         idx_list = self.distortions_sampler.rank_indices
-        if len(idx_list) == du.shape[0] and idx_list == list(range(du.shape[0])):
-            idx = None
-            if du.device != device:
-                both = torch.stack((du, de), dim=-1).to(device)      # keep the interleaved layout
-                du, de = both[..., 0], both[..., 1]
-        else:
-            idx = torch.tensor(idx_list, dtype=torch.long, device=du.device)
-            both = torch.stack((du.index_select(0, idx), de.index_select(0, idx)), dim=-1).to(device)
+        n_total = int(self.heliostat_group.number_of_active_heliostats)
+        owns_all = len(idx_list) == n_total and idx_list == list(range(n_total))
+        if len(idx_list) != du.shape[0]:            # a dataset someone swapped in: select the owned rows here
+            sel = torch.tensor(idx_list, dtype=torch.long, device=du.device)
+            du, de = du.index_select(0, sel), de.index_select(0, sel)
+        if du.device != device:
+            both = torch.stack((du, de), dim=-1).to(device)          # one interleaved buffer on the device
             du, de = both[..., 0], both[..., 1]
-            idx = idx.to(device)
+        idx = None if owns_all else torch.tensor(idx_list, dtype=torch.long, device=device)
         self._local_cache = (device, idx, du, de)
         return idx, du, de
 
@@ -167,14 +171,7 @@ class HeliostatRayTracer:
                 group.preferred_reflection_directions = reflect(incident_ray_directions.unsqueeze(1), normals)
 
         tower = self.scenario.solar_tower
-        # the kernels index the target tables with these: validated on the host, once per tensor object and version
-        checked = self._checked_targets
-        if target_area_indices.numel() > 0 and not (checked is not None and checked[0]() is target_area_indices and
-                                                     checked[1] == target_area_indices._version):
-            lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
-            if lo < 0 or hi >= int(tower.number_of_target_areas_per_type.sum()):
-                raise IndexError("target_area_indices out of range")
-            self._checked_targets = (weakref.ref(target_area_indices), target_area_indices._version)
+        self._validate_targets(target_area_indices, tower)
         idx, dist_u, dist_e = self._local_rows(device)
         if idx is not None:
             points, normals = points.index_select(0, idx), normals.index_select(0, idx)
@@ -191,6 +188,18 @@ class HeliostatRayTracer:
         if self.blocking_active:
             self.filtered_blocking_primitive_indices = torch.nonzero(flags, as_tuple=True)[0]
         return flux, factors[0], factors[1], factors[2]
+
+    def _validate_targets(self, target_area_indices, tower) -> None:
+        """The kernels index the target tables with these: validated on the host, once per tensor object and version
+        (one host-device synchronisation, not one per epoch).  The C ABI checks them again on the device and reports
+        ``ART_ETARGET`` instead of reading out of bounds (include/artist_hip.h)."""
+        checked = self._checked_targets
+        if target_area_indices.numel() > 0 and not (checked is not None and checked[0]() is target_area_indices and
+                                                     checked[1] == target_area_indices._version):
+            lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
+            if lo < 0 or hi >= int(tower.number_of_target_areas_per_type.sum()):
+                raise IndexError("target_area_indices out of range")
+            self._checked_targets = (weakref.ref(target_area_indices), target_area_indices._version)
 
     def _blocking_arguments(self, idx, active_heliostats_mask):
         """Rectangles of all heliostats (:291-301) + the rectangle index of each traced heliostat (:445-448)."""
@@ -229,6 +238,7 @@ class HeliostatRayTracer:
         points, normals = group.active_surface_points, group.active_surface_normals
         device = points.device if device is None else torch.device(device)
         tower = self.scenario.solar_tower
+        self._validate_targets(target_area_indices, tower)
         idx, dist_u, dist_e = self._local_rows(device)
         if idx is not None:
             points, normals = points.index_select(0, idx), normals.index_select(0, idx)

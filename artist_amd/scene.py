@@ -42,20 +42,41 @@ class Sun:
         return cls(number_of_rays=t["number_of_rays"], distribution_parameters=t["distribution_parameters"], device=device)
 
     def get_distortions(self, number_of_points: int, number_of_active_heliostats: int, random_seed: int = 7):
-        torch.manual_seed(random_seed)
-        if torch.cuda.is_available():
-            torch.cuda.manual_seed(random_seed)
-        shape = (number_of_active_heliostats, self.number_of_rays, number_of_points)
+        loc = self.distribution.loc
+        if loc.device.type == "cpu":
+            torch.manual_seed(random_seed)
+            sample = self.distribution.sample((number_of_active_heliostats, self.number_of_rays, number_of_points))
+            distortions_u, distortions_e = sample.permute(3, 0, 1, 2)
+            return distortions_u, distortions_e
+        return self.get_distortions_rows(range(number_of_active_heliostats), number_of_points, number_of_active_heliostats,
+                                         random_seed)
+
+    def get_distortions_rows(self, rows, number_of_points: int, number_of_active_heliostats: int, random_seed: int = 7):
+        """Rows ``rows`` of the ``[H,R,P]`` distortion views when the light source lives on the GPU (None on the CPU: the
+        caller then slices the reference's one seeded stream, ``artist_amd.sampling.DistortionsDataset``).
+
+        On the device every heliostat sample has a Philox stream of its own, keyed by (seed, row): a rank that owns
+        some of the heliostats draws exactly its rows, bit-identical to the rows of an unsharded draw,
+        and nothing of size ``[H,R,P]`` exists anywhere.  Same law as ``MultivariateNormal.sample``
+        (``loc + scale_tril @ eps``), written element-wise: the batched 2x2 matrix-vector product of torch's
+        ``MultivariateNormal.sample`` faulted on ROCm for ~1e7 and more samples."""
         loc, tril = self.distribution.loc, self.distribution.scale_tril
         if loc.device.type == "cpu":
-            sample = self.distribution.sample(shape)
+            return None
+        rows = [int(r) for r in rows]
+        out = torch.empty((len(rows), self.number_of_rays, number_of_points, 2), dtype=loc.dtype, device=loc.device)
+        gen = torch.Generator(device=loc.device)
+        for k, row in enumerate(rows):
+            gen.manual_seed((int(random_seed) * 1000003 + row) & 0x7FFFFFFFFFFFFFFF)
+            torch.randn(out[k].shape, generator=gen, dtype=loc.dtype, device=loc.device, out=out[k])
+        if float(tril[1, 0]) != 0.0:
+            out[..., 1] = tril[1, 0] * out[..., 0] + tril[1, 1] * out[..., 1]
         else:
-            # same draw as MultivariateNormal.sample (loc + scale_tril @ eps), written element-wise: its batched
-            # 2x2 matrix-vector product faults on ROCm for ~1e7 and more samples
-            eps = torch.randn(shape + (2,), dtype=loc.dtype, device=loc.device)
-            sample = torch.stack((loc[0] + tril[0, 0] * eps[..., 0],
-                                  loc[1] + tril[1, 0] * eps[..., 0] + tril[1, 1] * eps[..., 1]), dim=-1)
-        distortions_u, distortions_e = sample.permute(3, 0, 1, 2)
+            out[..., 1] *= tril[1, 1]
+        out[..., 0] *= tril[0, 0]
+        if float(loc.abs().max()) != 0.0:
+            out += loc
+        distortions_u, distortions_e = out.permute(3, 0, 1, 2)
         return distortions_u, distortions_e
 
 

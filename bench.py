@@ -32,8 +32,9 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-MEASURED_COPY_GBS = 4796.8   # tools/hbm_peak.py on this pool's MI355X (profiles/r01_hbm_peak.json)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_FILE = ROOT / "profiles" / "r02_hbm_peak.json"       # tools/hbm_peak.hip on this pool's MI355X (float4 copy / read / write)
+HBM_TRAFFIC_FILE = ROOT / "profiles" / "r02_hbm_traffic.json"  # rocprofv3 --pmc passes of this command (tools/pmc_hbm.sh)
 
 
 def parse():
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument("--n-eval", type=int, default=50, help="evaluation points per facet per direction")
     ap.add_argument("--n-cp", type=int, default=10, help="NURBS control points per facet per direction")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle comparison of the timed rays")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -92,14 +94,92 @@ def cpu_baseline(args, cp_host, canting, transl, uv, orientation, incident, plan
                       f"({h_count * R * P:.2e} rays) in {t:.2f} s"}
 
 
+def torch_eager_baseline(args, ap, an, inc, planar, seconds):
+    """The reference's own shape of the hot path - eager PyTorch-CPU ops with materialised per-ray intermediates
+    (tools/torch_eager_baseline.py, pinned to the reference-generated fixtures) - fwd+bwd on a bounded sample of the
+    metric workload, batch_size in {10, 100} best-of, torch's own thread pool."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import torch_eager_baseline as teb
+
+    threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("ARTIST_CPU_THREADS", "16"))))
+    torch.set_num_threads(threads)
+    R, P = args.rays, 4 * args.n_eval * args.n_eval
+    tables = tuple(t.detach().cpu() for t in (planar.centers, planar.normals, planar.dimensions))
+    gen = torch.Generator().manual_seed(7)
+
+    def run(h, batch):
+        both = torch.randn((h, R, P, 2), generator=gen) * (4.3681e-06 ** 0.5)
+        return teb.time_epoch(ap[:h], an[:h], inc[:h], both[..., 0], both[..., 1], torch.zeros(h, dtype=torch.long), *tables,
+                              batch_size=batch, backward=True)
+
+    t1 = run(1, 10)                                        # 1e6 rays: sizes the sample
+    h = max(2, min(ap.shape[0], 20, int(seconds / 2 / max(t1, 1e-3))))
+    best = None
+    for batch in (10, 100):
+        t = run(h, batch)
+        if best is None or t < best[0]:
+            best = (t, batch)
+    return {"value": h * R * P / best[0], "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"eager PyTorch-CPU restatement of heliostat_ray_tracer.py:316-506 + autograd, fwd+bwd of {h} heliostats x {R} rays "
+                      f"x {P} points ({h * R * P:.2e} rays) in {best[0]:.2f} s, batch_size {best[1]} (best of 10/100), "
+                      f"torch {torch.__version__}, {threads} threads"}
+
+
+def correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops):
+    """Four heliostats of the field that was just timed (first, one third, two thirds, last of this rank's list = near to far)
+    through the HIP kernels once more and through the oracle: flux relative L2, ray counters, gradient relative L2."""
+    import numpy as np
+
+    import oracle
+    H = ap.shape[0]
+    sel = sorted({0, H // 3, (2 * H) // 3, H - 1})
+    idx = torch.tensor(sel, device=ap.device)
+    a, n_, i_, t_ = ap[idx].contiguous(), an[idx].contiguous(), inc[idx].contiguous(), tix[idx].contiguous()
+    both = torch.stack((dist_u[idx], dist_e[idx]), dim=-1).contiguous()
+    du, de = both[..., 0], both[..., 1]
+    ag, ng = a.clone().requires_grad_(True), n_.clone().requires_grad_(True)
+    flux, factors = ops.trace_rays(ag, ng, i_, du, de, t_, planar.centers, planar.normals, planar.dimensions, 1.0, 0.0, 0.935,
+                                   (256, 256))
+    gen = torch.Generator(device=ap.device).manual_seed(11)
+    w = torch.rand(flux.shape, generator=gen, device=ap.device)
+    go, gn = torch.autograd.grad(flux, (ag, ng), w)
+    npf = lambda x: x.detach().cpu().numpy()  # noqa: E731
+    tabs = (npf(planar.centers), npf(planar.normals), npf(planar.dimensions))
+    o_flux, o_fac = oracle.trace_fwd(npf(a), npf(n_), npf(i_), npf(du), npf(de), npf(t_).astype(np.int32), *tabs, (256, 256))
+    o_go, o_gn = oracle.trace_bwd(npf(a), npf(n_), npf(i_), npf(du), npf(de), npf(t_).astype(np.int32), *tabs, (256, 256), npf(w))
+    rel = lambda x, y: float(np.linalg.norm(x.astype(np.float64) - y) / max(np.linalg.norm(y.astype(np.float64)), 1e-300))  # noqa: E731
+    return {"heliostats": sel, "rays": int(len(sel) * du.shape[1] * du.shape[2]),
+            "flux_rel_l2": rel(npf(flux), o_flux), "flux_rel_l2_per_heliostat": [rel(npf(flux[k]), o_flux[k]) for k in range(len(sel))],
+            "ray_counters_equal": bool(np.array_equal(npf(factors[:2]), o_fac[:2])),
+            "grad_origins_rel_l2": rel(npf(go), o_go), "grad_normals_rel_l2": rel(npf(gn), o_gn),
+            "against": "oracle (C restatement of the reference, fp32 op for op) on the same inputs"}
+
+
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script under ``torch.distributed.run``
+    (one process per GPU, rendezvous on 127.0.0.1) as a CHILD process and hand back its exit code.  The parent never
+    touches the GPU (tutorials/02_heliostat_raytracing_distributed_tutorial.py:60-75 leaves the launch to torchrun too)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(pathlib.Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -112,6 +192,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        print(f"[bench] rank {rank}/{world} on {dev} ({torch.cuda.get_device_name(dev)}), backend {backend}", file=sys.stderr, flush=True)
 
     from artist_amd import HeliostatRayTracer, NURBSSurfaces
     from artist_amd.distributed import all_reduce_sum_async, gather_owned_rows, owned_heliostats
@@ -246,16 +328,28 @@ def main():
     else:
         dom = dict(kernel="trace_fwd_lds_kernel", ms=ms_fwd, bytes=bytes_fwd)
     achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (profiles/r01_hbm_traffic.json,
-    # FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes); only valid for the profiled workload.
-    traffic = None
+    # HBM bytes per launch: REPLAYED from the rocprofv3 --pmc passes of this same command that are committed under
+    # profiles/ (separate passes, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes) - not measured by this run,
+    # hence "traffic_source"; null when the profiled workload is not the one timed here.
+    traffic, traffic_source = None, None
     try:
-        prof = json.load(open(ROOT / "profiles" / "r01_hbm_traffic.json"))
+        prof = json.load(open(HBM_TRAFFIC_FILE))
         c = prof["config"]
         if (c["heliostats"], c["rays_per_point"], c["points_per_heliostat"]) == (H, R, P) and world == 1:
             traffic = prof[dom["kernel"]]["total_bytes"]
+            traffic_source = f"replayed from {HBM_TRAFFIC_FILE.relative_to(ROOT)} (rocprofv3 --pmc, not measured in this run)"
     except (OSError, KeyError, ValueError):
         pass
+    measured_peak = None
+    try:
+        measured_peak = json.load(open(HBM_PEAK_FILE))
+    except (OSError, ValueError):
+        pass
+
+    # ---- correctness stamp, outside every timed region: the rays just timed against the oracle ---------------
+    check = None
+    if rank == 0 and not args.no_check:
+        check = correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops)
 
     if rank == 0:
         total_rays = H_total * R * P
@@ -283,12 +377,18 @@ def main():
                         "trace_fwd_GBps": bytes_fwd / (ms_fwd * 1e-3) / 1e9,
                         "trace_bwd_GBps": bytes_bwd / (ms_bwd * 1e-3) / 1e9},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "peak_measured_copy": MEASURED_COPY_GBS, "frac_of_measured_copy": achieved / MEASURED_COPY_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"],
-                         # what actually binds the kernel (not one of the contract's two roofs): see DESIGN.md 4.1 / 4.4
-                         "limiter": "fp32 VALU issue - SQ_ACTIVE_INST_VALU is 0.87 of the kernel's cycles "
-                                    "(profiles/r01_pmc_summary.txt), shader clock power-managed to 2.2 GHz (tools/timeline.sh)"},
+                         # what a hand-written float4 streaming kernel reaches on this pool's MI355X (tools/hbm_peak.hip):
+                         # replayed from profiles/, next to the 8 TB/s spec peak that `frac` is quoted against
+                         "peak_measured": None if measured_peak is None else {
+                             "copy": measured_peak["copy"], "read": measured_peak["read"], "write": measured_peak["write"],
+                             "unit": "GB/s", "source": f"replayed from {HBM_PEAK_FILE.relative_to(ROOT)}",
+                             "frac_of_measured_read": achieved / measured_peak["read"]},
+                         # what binds the kernel (neither of the contract's two roofs): replayed analysis, DESIGN.md 4.0 / 4.1
+                         "limiter_note": "vector-instruction issue, not HBM: see DESIGN.md section 4.0 (tools/issue_bench.hip, "
+                                         "profiles/r02_issue_bench.json) - stated from profiles/, not measured by this run"},
+            "check": check,
         }
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
@@ -298,6 +398,9 @@ def main():
                 args, npf(cp[:k]), npf(canting[:k]), npf(transl[:k]), npf(uv[:1].contiguous()),
                 npf(orientation[:k]), npf(inc[:k]), (npf(planar.centers), npf(planar.normals), npf(planar.dimensions)),
                 args.cpu_seconds)
+            # the reference-shaped path (eager PyTorch-CPU op chain) next to the C port
+            out["cpu_baseline"]["reference_shape_torch"] = torch_eager_baseline(
+                args, ap[:min(H, 64)].cpu(), an[:min(H, 64)].cpu(), inc[:min(H, 64)].cpu(), planar, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

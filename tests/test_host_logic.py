@@ -240,3 +240,52 @@ def test_h5lite_reads_groups_datasets_and_attributes():
         assert len(names) == 1 and f["heliostats"][names[0]]["position"].shape == (4,)
     with pytest.raises(OSError):
         h5lite.File(pathlib.Path(__file__), "r")
+
+
+@pytest.mark.parametrize("name", ["small_deg3", "small_deg2_tilted", "small_offtarget", "mid_256"])
+def test_torch_eager_baseline_equals_reference_fixtures(golden, name):
+    """tools/torch_eager_baseline.py (the reference-shaped CPU baseline that bench.py times) against what the imported
+    reference produced on the same inputs: flux, the two ray-count factors and the autograd gradients."""
+    import sys
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent / "tools"))
+    import torch_eager_baseline as teb
+
+    d = golden(name)
+    tt = lambda k: torch.from_numpy(np.ascontiguousarray(d[k]))  # noqa: E731
+    pts, nrm = tt("aligned_points").requires_grad_(True), tt("aligned_normals").requires_grad_(True)
+    for batch in (1, 100):
+        flux, intercept, on_target = teb.trace_rays(
+            pts, nrm, tt("incident"), tt("distortions_u"), tt("distortions_e"), tt("target_idx"), tt("target_centers"),
+            tt("target_normals"), tt("target_dims"), tuple(int(v) for v in d["resolution"]), float(d["ray_magnitude"]),
+            float(d["extinction"]), float(d["reflectivity"]), batch_size=batch)
+        ref = d["flux"].astype(np.float64)
+        err = np.linalg.norm(flux.detach().numpy() - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert err < 1e-6, (name, batch, err)          # same ATen ops; scatter_add_ order is the only freedom
+        assert np.array_equal(intercept.numpy(), d["intercept"]) and np.array_equal(on_target.numpy(), d["on_target"])
+    (flux * tt("loss_weights")).sum().backward()
+    for got, key in ((pts.grad, "grad_aligned_points"), (nrm.grad, "grad_aligned_normals")):
+        ref = d[key].astype(np.float64)
+        assert np.linalg.norm(got.numpy() - ref) / np.linalg.norm(ref) < 1e-5, (name, key)
+
+
+def test_distortions_dataset_keeps_owned_rows_of_the_same_seeded_stream():
+    """A rank's DistortionsDataset holds its own rows only, and they are the rows of the unsharded seed-7 tensor
+    (reference recipe: artist/scene/sun.py:224-233; partition: artist/raytracing/sampling.py:129-146)."""
+    from artist_amd.sampling import DistortionsDataset, RestrictedDistributedSampler
+    from artist_amd.scene import Sun
+
+    for (H, R, P) in [(5, 4, 64), (7, 3, 63)]:            # 2RP a multiple of 16 (stream slicing) / not (sample + slice)
+        sun = Sun(R, device=torch.device("cpu"))
+        full = DistortionsDataset(sun, P, H, random_seed=7)
+        ref_u, ref_e = sun_distortions(H, R, P)
+        assert torch.equal(full.distortions_u, ref_u) and torch.equal(full.distortions_e, ref_e)
+        seen = []
+        for rank in range(3):
+            rows = RestrictedDistributedSampler(H, H, world_size=3, rank=rank).rank_indices
+            part = DistortionsDataset(sun, P, H, random_seed=7, rows=rows)
+            assert len(part) == len(rows) and part.distortions_u.shape == (len(rows), R, P)
+            assert torch.equal(part.distortions_u, ref_u[rows]) and torch.equal(part.distortions_e, ref_e[rows])
+            # still the two stride-2 views of one interleaved buffer (one 8-byte load per ray in the kernel)
+            assert part.distortions_u.stride() == part.distortions_e.stride() and part.distortions_u.stride(-1) == 2
+            seen += rows
+        assert sorted(seen) == list(range(H))
