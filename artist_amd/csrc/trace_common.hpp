@@ -84,6 +84,33 @@ __device__ __forceinline__ void load_dist_row(const float* __restrict__ row_u, c
     }
 }
 
+// The same fetch for the hot sample loops: non-temporal (the 8 B/ray stream is read exactly once; MI355X_MICROARCH.md
+// "nt-weights": issued -> landed ~18 % sooner), which matters because these kernels live on the latency of this stream.
+template <bool INTERLEAVED>
+__device__ __forceinline__ void load_dist_stream(const float* __restrict__ row_u, const float* __restrict__ row_e,
+                                                 int lane_off, float& u, float& e)
+{
+#ifdef ART_ABLATE_NO_LOADS
+    u = 1e-6f * (float)(lane_off & 1023); e = -1e-6f * (float)((lane_off >> 3) & 1023);
+    return;
+#endif
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    if constexpr (INTERLEAVED) {
+#ifdef ART_STREAM_PLAIN_LOADS
+        const v2f v = *reinterpret_cast<const v2f*>(row_u + lane_off);
+#else
+        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(row_u + lane_off));
+#endif
+        u = v.x; e = v.y;
+    } else {
+#ifdef ART_STREAM_PLAIN_LOADS
+        u = row_u[lane_off]; e = row_e[lane_off];
+#else
+        u = __builtin_nontemporal_load(row_u + lane_off); e = __builtin_nontemporal_load(row_e + lane_off);
+#endif
+    }
+}
+
 static inline bool fill_args(TraceArgs& a, const float* origins, const float* normals, const float* incident,
                       const float* dist_u, const float* dist_e, int64_t sh, int64_t sr, int64_t sp,
                       const int32_t* target_idx, const float* centers, const float* pnormals, const float* dims,

@@ -737,13 +737,264 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     if (tid < 3 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
+
+// --------------------------------------------------------------------------------------------
+// The planar, non-blocking forward item with the LEAN ray body (the production path of the metric workload).
+//
+// What tools/issue_bench.hip measured on gfx950 (true shader cycles, profiles/r02_issue_bench.json) shapes this body:
+//   * v_fma / v_mul / v_add / v_sub f32, v_add_u32, v_mov on VGPRs issue every ~2 cycles per SIMD; everything else
+//     (v_cvt, v_trunc, v_med3, v_cmp, v_max, v_mad_u32_u24, v_lshl_add, DPP, ops with an SGPR operand, v_pk_*_f32)
+//     needs ~3.4 back to back but hides behind fast instructions of the other waves when interleaved with them;
+//   * v_cndmask_b32 in its VOP2 form (implicit VCC) costs ~13 CYCLES EACH when the scalar unit wrote VCC last
+//     (s_and_b64 vcc, ... ; v_cndmask x3 = 41 cycles) - the round-1 body did exactly that three times per ray (10 % of
+//     the kernel).  The VOP3 form with an explicit SGPR pair costs a normal slot.
+// So: no select on the division's denominator (a back-facing ray's garbage is masked by `front` anyway), the window
+// test and the cell address are formed in floating point from the truncated pixel coordinates (exact: small
+// integers) and clamped with one v_med3 instead of selected, masks are compared on the float BIT patterns (one
+// unsigned compare = a two-sided range test, NaN and negative values fail), the single remaining select (the ray's
+// scaled intensity, zero outside the window) is a VOP3 v_cndmask on the ballot mask, the intensity scalars are folded
+// into one per-workgroup factor, and cle = 1 - che replaces (trunc + 1) - be (identical: both are exact).
+// Per ray: ~95 vector instructions instead of 135.  Ray POSITIONS (scatter, hit, pixel coordinates) keep the
+// reference's operation order bit for bit; the ray's intensity differs from the reference's three roundings by
+// at most 2 ULP, far below the fixed-point quantum of the window.
+// Requires positive, sanely scaled intensity factors (`lean` of the generic item), decided on the host.
+// --------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+__device__ __forceinline__ float select_or_zero(unsigned long long mask, float x)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+    return r;
+}
+__device__ __forceinline__ unsigned f32_bits(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+
+template <bool INTERLEAVED>
+__device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
+                                                    const int bid, const WorkItem item, unsigned int* __restrict__ work_counter,
+                                                    int* s_next)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned tile[];
+    __shared__ float s_red[13][16];
+    __shared__ Window s_win;
+    __shared__ unsigned s_cnt[3];
+
+    const int pblock = item.pblock;
+    const int h = item.h;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+
+    const int t = a.target_idx[h];
+    if (t >= a.T || item.r1 <= item.r0) {            // a cylinder's heliostat (the other launch owns it) or an empty item
+        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+        return;
+    }
+    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    const Cyl cy = {};
+    float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
+    const float4 inc = a.incident[h];
+    const int p0 = pblock * a.p_block;
+    const int p1 = min(p0 + a.p_block, a.P);
+    const int r0 = item.r0;
+    const int r1 = item.r1;
+    const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
+    const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
+    const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
+
+    // ---- phase 1: window (as in the generic item) ------------------------------------------------
+    if (tid < 3) s_cnt[tid] = 0;
+    const int pf = p0 + tid;
+    FirstPoint fp = {{0.0f, 0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f, 0.0f}, 0.0f, 0.0f};
+    if (pf < p1) {
+        fp.o = org[pf]; fp.n = nrm[pf];
+        load_dist_row<INTERLEAVED>(a.dist_u + dbase, a.dist_e + dbase, pf * (int)a.sp, fp.u, fp.e);
+    }
+    {
+        uint4* t4 = reinterpret_cast<uint4*>(tile);
+        for (int i = tid; i < a.tile_cap / 4; i += blockDim.x) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 2) tile[a.tile_cap + tid] = 0u;
+    }
+    compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
+    const Window win = s_win;
+    const float Wf = (float)a.W, Hf = (float)a.Hh;
+    const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
+    // |I| S = |r.m| * kS for a front-facing ray:  I = ((mag (-a)) k_ext) k_refl  (heliostat_ray_tracer.py:482-487, geometry.py:139)
+    const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
+    const float kS = kI * win.scale;
+    const float lds_base = (float)(unsigned)(size_t)(lds_u32*)tile;         // byte address of cell 0 (a link-time constant)
+    const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw);
+    const unsigned twm2_bits = f32_bits((float)(win.tw - 2));               // low pixel column le in [0, tw - 2]
+    const unsigned tw4 = 4u * (unsigned)win.tw;
+  for (int pass = 0; pass < win.npass; ++pass) {
+    const int pu0 = win.u0 + pass * (win.ths - 1);
+    const int pth = min(win.ths, win.u0 + win.th - pu0);
+    const bool first = pass == 0;
+    const float pu0f = (float)pu0;
+    const unsigned thm2_bits = f32_bits((float)(pth - 2));
+    // largest byte address a ray of this pass can produce for its LOW row; rays outside the window are clamped into
+    // [cell 0, that] and add zero there
+    const float addr_hi_f = lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2));
+    unsigned n_valid = 0;
+    if (!first) {
+        const int npx = win.tw * pth;
+        for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
+        __syncthreads();
+    }
+
+    // ---- phase 2: trace ------------------------------------------------------------------------
+    unsigned po1 = 0u, po2 = 0u, po3 = 0u, po4 = 0u, pq1 = 0u, pq2 = 0u, pq3 = 0u, pq4 = 0u;   // the previous ray's adds
+    float ptbe = 0.0f, ptbu = 0.0f;
+    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+        const float4 o = org[p];
+        const float4 n = nrm[p];
+        float4 d; float s;
+        reflect(inc, n, d, s);
+        const float numer = plane_numer(pl, o);
+        auto carries = [&]() {                       // cold: a cell of the previous ray wrapped (see resolve_carries)
+            PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
+            resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+        };
+        // `live`: all ones, or zero for the padding rays of the last ring round (they then fail every mask)
+        auto trace_one = [&](auto small_angles, const float u, const float e, const unsigned long long live) {
+            const Rot m = make_rot_t<decltype(small_angles)::value>(e, u);
+            float rx, ry, rz;
+            scatter(m, d, rx, ry, rz);
+            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
+            const unsigned long long m_front = ballot64(ah < 0.0f) & live;
+            const float tt = div_noscale(numer, ah);                           // :130-131 (back-facing: masked below)
+            const float hx = o.x + rx * tt, hz = o.z + rz * tt;                // :133-136
+            const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
+            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;    // :154-174
+            const float be = pl.wm1 - be0;                                     // :195-197
+            const float tbe = truncf(be), tbu = truncf(bu);                    // heliostat_ray_tracer.py:674-675
+            const float che = be - tbe, chu = bu - tbu;                        // :694-700 (exact)
+            const float cle = 1.0f - che, clu = 1.0f - chu;                    // == (tbe + 1) - be: both exact
+            const float lef = tbe - e0f, luf = tbu - pu0f;                     // window coordinates of the low pixel
+            // :178-184 on the bit patterns: 0 <= x <= hi  <=>  bits(x) <= bits(hi) unsigned (negative, NaN: larger)
+            const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
+            const unsigned long long m_in = m_front & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
+            n_valid += __popcll(m_valid);
+            const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
+            const unsigned addr_lo = (unsigned)af;
+            const unsigned addr_up = addr_lo + tw4;                            // flat row iu + 1
+            const float Is = select_or_zero(m_in, fabsf(ah) * kS);
+            const float wa = chu * Is, wb = clu * Is;
+            // the previous ray's adds have landed; a carry needs a cell that was already above 2^31 (q < 2^22)
+            if (__builtin_expect(wave_any(((po1 | po2 | po3 | po4) >> 31) != 0u), 0)) carries();
+            pq1 = cvt_nearest_u32(cle * wa); pq2 = cvt_nearest_u32(che * wa);
+            pq3 = cvt_nearest_u32(che * wb); pq4 = cvt_nearest_u32(cle * wb);
+            ptbe = tbe; ptbu = tbu;
+            lds_u32* up = (lds_u32*)(size_t)addr_up;
+            lds_u32* lo = (lds_u32*)(size_t)addr_lo;
+#ifdef ART_ABLATE_NO_LDS_ATOMICS   // diagnostic build: keep the operands alive, skip the LDS traffic
+            asm volatile("" ::"v"(up), "v"(lo), "v"(pq1), "v"(pq2), "v"(pq3), "v"(pq4));
+#else
+            po1 = __hip_atomic_fetch_add(up, pq1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            po2 = __hip_atomic_fetch_add(up + 1, pq2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            po3 = __hip_atomic_fetch_add(lo + 1, pq3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            po4 = __hip_atomic_fetch_add(lo, pq4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+#ifndef ART_ABLATE_NO_STRAYS       // diagnostic build drops the stray rays (wrong bitmap) to price them
+            if (__builtin_expect((m_valid & ~m_in) != 0ull, 0)) {
+                // valid but not in this pass's band: another band's ray, the last pixel row/column
+                // (heliostat_ray_tracer.py:723-728), or a stray of the union window -> global atomics, once
+                const bool valid = (m_valid >> lane) & 1ull;
+                const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
+                const int ie = (int)tbe, iu = (int)tbu;
+                const bool in_union = (unsigned)(ie - win.e0) < (unsigned)(win.tw - 1) && (unsigned)(iu - win.u0) < (unsigned)(win.th - 1);
+                if (first && valid && on && !in_union) {
+                    const float I = (pl.mag * (-ah) * pl.k_ext) * pl.k_refl;
+                    float* row_hi = bitmap + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
+                    float* row_lo = row_hi + a.W;
+                    atomicAdd(row_hi, cle * chu * I); atomicAdd(row_hi + 1, che * chu * I);
+                    atomicAdd(row_lo + 1, che * clu * I); atomicAdd(row_lo, cle * clu * I);
+                }
+            }
+#endif
+        };
+        // The distortion stream: a ring of kRing samples per thread, each slot re-requested the moment its value has been
+        // read, so that kRing - 1 loads (3.5 KB per wave, 56 KB per CU) are in flight at every instant.  The ablation
+        // builds (tools/ablate.sh) showed what round 1 missed: with the loads of a group of four issued only one group
+        // ahead, the waves waited for this stream 40 % of the forward and 60 % of the backward kernel's time.
+        const int lane_off = p * (int)a.sp;
+        const int nr = r1 - r0;
+        const float* __restrict__ bu_ = a.dist_u + dbase;     // wave-uniform
+        const float* __restrict__ be_ = a.dist_e + dbase;
+        auto request = [&](int r, float& u, float& e) {
+            const int64_t row = (int64_t)min(r, nr - 1) * a.sr;
+            load_dist_stream<INTERLEAVED>(bu_ + row, be_ + row, lane_off, u, e);
+        };
+        auto trace_ray = [&](const float u, const float e, const unsigned long long live) {
+            // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always and the full-range
+            // sin/cos code stays out of the way behind a wave-uniform branch
+            if (__builtin_expect(wave_any(!(fmaxf(fabsf(u), fabsf(e)) <= kSmallAngle)), 0)) trace_one(std::false_type{}, u, e, live);
+            else trace_one(std::true_type{}, u, e, live);
+        };
+        if (nr >= 8) {
+            // Every step of a round runs unconditionally (no control flow re-defines a slot: a conditional step made the
+            // compiler copy freshly requested slots around and wait for them at once); the rays that pad the last round
+            // re-read sample nr - 1 and are masked out.
+            float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
+            request(0, su0, se0); request(1, su1, se1); request(2, su2, se2); request(3, su3, se3);
+            request(4, su4, se4); request(5, su5, se5); request(6, su6, se6); request(7, su7, se7);
+#define ART_RING_STEP(j)                                                            \
+            {                                                                       \
+                /* the slot's value moves to registers of its own first, so that the new request can land in the */ \
+                /* SAME registers: otherwise the slots rotate and the loop's back-edge has to copy (= wait for) all of them */ \
+                float u, e;                                                         \
+                asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(u), "=v"(e) : "v"(su##j), "v"(se##j) : "memory"); \
+                request(k + j + 8, su##j, se##j);                                   \
+                trace_ray(u, e, k + j < nr ? ~0ull : 0ull);                         \
+            }
+            for (int k = 0; k < nr; k += 8) {
+                ART_RING_STEP(0) ART_RING_STEP(1) ART_RING_STEP(2) ART_RING_STEP(3)
+                ART_RING_STEP(4) ART_RING_STEP(5) ART_RING_STEP(6) ART_RING_STEP(7)
+            }
+#undef ART_RING_STEP
+        } else {
+            for (int r = 0; r < nr; ++r) {           // few samples per point (field-scale prediction): nothing to pipeline
+                float u, e;
+                request(r, u, e);
+                trace_ray(u, e, ~0ull);
+            }
+        }
+    }
+    {
+        PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
+        resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+    }
+    if (first && lane == 0) { atomicAdd(&s_cnt[0], n_valid); atomicAdd(&s_cnt[1], n_valid); }
+    __syncthreads();
+    unsigned next_item = 0u;
+    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
+
+    // ---- phase 3: flush ------------------------------------------------------------------------
+    for (int row = wave; row < pth; row += nwaves) {
+        float* g = bitmap + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
+        const unsigned* trow = tile + row * win.tw;
+        for (int c = lane; c < win.tw; c += 64) {
+            const unsigned q = trow[c];
+#ifdef ART_ABLATE_NO_FLUSH
+            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (float)q * win.inv_scale);
+#else
+            if (q != 0u) atomicAdd(g + c, (float)q * win.inv_scale);
+#endif
+        }
+    }
+    if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
+    __syncthreads();
+  }
+    if (tid < 2 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
+}
+
 // Everything the forward kernel is launched with, as ONE argument: the persistent loop below re-reads what an item
 // needs from the kernarg segment instead of carrying it in registers.
 struct FwdLaunch { TraceArgs a; float* flux; unsigned int* counts; unsigned int* work_counter; };
 
-template <bool INTERLEAVED, bool CYL, bool BLOCKING>
+template <bool INTERLEAVED, bool CYL, bool BLOCKING, bool LEAN = false>
 __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
+    static_assert(!LEAN || (!CYL && !BLOCKING), "the lean ray body is the planar, non-blocking one");
     __shared__ int s_next, s_reverse;
 #ifdef ART_FWD_SINGLE_ITEM   // diagnostic build: one workgroup per item, no loop (A/B against the persistent form)
     constexpr bool single_item = true;
@@ -776,8 +1027,12 @@ __global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(FwdLaunch launch)
         const int item = __builtin_amdgcn_readfirstlane(s_next);
         __syncthreads();                                     // everybody has read s_next before this item overwrites it
         if (item >= work_item_count(L.a)) break;             // workgroup-uniform
-        trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0),
-                                                   L.work_counter, &s_next);
+        if constexpr (LEAN)
+            trace_fwd_item_lean<INTERLEAVED>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0), L.work_counter,
+                                             &s_next);
+        else
+            trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0),
+                                                       L.work_counter, &s_next);
         __syncthreads();
     }
 }
@@ -1515,26 +1770,34 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
         // exits at once (the type is only known on the device)
-#define ART_LAUNCH_FWD(IL, CY, BL)                                                                               \
+#define ART_LAUNCH_FWD(IL, CY, BL, LN)                                                                           \
         do {                                                                                                     \
             const int64_t blocks = (CY || BL) ? items : persistent_blocks;     /* see trace_fwd_lds_kernel */    \
-            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL>),        \
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL, LN>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = next_work_counter(stream);                                                  \
             if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
             const FwdLaunch launch = {a, flux, counts, work_counter};                                            \
-            hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL>), dim3((unsigned)blocks), dim3(cfg.block), lds, \
-                               stream, launch);                                                                  \
+            hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL, LN>), dim3((unsigned)blocks), dim3(cfg.block),  \
+                               lds, stream, launch);                                                             \
         } while (0)
 #define ART_LAUNCH_FWD_TYPE(CY)                                                                                  \
         do {                                                                                                     \
-            if (il && blocking) ART_LAUNCH_FWD(true, CY, true);                                                  \
-            else if (il) ART_LAUNCH_FWD(true, CY, false);                                                        \
-            else if (blocking) ART_LAUNCH_FWD(false, CY, true);                                                  \
-            else ART_LAUNCH_FWD(false, CY, false);                                                               \
+            if (il && blocking) ART_LAUNCH_FWD(true, CY, true, false);                                           \
+            else if (il) ART_LAUNCH_FWD(true, CY, false, false);                                                 \
+            else if (blocking) ART_LAUNCH_FWD(false, CY, true, false);                                           \
+            else ART_LAUNCH_FWD(false, CY, false, false);                                                        \
         } while (0)
         const bool il = interleaved_layout(a);
-        if (T > 0) ART_LAUNCH_FWD_TYPE(false);
+        // the lean ray body (trace_fwd_item_lean): planar receivers, no blocking, positive and sanely scaled intensity
+        // factors - then a valid ray is known to carry intensity and one counter serves both factors
+        const bool lean = !blocking && persistent_blocks != items + 1 && env_int("ARTIST_HIP_LEAN", 1) != 0 &&
+                          a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f && a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
+        if (T > 0) {
+            if (lean && il) ART_LAUNCH_FWD(true, false, false, true);
+            else if (lean) ART_LAUNCH_FWD(false, false, false, true);
+            else ART_LAUNCH_FWD_TYPE(false);
+        }
         if (Tc > 0) ART_LAUNCH_FWD_TYPE(true);
 #undef ART_LAUNCH_FWD_TYPE
 #undef ART_LAUNCH_FWD
