@@ -344,6 +344,7 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
     const int p = ptile * kFilterBlock + threadIdx.x;
     const bool active = p < a.P;
     const int t = a.target_idx[h];
+    if ((unsigned)t >= (unsigned)(a.T + a.Tc)) return;     // workgroup-uniform; art_trace_fwd reports the bad index (ART_ETARGET)
     const bool is_cyl = t >= a.T;
     Plane pl; Cyl cy;
     if (is_cyl) cy = load_cyl(a.cyl_centers, a.cyl_normals, a.cyl_axes, a.cyl_radii, a.cyl_heights, a.cyl_opening,

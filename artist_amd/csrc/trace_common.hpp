@@ -52,7 +52,25 @@ struct TraceArgs {
     int n_pblocks;            // ceil(P / p_block)
     int tile_cap;             // LDS bitmap-window capacity in pixels
     int multipass_ratio;      // footprints above ratio x capacity are swept in several passes
+    // Forward accumulation (windowed kernels): every bitmap pixel has a 64-bit FIXED-POINT accumulator in `accum`
+    // ([n_maps,Hh,W], all zero on entry).  Window flushes, cell carries and stray rays add integers to it - integer
+    // addition is associative, so the flux is bit-reproducible whatever the order of the workgroups - and
+    // accum_to_flux_kernel turns it into the fp32 bitmap (one rounding per pixel) and leaves it zero again.
+    // One unit = sign(k) 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|: the largest single contribution is < 2^28 |d||m| units.
+    unsigned long long* accum;
+    int ex_g;
+    float scale_g;            // 2^(28 - ex_g)
+    unsigned int* status;     // device status word (mapped host memory): bit 0 = a target index was out of range
 };
+
+// Target indices come from the caller: a stale one must not index the target tables.  The heliostat is skipped (its
+// bitmap and factors stay zero) and bit 0 of the status word - mapped host memory, read by art_async_status - is set.
+__device__ __forceinline__ bool target_in_range(const TraceArgs& a, int t)
+{
+    if ((unsigned)t < (unsigned)(a.T + a.Tc)) return true;
+    if (threadIdx.x == 0 && a.status != nullptr) __hip_atomic_fetch_or(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
+}
 
 // Distortion fetch.  INTERLEAVED: (u,e) adjacent floats of one [H,R,P,2] buffer -> one 8-byte load.
 template <bool INTERLEAVED>
@@ -139,6 +157,7 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
     a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
     a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;
     a.n_ptiles = (int)((P + kBlock - 1) / kBlock);
+    a.accum = nullptr; a.ex_g = 0; a.scale_g = 1.0f; a.status = nullptr;
     return true;
 }
 

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
     const bool active = p < a.P;
 
     const int t = a.target_idx[h];
-    if (t >= a.T) return;             // planar receivers only (host refuses cylinders for this variant)
+    if (!target_in_range(a, t) || t >= a.T) return;   // planar receivers only (host refuses cylinders for this variant)
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
 
@@ -127,9 +127,8 @@ struct Window {
     int ths, npass;       // rows per pass (tw*ths <= tile_cap) and number of passes; pass k covers flat rows
                           // [u0 + k(ths-1), u0 + k(ths-1) + ths): consecutive passes share one row because a
                           // ray splats rows iu and iu+1 and belongs to the pass that holds row iu
-    float scale;          // S  (power of two)
-    float inv_scale;      // sign / S           (sign of mag*k_ext*k_refl)
-    float carry;          // sign * 2^32 / S    (value of one cell wrap)
+    float scale;          // S  (power of two): window cells count units of 1 / S
+    int shift;            // log2(global accumulator units per cell unit) = (28 - ex_g) - log2 S  (>= 0)
 };
 
 // Wave reductions on the DPP network (VALU ops, a few cycles each) instead of __shfl_xor (ds_bpermute through the LDS
@@ -205,21 +204,26 @@ struct PendingSplat {
     int ie, iu;                // low pixel of the pending ray (pointer math only if a carry happened)
 };
 
-// A cell wrapped iff old + q < old (unsigned).  Rare: a cell holds ~2^10 full-size contributions.
-__device__ __forceinline__ void resolve_carries(const PendingSplat& ps, float* __restrict__ bitmap, int W, int Hh,
-                                                float carry)
+// A cell wrapped iff old + q < old (unsigned).  Rare: a cell holds ~2^10 full-size contributions.  The 2^32 cell units
+// go straight to the pixel's accumulator.
+__device__ __forceinline__ void resolve_carries(const PendingSplat& ps, unsigned long long* __restrict__ acc, int W, int Hh,
+                                                int shift)
 {
     const bool c1 = ps.o1 + ps.q1 < ps.o1, c2 = ps.o2 + ps.q2 < ps.o2;
     const bool c3 = ps.o3 + ps.q3 < ps.o3, c4 = ps.o4 + ps.q4 < ps.o4;
     if (__builtin_expect(wave_any(c1 | c2 | c3 | c4), 0)) {
-        float* row_hi = bitmap + (int64_t)(Hh - 2 - ps.iu) * W + ps.ie;   // flat row iu + 1 of the flipped bitmap
-        float* row_lo = row_hi + W;
+        const unsigned long long carry = 1ull << (32 + shift);
+        unsigned long long* row_hi = acc + (int64_t)(Hh - 2 - ps.iu) * W + ps.ie;   // flat row iu + 1 of the flipped bitmap
+        unsigned long long* row_lo = row_hi + W;
         if (c1) atomicAdd(row_hi, carry);
         if (c2) atomicAdd(row_hi + 1, carry);
         if (c3) atomicAdd(row_lo + 1, carry);
         if (c4) atomicAdd(row_lo, carry);
     }
 }
+
+// A contribution that bypasses the window (a stray ray): |v| in accumulator units, rounded to nearest.
+__device__ __forceinline__ unsigned long long to_accum(float v, float scale_g) { return (unsigned long long)cvt_nearest_u32(fabsf(v) * scale_g); }
 
 // Phase 1 of the windowed kernels: bounding box (in un-flipped bitmap coordinates) of where the
 // workgroup's rays can land, clipped to `tile_cap` pixels, plus the fixed-point scale of the forward
@@ -312,7 +316,7 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
         usq = row_reduce<kSum>(has ? s_red[12][w] : 0.0f);
     }
     if (tid == 0) {
-        Window win = {0, 0, 0, 0, 0, 1, 1.0f, 1.0f, 0.0f};
+        Window win = {0, 0, 0, 0, 0, 1, 1.0f, 0};
         if (emax >= emin) {
             // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
             // worth keeping in the window (~4.2 sigma); +2 px for the bilinear footprint and rounding.
@@ -366,11 +370,11 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             const float bound = fabsf(kI) * sqrtf(dmax2) * mnorm * 1.001f;
             int ex = 0;
             if (bound > 0.0f && bound < 3.0e38f) (void)frexpf(bound, &ex);
-            ex = min(max(ex, -90), 90);
-            const float sgn = kI < 0.0f ? -1.0f : 1.0f;
+            // the cell unit is a power-of-two multiple of the accumulator unit (within 2^-6 .. 2^8 of |k|'s own exponent:
+            // |d| |m| is ~1 for unit normals; beyond that range the window is merely coarser or wraps its cells sooner)
+            ex = min(max(ex, a.ex_g - 6), a.ex_g + 8);
             win.scale = ldexpf(1.0f, 22 - ex);
-            win.inv_scale = sgn * ldexpf(1.0f, ex - 22);
-            win.carry = sgn * ldexpf(1.0f, ex + 10);
+            win.shift = 6 + ex - a.ex_g;
         }
         *s_win = win;
     }
@@ -429,6 +433,7 @@ __device__ __forceinline__ bool farther_end_is_last(const TraceArgs& a)
     auto distance2 = [&](int h) {
         const float4 o = a.origins[(int64_t)h * a.P];
         const int t = a.target_idx[h];
+        if ((unsigned)t >= (unsigned)(a.T + a.Tc)) return 0.0f;          // reported by the item that owns the heliostat
         const float* c = t < a.T ? a.centers + 4 * t : a.cyl_centers + 4 * (t - a.T);
         const float dx = o.x - c[0], dy = o.y - c[1], dz = o.z - c[2];
         return dx * dx + dy * dy + dz * dz;
@@ -472,7 +477,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    if ((t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: the other instantiation's launch owns this heliostat
+    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: a bad index, or the other instantiation's launch owns this heliostat
         if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
         return;
     }
@@ -481,7 +486,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
                                      t - a.T, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     else pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     const float k_ext = a.k_ext, k_refl = a.k_refl;
-    float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
+    unsigned long long* __restrict__ acc = a.accum + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;   // this bitmap's accumulators
     const float4 inc = a.incident[h];
     const int p0 = pblock * a.p_block;
     const int p1 = min(p0 + a.p_block, a.P);
@@ -627,7 +632,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
             n_int += __popcll(m_valid & __builtin_amdgcn_ballot_w64(I > 0.0f) & ~lean_all);
             // the previous ray's adds have landed; a carry needs a cell that was already above 2^31 (q < 2^22)
             if (__builtin_expect(wave_any(((ps.o1 | ps.o2 | ps.o3 | ps.o4) >> 31) != 0u), 0))
-                resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+                resolve_carries(ps, acc, a.W, a.Hh, win.shift);
             ps.q1 = cvt_nearest_u32(cle * chu * Is); ps.q2 = cvt_nearest_u32(che * chu * Is);
             ps.q3 = cvt_nearest_u32(che * clu * Is); ps.q4 = cvt_nearest_u32(cle * clu * Is);
             ps.ie = ie; ps.iu = iu;
@@ -649,10 +654,10 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
 #endif
 #ifndef ART_ABLATE_NO_STRAYS   // diagnostic build drops the stray rays (wrong bitmap) to price them
                 if (first && valid && on && !in_union) {
-                    float* row_hi = bitmap + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
-                    float* row_lo = row_hi + a.W;
-                    atomicAdd(row_hi, cle * chu * I); atomicAdd(row_hi + 1, che * chu * I);
-                    atomicAdd(row_lo + 1, che * clu * I); atomicAdd(row_lo, cle * clu * I);
+                    unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
+                    unsigned long long* row_lo = row_hi + a.W;
+                    atomicAdd(row_hi, to_accum(cle * chu * I, a.scale_g)); atomicAdd(row_hi + 1, to_accum(che * chu * I, a.scale_g));
+                    atomicAdd(row_lo + 1, to_accum(che * clu * I, a.scale_g)); atomicAdd(row_lo, to_accum(cle * clu * I, a.scale_g));
                 }
 #endif
             }
@@ -699,7 +704,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
             cu0 = nu0; ce0 = ne0; cu1 = nu1; ce1 = ne1; cu2 = nu2; ce2 = ne2; cu3 = nu3; ce3 = ne3;
         }
     }
-    resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+    resolve_carries(ps, acc, a.W, a.Hh, win.shift);
     if (first && lane == 0) {                                                           // wave totals
         atomicAdd(&s_cnt[0], lean ? n_valid : n_int); atomicAdd(&s_cnt[1], n_valid);
 #ifdef ART_DEBUG_COUNT_STRAYS
@@ -716,14 +721,14 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
 
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
     for (int row = wave; row < pth; row += nwaves) {
-        float* g = bitmap + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
+        unsigned long long* g = acc + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
         const unsigned* trow = tile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) {
             const unsigned q = trow[c];
 #ifdef ART_ABLATE_NO_FLUSH      // diagnostic build: price the global atomics of the flush (wrong bitmap)
-            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (float)q * win.inv_scale);
+            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (unsigned long long)q << win.shift);
 #else
-            if (q != 0u) atomicAdd(g + c, (float)q * win.inv_scale);
+            if (q != 0u) atomicAdd(g + c, (unsigned long long)q << win.shift);
 #endif
         }
     }
@@ -767,6 +772,13 @@ __device__ __forceinline__ float select_or_zero(unsigned long long mask, float x
     asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
     return r;
 }
+// mask ? a : b with the lane mask in an SGPR pair
+__device__ __forceinline__ float select_mask(unsigned long long mask, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    return r;
+}
 __device__ __forceinline__ unsigned f32_bits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
@@ -779,19 +791,18 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     __shared__ float s_red[13][16];
     __shared__ Window s_win;
     __shared__ unsigned s_cnt[3];
-
     const int pblock = item.pblock;
     const int h = item.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    if (t >= a.T || item.r1 <= item.r0) {            // a cylinder's heliostat (the other launch owns it) or an empty item
+    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0) {   // a bad index, a cylinder's heliostat (the other launch owns it) or an empty item
         if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
         return;
     }
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     const Cyl cy = {};
-    float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
+    unsigned long long* __restrict__ acc = a.accum + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;   // this bitmap's accumulators
     const float4 inc = a.incident[h];
     const int p0 = pblock * a.p_block;
     const int p1 = min(p0 + a.p_block, a.P);
@@ -825,6 +836,8 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw);
     const unsigned twm2_bits = f32_bits((float)(win.tw - 2));               // low pixel column le in [0, tw - 2]
     const unsigned tw4 = 4u * (unsigned)win.tw;
+    const float u0f = (float)win.u0;
+    const unsigned uthm2_bits = f32_bits((float)(win.th - 2));           // low pixel row of the UNION window in [0, th - 2]
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);
     const int pth = min(win.ths, win.u0 + win.th - pu0);
@@ -842,6 +855,22 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     }
 
     // ---- phase 2: trace ------------------------------------------------------------------------
+    unsigned long long m_parked = 0ull;               // lanes holding a parked stray ray
+    float pk_be = 0.0f, pk_bu = 0.0f, pk_ah = 0.0f;   // its bitmap coordinates (geometry.py:186-197) and direction cosine
+    auto unpark = [&]() {                             // the parked rays' four weights -> their pixels' accumulators
+        if ((m_parked >> lane) & 1ull) {
+            const float tbe = truncf(pk_be), tbu = truncf(pk_bu);                              // heliostat_ray_tracer.py:674-675
+            if ((tbe + 1.0f < Wf) && (tbu + 1.0f < Hf)) {                                      // :723-728
+                const float che = pk_be - tbe, chu = pk_bu - tbu, cle = (tbe + 1.0f) - pk_be, clu = (tbu + 1.0f) - pk_bu;   // :694-700
+                const float I = (pl.mag * (-pk_ah) * pl.k_ext) * pl.k_refl;                    // :482-487, geometry.py:139
+                unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;   // flat row iu + 1, flipped
+                unsigned long long* row_lo = row_hi + a.W;
+                atomicAdd(row_hi, to_accum(cle * chu * I, a.scale_g)); atomicAdd(row_hi + 1, to_accum(che * chu * I, a.scale_g));
+                atomicAdd(row_lo + 1, to_accum(che * clu * I, a.scale_g)); atomicAdd(row_lo, to_accum(cle * clu * I, a.scale_g));
+            }
+        }
+        m_parked = 0ull;
+    };
     unsigned po1 = 0u, po2 = 0u, po3 = 0u, po4 = 0u, pq1 = 0u, pq2 = 0u, pq3 = 0u, pq4 = 0u;   // the previous ray's adds
     float ptbe = 0.0f, ptbu = 0.0f;
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
@@ -852,7 +881,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         const float numer = plane_numer(pl, o);
         auto carries = [&]() {                       // cold: a cell of the previous ray wrapped (see resolve_carries)
             PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
-            resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+            resolve_carries(ps, acc, a.W, a.Hh, win.shift);
         };
         // `live`: all ones, or zero for the padding rays of the last ring round (they then fail every mask)
         auto trace_one = [&](auto small_angles, const float u, const float e, const unsigned long long live) {
@@ -895,20 +924,20 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             po4 = __hip_atomic_fetch_add(lo, pq4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 #ifndef ART_ABLATE_NO_STRAYS       // diagnostic build drops the stray rays (wrong bitmap) to price them
-            if (__builtin_expect((m_valid & ~m_in) != 0ull, 0)) {
-                // valid but not in this pass's band: another band's ray, the last pixel row/column
-                // (heliostat_ray_tracer.py:723-728), or a stray of the union window -> global atomics, once
-                const bool valid = (m_valid >> lane) & 1ull;
-                const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
-                const int ie = (int)tbe, iu = (int)tbu;
-                const bool in_union = (unsigned)(ie - win.e0) < (unsigned)(win.tw - 1) && (unsigned)(iu - win.u0) < (unsigned)(win.th - 1);
-                if (first && valid && on && !in_union) {
-                    const float I = (pl.mag * (-ah) * pl.k_ext) * pl.k_refl;
-                    float* row_hi = bitmap + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
-                    float* row_lo = row_hi + a.W;
-                    atomicAdd(row_hi, cle * chu * I); atomicAdd(row_hi + 1, che * chu * I);
-                    atomicAdd(row_lo + 1, che * clu * I); atomicAdd(row_lo, cle * clu * I);
-                }
+            // Valid rays outside this pass's window: strays of the union window (or, when the footprint is swept in
+            // bands, rays of another band; or rays on the last pixel row / column, heliostat_ray_tracer.py:723-728).
+            // A stray lane PARKS its ray - pixel coordinates and direction cosine, three registers - and the wave moves
+            // on: one stray lane used to drag its whole wave through ~50 instructions of address arithmetic and four
+            // atomics in 45 % of the ray steps.  The parked rays go to their pixels' accumulators when a lane that is
+            // already holding one strays again (every ~10 strays of a wave) and at the end of the item.
+            unsigned long long m_out = m_valid & ~m_in;
+            if (__builtin_expect(m_out != 0ull, 0)) {
+                if (!first) m_out = 0ull;
+                else if (win.npass > 1)                         // banded sweep: only what no band holds
+                    m_out &= ~(ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(tbu - u0f) <= uthm2_bits));
+                if (m_out & m_parked) unpark();
+                pk_be = select_mask(m_out, be, pk_be); pk_bu = select_mask(m_out, bu, pk_bu); pk_ah = select_mask(m_out, ah, pk_ah);
+                m_parked |= m_out;
             }
 #endif
         };
@@ -930,7 +959,11 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             if (__builtin_expect(wave_any(!(fmaxf(fabsf(u), fabsf(e)) <= kSmallAngle)), 0)) trace_one(std::false_type{}, u, e, live);
             else trace_one(std::true_type{}, u, e, live);
         };
+#ifdef ART_LEAN_NO_RING          // A/B build: every sample requested where it is used
+        if (false) {
+#else
         if (nr >= 8) {
+#endif
             // Every step of a round runs unconditionally (no control flow re-defines a slot: a conditional step made the
             // compiler copy freshly requested slots around and wait for them at once); the rays that pad the last round
             // re-read sample nr - 1 and are masked out.
@@ -961,8 +994,9 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     }
     {
         PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
-        resolve_carries(ps, bitmap, a.W, a.Hh, win.carry);
+        resolve_carries(ps, acc, a.W, a.Hh, win.shift);
     }
+    if (m_parked != 0ull) unpark();
     if (first && lane == 0) { atomicAdd(&s_cnt[0], n_valid); atomicAdd(&s_cnt[1], n_valid); }
     __syncthreads();
     unsigned next_item = 0u;
@@ -970,14 +1004,14 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
 
     // ---- phase 3: flush ------------------------------------------------------------------------
     for (int row = wave; row < pth; row += nwaves) {
-        float* g = bitmap + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
+        unsigned long long* g = acc + (int64_t)(a.Hh - 1 - (pu0 + row)) * a.W + win.e0;
         const unsigned* trow = tile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) {
             const unsigned q = trow[c];
 #ifdef ART_ABLATE_NO_FLUSH
-            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (float)q * win.inv_scale);
+            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (unsigned long long)q << win.shift);
 #else
-            if (q != 0u) atomicAdd(g + c, (float)q * win.inv_scale);
+            if (q != 0u) atomicAdd(g + c, (unsigned long long)q << win.shift);
 #endif
         }
     }
@@ -1070,7 +1104,7 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
     if (p >= a.P) return;
 
     const int t = a.target_idx[h];
-    if (t >= a.T) return;
+    if (!target_in_range(a, t) || t >= a.T) return;
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
 
@@ -1200,7 +1234,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const bool atomic_item = ATOMIC_OUT || item.half;
 
     const int t = a.target_idx[h];
-    if ((t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: the other instantiation's launch owns this heliostat
+    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: a bad index, or the other instantiation's launch owns this heliostat
         if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
         return;
     }
@@ -1528,6 +1562,23 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
     }
 }
 
+// pixel accumulators -> fp32 bitmap (one rounding per pixel), and the accumulators are left zero for the next call.
+// sign_unit = sign(mag k_ext k_refl) 2^(ex_g - 28).  Two pixels per thread: 16-byte loads, 8-byte stores.
+__global__ __launch_bounds__(256) void accum_to_flux_kernel(unsigned long long* __restrict__ accum, float* __restrict__ flux,
+                                                            int64_t npix, float sign_unit)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < npix) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(accum + i);
+        *reinterpret_cast<float2*>(flux + i) = make_float2((float)v.x * sign_unit, (float)v.y * sign_unit);
+        if ((v.x | v.y) != 0ull) *reinterpret_cast<ulonglong2*>(accum + i) = make_ulonglong2(0ull, 0ull);
+    } else if (i < npix) {
+        const unsigned long long v = accum[i];
+        flux[i] = (float)v * sign_unit;
+        if (v != 0ull) accum[i] = 0ull;
+    }
+}
+
 // out[t] = sum_h [target_idx[h] == t] bitmaps[h]   (heliostat_ray_tracer.py:593-608)
 // One thread per (t, VEC pixels); heliostats are added in index order (deterministic) with 8-16 loads in flight.
 // A 256 x 256 bitmap has too few pixels to fill the chip with 4-pixel threads: VEC = 4 only for large bitmaps.
@@ -1648,6 +1699,30 @@ static unsigned* next_work_counter(hipStream_t stream)
     return slot;
 }
 
+
+// Device status word: 4 bytes of mapped host memory per GPU, allocated on the first trace call and kept.  Kernels set
+// bit 0 when they meet a target index outside the tables (the heliostat is skipped); the host reads it without a
+// synchronisation at the start of every trace call (a failure of an EARLIER launch then surfaces as ART_ETARGET) and,
+// synchronised, in art_async_status.
+struct StatusWord { unsigned* host; unsigned* dev; };
+static StatusWord status_word()
+{
+    constexpr int kMaxDevices = 64;
+    static StatusWord words[kMaxDevices] = {};
+    static std::mutex lock;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return {nullptr, nullptr};
+    std::lock_guard<std::mutex> guard(lock);
+    if (words[dev].host == nullptr) {
+        unsigned* h = nullptr; unsigned* d = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) return {nullptr, nullptr};
+        *h = 0u;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipHostFree(h); return {nullptr, nullptr}; }
+        words[dev] = {h, d};
+    }
+    return words[dev];
+}
+
 // Workgroups that run at once: one per CU (a window fills the CU's LDS).
 static int resident_workgroups()
 {
@@ -1729,7 +1804,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                              const int32_t* cand_count, int64_t Cmax, double max_scatter_angle,
                              double ray_magnitude, double extinction, double reflectivity, int64_t H, int64_t R,
                              int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux,
-                             float* factors, void* stream_)
+                             float* factors, uint64_t* accum, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
@@ -1743,6 +1818,9 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                    plane_centers, plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights,
                    cyl_opening, ray_magnitude, extinction, reflectivity, H, R, P, T, Tc, W, Hh, mode))
         return ART_EINVAL;
+    const StatusWord status = status_word();
+    if (status.host != nullptr && (*status.host & 1u)) return ART_ETARGET;     // an earlier launch met a bad target index
+    a.status = status.dev;
     const bool blocking = prim_corners != nullptr;
     if (blocking) {
         if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > kMaxCand) return ART_EINVAL;
@@ -1751,13 +1829,25 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         set_cone(a, max_scatter_angle);
     }
     const int64_t n_maps = mode == 0 ? H : T + Tc;
-    ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * n_maps * Hh * W, stream));
-    if (H == 0) return ART_OK;
     ART_HIP(hipMemsetAsync(factors, 0, sizeof(float) * 3 * H, stream));
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
     FwdConfig cfg = fwd_config();
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
+        if (accum == nullptr || (reinterpret_cast<uintptr_t>(accum) % 16) != 0) return ART_EINVAL;
+        // unit of the pixel accumulators: 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|
+        {
+            const float kI = (a.mag * a.k_ext) * a.k_refl;
+            int ex = 0;
+            if (kI != 0.0f && fabsf(kI) < 3.0e38f) (void)frexpf(fabsf(kI) * 1.001f, &ex);
+            a.ex_g = std::min(std::max(ex, -80), 80);
+            a.scale_g = ldexpf(1.0f, 28 - a.ex_g);
+            a.accum = reinterpret_cast<unsigned long long*>(accum);
+        }
+        // the lean ray body (trace_fwd_item_lean): planar receivers, no blocking, positive and sanely scaled intensity
+        // factors - then a valid ray is known to carry intensity and one counter serves both factors
+        const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
+                          a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
         window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
@@ -1789,10 +1879,6 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             else ART_LAUNCH_FWD(false, CY, false, false);                                                        \
         } while (0)
         const bool il = interleaved_layout(a);
-        // the lean ray body (trace_fwd_item_lean): planar receivers, no blocking, positive and sanely scaled intensity
-        // factors - then a valid ray is known to carry intensity and one counter serves both factors
-        const bool lean = !blocking && persistent_blocks != items + 1 && env_int("ARTIST_HIP_LEAN", 1) != 0 &&
-                          a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f && a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
         if (T > 0) {
             if (lean && il) ART_LAUNCH_FWD(true, false, false, true);
             else if (lean) ART_LAUNCH_FWD(false, false, false, true);
@@ -1801,8 +1887,17 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         if (Tc > 0) ART_LAUNCH_FWD_TYPE(true);
 #undef ART_LAUNCH_FWD_TYPE
 #undef ART_LAUNCH_FWD
+        ART_HIP(hipGetLastError());
+        {   // accumulators -> fp32 bitmaps (every pixel is written: no memset of `flux`); accumulators back to zero
+            const int64_t npix = n_maps * Hh * W;
+            const float kI = (a.mag * a.k_ext) * a.k_refl;
+            const float sign_unit = (kI < 0.0f ? -1.0f : 1.0f) * ldexpf(1.0f, a.ex_g - 28);
+            hipLaunchKernelGGL(accum_to_flux_kernel, dim3((unsigned)((npix / 2 + 1 + 255) / 256)), dim3(256), 0, stream, a.accum, flux, npix,
+                               sign_unit);
+        }
     } else {
         if (Tc > 0 || blocking) return ART_EUNSUPPORTED;   // the global-atomic A/B variant: planar, no blocking
+        ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * n_maps * Hh * W, stream));
         choose_chunks(a, 4096, 8);
         const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
         if (blocks > 2147483647LL) return ART_EINVAL;
@@ -1849,6 +1944,11 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                    plane_centers, plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights,
                    cyl_opening, ray_magnitude, extinction, reflectivity, H, R, P, T, Tc, W, Hh, mode))
         return ART_EINVAL;
+    {
+        const StatusWord status = status_word();
+        if (status.host != nullptr && (*status.host & 1u)) return ART_ETARGET;
+        a.status = status.dev;
+    }
     const bool blocking = prim_corners != nullptr;
     if (blocking) {
         if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > kMaxCand || N <= 0 ||
@@ -1956,4 +2056,15 @@ extern "C" int art_per_target_sum(const float* bitmaps, const int32_t* target_id
                            bitmaps, target_idx, (int)H, (int)T, npix, out);
     ART_HIP(hipGetLastError());
     return ART_OK;
+}
+
+extern "C" int art_async_status(void* stream_, int clear)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const StatusWord status = status_word();
+    if (status.host == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
+    ART_HIP(hipStreamSynchronize(stream));
+    const unsigned word = *status.host;
+    if (clear) *status.host = 0u;
+    return (word & 1u) ? ART_ETARGET : ART_OK;
 }

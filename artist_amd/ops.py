@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 __all__ = ["trace_rays", "nurbs_surface_points_and_normals", "per_target_sum", "align_surfaces", "TraceRays",
-           "NurbsEval", "AlignSurfaces"]
+           "NurbsEval", "AlignSurfaces", "check_async_errors"]
 
 
 def _stream(device: torch.device) -> int:
@@ -78,6 +78,32 @@ def _planar_ptrs(centers, plane_normals, dims):
 
 #: capacity of a heliostat's list of candidate blocking rectangles (``Cmax`` of art_blocking_filter, <= 32)
 BLOCKING_CANDIDATES = 32
+
+# Pixel accumulators of art_trace_fwd ([n_maps,Hh,W] uint64, zero on entry and zero again afterwards): one buffer per
+# (device, stream), grown on demand, so that calls on different streams never share one.
+_ACCUM: dict = {}
+
+
+def _accumulators(dev: torch.device, n: int) -> torch.Tensor:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
+    buf = _ACCUM.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.zeros((n,), dtype=torch.int64, device=dev)
+        _ACCUM[key] = buf
+    return buf
+
+
+def check_async_errors(device=None, clear: bool = True) -> None:
+    """Synchronise the current stream of ``device`` and raise if a kernel met a target index outside the target
+    tables (``art_async_status``): the entry points are asynchronous, so the device-side range check reports here -
+    or at the next trace call, which refuses to start while the status is set."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().art_async_status(_stream(dev), 1 if clear else 0)
+    if rc == -2:
+        _ACCUM.clear()              # a skipped heliostat leaves nothing behind, but take no chances with the invariant
+        raise IndexError("target_area_indices out of range (found by the kernels: art_async_status)")
+    _lib.check(rc, "art_async_status")
 
 
 class TraceRays(torch.autograd.Function):
@@ -146,12 +172,18 @@ class TraceRays(torch.autograd.Function):
 
         flux = torch.empty((n_maps, height, width), dtype=torch.float32, device=dev)
         factors = torch.empty((3, H), dtype=torch.float32, device=dev)
+        accum = _accumulators(dev, n_maps * height * width)
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_fwd(
                 *geometry, *block_ptrs, Cmax, float(max_scatter_angle), float(ray_magnitude), float(extinction),
                 float(reflectivity),
                 H, R, P, T, Tc, width, height, 1 if per_target else 0, flux.data_ptr(), factors.data_ptr(),
-                _stream(dev))
+                accum.data_ptr(), _stream(dev))
+        if rc != 0:
+            _ACCUM.clear()
+        if rc == -2:
+            raise IndexError("target_area_indices out of range (found by the kernels of an earlier call; "
+                             "artist_amd.ops.check_async_errors() clears the status)")
         _lib.check(rc, "art_trace_fwd")
         ctx.save_for_backward(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                               *cyl_tabs, *block_tabs)

@@ -27,7 +27,7 @@ extern "C" {
 
 #define ART_OK 0
 #define ART_EINVAL -1      /* bad size / null pointer / unsupported degree */
-#define ART_ETARGET -2     /* reserved: target index out of range (checked on host copies only) */
+#define ART_ETARGET -2     /* a target index was outside [0, T + Tc): found on the DEVICE (art_async_status) */
 #define ART_ELAUNCH -3     /* HIP launch or runtime error (see art_last_hip_error) */
 #define ART_EUNSUPPORTED -4
 
@@ -76,8 +76,16 @@ int art_last_hip_error(void);
  *                     1: flux is [T+Tc,Hh,W] (summed per target area)
  *   flux              output, zero-filled then accumulated; rows already up-down flipped
  *   factors           output [3,H]: intercept, on_target, blocking fractions
+ *   accum             [n_maps,Hh,W] uint64, 16-byte aligned, n_maps = H (mode 0) or T + Tc (mode 1): the pixels'
+ *                     fixed-point accumulators.  ALL ZERO on entry, all zero again when the call's work has finished
+ *                     (the caller keeps one buffer per stream and never clears it).  Window flushes, cell carries and
+ *                     stray rays add integers to it and a last kernel converts it to `flux` with one rounding per
+ *                     pixel: the flux does not depend on the order in which workgroups finish - two calls with the
+ *                     same inputs give the same bits (the reference needs torch.use_deterministic_algorithms for
+ *                     that, tests/conftest.py:109).  `flux` itself needs no initialisation.
  * Device memory: every buffer is the caller's, except 4 KB per GPU that the library allocates on the first trace
- * call and keeps (work counters of its persistent workgroups, one slot per launch, zeroed on the launch stream).
+ * call and keeps (work counters of its persistent workgroups, one slot per launch, zeroed on the launch stream)
+ * and 64 bytes of mapped host memory per GPU (the status word of art_async_status).
  * ------------------------------------------------------------------------------------------- */
 int art_trace_fwd(const float *origins, const float *normals, const float *incident,
                   const float *dist_u, const float *dist_e, int64_t dist_sh, int64_t dist_sr, int64_t dist_sp,
@@ -88,7 +96,18 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
                   const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax,
                   double max_scatter_angle, double ray_magnitude, double extinction, double reflectivity,
                   int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
-                  float *flux, float *factors, void *stream);
+                  float *flux, float *factors, uint64_t *accum, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_async_status - the entry points are asynchronous, so what only the DEVICE can find out is reported here:
+ * synchronises `stream` and returns ART_ETARGET if a kernel launched through this library met a target index
+ * outside [0, T + Tc) since the status was last cleared (the heliostat was skipped - no table is indexed out of
+ * bounds - and its bitmap and factors are zero), ART_OK otherwise.  `clear` != 0 resets the status.  Until it is
+ * cleared, every later art_trace_fwd / art_trace_bwd call returns ART_ETARGET at once (checked without a
+ * synchronisation).  The reference fails in the same situation with an IndexError from its target-area gather
+ * (artist/raytracing/geometry.py:104-105).
+ * ------------------------------------------------------------------------------------------- */
+int art_async_status(void *stream, int clear);
 
 /* ---------------------------------------------------------------------------------------------
  * art_trace_bwd - what torch.autograd derives for the op chain of art_trace_fwd (mode 0 or 1):
