@@ -104,6 +104,46 @@ __global__ __launch_bounds__(kAlignBlock) void align_bwd_kernel(const float4* __
     }
 }
 
+// dL/dM[j][k] = sum_p (gP_j xP_k + gN_j xN_k) of ONE heliostat per workgroup, summed in a fixed order (thread-strided
+// partial sums, DPP-free shuffle tree, waves in index order): bit-reproducible, no atomics and nothing to pre-zero.
+// The kinematics optimisers sit on this gradient (heliostat_group_rigid_body.py:217-222 in the autograd graph), and a
+// 250-step Adam run amplifies a last-bit difference into a different path.
+constexpr int kGmBlock = 1024;
+__global__ __launch_bounds__(kGmBlock) void align_gm_kernel(const float4* __restrict__ points, const float4* __restrict__ normals,
+                                                            const float4* __restrict__ g_out_points,
+                                                            const float4* __restrict__ g_out_normals, int P,
+                                                            float* __restrict__ g_orientation)
+{
+    __shared__ float s_part[kGmBlock / 64][16];
+    const int h = blockIdx.x;
+    float gm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) gm[k] = 0.0f;
+    for (int p = threadIdx.x; p < P; p += kGmBlock) {
+        const int64_t i = (int64_t)h * P + p;
+        const float4 gp = g_out_points[i], gn = g_out_normals[i], xp = points[i], xn = normals[i];
+        const float g4[4] = {gp.x, gp.y, gp.z, gp.w}, h4[4] = {gn.x, gn.y, gn.z, gn.w};
+        const float x4[4] = {xp.x, xp.y, xp.z, xp.w}, y4[4] = {xn.x, xn.y, xn.z, xn.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gm[4 * j + k] += g4[j] * x4[k] + h4[j] * y4[k];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float v = wave_sum_f32(gm[k]);
+        if (lane == 0) s_part[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kGmBlock / 64; ++w) v += s_part[w][threadIdx.x];
+        g_orientation[(int64_t)h * 16 + threadIdx.x] = v;
+    }
+}
+
 }  // namespace art
 
 using namespace art;
@@ -139,22 +179,17 @@ extern "C" int art_align_bwd(const float* points, const float* normals, const fl
     if (H == 0) return ART_OK;
     const int n_tiles = (int)((P + kAlignBlock - 1) / kAlignBlock);
     const dim3 grid((unsigned)(H * n_tiles));
-    if (grad_orientation) {
-        ART_HIP(hipMemsetAsync(grad_orientation, 0, sizeof(float) * 16 * H, stream));
-        hipLaunchKernelGGL(align_bwd_kernel<true>, grid, dim3(kAlignBlock), 0, stream,
+    hipLaunchKernelGGL(align_bwd_kernel<false>, grid, dim3(kAlignBlock), 0, stream,
+                       reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals),
+                       orientation, reinterpret_cast<const float4*>(grad_out_points),
+                       reinterpret_cast<const float4*>(grad_out_normals), (int)P, n_tiles,
+                       reinterpret_cast<float4*>(grad_points), reinterpret_cast<float4*>(grad_normals),
+                       grad_orientation);
+    if (grad_orientation)
+        hipLaunchKernelGGL(align_gm_kernel, dim3((unsigned)H), dim3(kGmBlock), 0, stream,
                            reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals),
-                           orientation, reinterpret_cast<const float4*>(grad_out_points),
-                           reinterpret_cast<const float4*>(grad_out_normals), (int)P, n_tiles,
-                           reinterpret_cast<float4*>(grad_points), reinterpret_cast<float4*>(grad_normals),
-                           grad_orientation);
-    } else {
-        hipLaunchKernelGGL(align_bwd_kernel<false>, grid, dim3(kAlignBlock), 0, stream,
-                           reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals),
-                           orientation, reinterpret_cast<const float4*>(grad_out_points),
-                           reinterpret_cast<const float4*>(grad_out_normals), (int)P, n_tiles,
-                           reinterpret_cast<float4*>(grad_points), reinterpret_cast<float4*>(grad_normals),
-                           grad_orientation);
-    }
+                           reinterpret_cast<const float4*>(grad_out_points), reinterpret_cast<const float4*>(grad_out_normals),
+                           (int)P, grad_orientation);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

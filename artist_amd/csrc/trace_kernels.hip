@@ -420,7 +420,7 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
 //   * optionally (ARTIST_HIP_TAIL=1) the last n_tail items are dealt as two halves of their sample range, so that the
 //     kernel ends within half an item; neutral on the metric field, off by default.
 // Item numbering: [0, n_base - n_tail) whole items, then 2 n_tail halves.
-struct WorkItem { int h, pblock, r0, r1; bool half; };   // half: one of the two halves of a tail item
+struct WorkItem { int h, pblock, rchunk, r0, r1; bool half; };   // half: one of the two halves of a tail item
 __device__ __forceinline__ int work_item_count(const TraceArgs& a) { return a.H * a.n_pblocks * a.n_rchunks + a.n_tail; }
 // Longest items first: an item's cost grows with the distance between heliostat and target (wider image, more rays
 // beyond the window: 83 -> 115 us from the nearest to the farthest tenth of the metric field), and a queue that ends
@@ -451,6 +451,7 @@ __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int ite
     const int rchunk = base % a.n_rchunks;
     w.pblock = (base / a.n_rchunks) % a.n_pblocks;
     w.h = base / (a.n_rchunks * a.n_pblocks);
+    w.rchunk = rchunk;
     w.r0 = rchunk * a.r_chunk;
     w.r1 = min(w.r0 + a.r_chunk, a.R);
     w.half = half >= 0;
@@ -1230,8 +1231,16 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const int pblock = item.pblock;
     const int h = item.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    // the two halves of a tail item add their gradients to rows the host has zeroed
-    const bool atomic_item = ATOMIC_OUT || item.half;
+    // ATOMIC_OUT (a name from round 1): the samples of a point are split over several items.  Each sample chunk then
+    // writes its partial gradients with plain stores to a slab of its own - `grad_origins` / `grad_normals` point at
+    // [n_rchunks,H,P] scratch arrays - and reduce_chunks_kernel adds the slabs in chunk order: bit-reproducible, where
+    // float atomics onto one row were not.  (The two halves of a tail item - an experiment knob, never combined with
+    // chunking - still add with atomics to rows the host has zeroed.)
+    const bool atomic_item = !ATOMIC_OUT && item.half;
+    if constexpr (ATOMIC_OUT) {
+        grad_origins += (int64_t)item.rchunk * a.H * a.P;
+        grad_normals += (int64_t)item.rchunk * a.H * a.P;
+    }
 
     const int t = a.target_idx[h];
     if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: a bad index, or the other instantiation's launch owns this heliostat
@@ -1560,6 +1569,22 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
         item = s_next;
         __syncthreads();
     }
+}
+
+// grads[i] = sum_c slabs[c][i] in chunk order (two [n_chunks,n] float4 slab sets: origins, normals).
+__global__ __launch_bounds__(256) void reduce_chunks_kernel(const float4* __restrict__ slabs_o, const float4* __restrict__ slabs_n,
+                                                            int n_chunks, int64_t n, float4* __restrict__ out_o,
+                                                            float4* __restrict__ out_n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 so = slabs_o[i], sn = slabs_n[i];
+    for (int c = 1; c < n_chunks; ++c) {
+        const float4 a = slabs_o[(int64_t)c * n + i], b = slabs_n[(int64_t)c * n + i];
+        so.x += a.x; so.y += a.y; so.z += a.z; so.w += a.w;
+        sn.x += b.x; sn.y += b.y; sn.z += b.z; sn.w += b.w;
+    }
+    out_o[i] = so; out_n[i] = sn;
 }
 
 // pixel accumulators -> fp32 bitmap (one rounding per pixel), and the accumulators are left zero for the next call.
@@ -1934,7 +1959,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                              double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
                              int64_t Tc, int64_t W, int64_t Hh, int mode, const float* grad_flux, float* grad_origins,
                              float* grad_normals, float* grad_prim_corners, float* grad_prim_spans,
-                             float* grad_prim_normals, void* stream_)
+                             float* grad_prim_normals, float* grad_scratch, int64_t grad_scratch_floats, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
@@ -1968,14 +1993,23 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+        // A small field is cut into sample chunks to fill the chip; the chunks of a point then write partial gradients
+        // to [n_rchunks,H,P] slabs in the caller's scratch buffer and reduce_chunks_kernel adds them in chunk order
+        // (no float atomics: bit-reproducible gradients).  Without (enough) scratch the samples stay in one item.
+        if (a.n_rchunks > 1 && (grad_scratch == nullptr || (reinterpret_cast<uintptr_t>(grad_scratch) % 16) != 0 ||
+                                grad_scratch_floats < (int64_t)a.n_rchunks * H * P * 8)) {
+            cfg.target_blocks = 1;
+            window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+        }
+        const bool atomic_out = a.n_rchunks > 1;
+        if (atomic_out) a.n_tail = 0;
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float);
-        const bool atomic_out = a.n_rchunks > 1;
         if (atomic_out) {
-            ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
-            ART_HIP(hipMemsetAsync(grad_normals, 0, sizeof(float) * 4 * H * P, stream));
+            go = reinterpret_cast<float4*>(grad_scratch);
+            gn = go + (int64_t)a.n_rchunks * H * P;
         } else if (a.n_tail > 0) {
             // the tail items are dealt as two halves that ADD their gradients: zero the rows of their points - the
             // suffix of the arrays that starts at the first tail item's (heliostat, point block)
@@ -2022,6 +2056,12 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
 #undef ART_LAUNCH_BWD_BL
 #undef ART_LAUNCH_BWD
         ART_HIP(hipGetLastError());
+        if (atomic_out) {
+            const int64_t n = H * P;
+            hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, go, gn, a.n_rchunks, n,
+                               reinterpret_cast<float4*>(grad_origins), reinterpret_cast<float4*>(grad_normals));
+            ART_HIP(hipGetLastError());
+        }
         return ART_OK;
     }
     if (Tc > 0 || blocking) return ART_EUNSUPPORTED;
@@ -2039,6 +2079,17 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     }
     ART_HIP(hipGetLastError());
     return ART_OK;
+}
+
+extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P)
+{
+    if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26)) return 0;
+    TraceArgs a = {};
+    a.H = (int)H; a.R = (int)R; a.P = (int)P;
+    const FwdConfig cfg = fwd_config();
+    if (cfg.variant != 0) return 0;
+    window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+    return a.n_rchunks > 1 ? (int64_t)a.n_rchunks * H * P * 8 : 0;
 }
 
 extern "C" int art_per_target_sum(const float* bitmaps, const int32_t* target_idx, int64_t H, int64_t T,

@@ -213,13 +213,16 @@ class TraceRays(torch.autograd.Function):
         g_pc = g_ps = g_pn = None
         if block_tabs:
             g_pc, g_ps, g_pn = (torch.empty_like(t) for t in block_tabs[:3])
+        n_scratch = int(_lib.lib().art_trace_bwd_scratch_floats(H, R, P))
+        scratch = torch.empty((n_scratch,), dtype=torch.float32, device=dev) if n_scratch else None
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_bwd(
                 origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
                 sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,
                 *block_ptrs, Cmax, N, max_scatter, mag, ext, refl, H, R, P, centers.shape[0], Tc, width, height,
                 1 if per_target else 0, grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(),
-                *(t.data_ptr() if t is not None else None for t in (g_pc, g_ps, g_pn)), _stream(dev))
+                *(t.data_ptr() if t is not None else None for t in (g_pc, g_ps, g_pn)),
+                None if scratch is None else scratch.data_ptr(), n_scratch, _stream(dev))
         _lib.check(rc, "art_trace_bwd")
         return (g_o, g_n) + (None,) * 14 + (g_pc, g_ps, g_pn, None, None, None)
 

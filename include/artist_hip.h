@@ -116,6 +116,7 @@ int art_async_status(void *stream, int clear);
  * 610-778; geometry.py:287-445 for cylinders).  Same inputs as the forward plus
  *   grad_flux     [H,Hh,W] (mode 0) or [T+Tc,Hh,W] (mode 1)
  *   grad_origins, grad_normals   outputs [H,P,4] (w components 0 / as autograd gives them)
+ *   grad_scratch, grad_scratch_floats   see art_trace_bwd_scratch_floats
  *   grad_prim_corners [N,4,4], grad_prim_spans [N,2,4], grad_prim_normals [N,4]   (blocking only; fully
  *                 written) DIRECT gradients of the soft mask w.r.t. the rectangle tables - corner 0, both spans,
  *                 the normal; the caller chains them through whatever built the tables (blocking.py:170-207)
@@ -130,7 +131,14 @@ int art_trace_bwd(const float *origins, const float *normals, const float *incid
                   double max_scatter_angle, double ray_magnitude, double extinction, double reflectivity,
                   int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
                   const float *grad_flux, float *grad_origins, float *grad_normals, float *grad_prim_corners,
-                  float *grad_prim_spans, float *grad_prim_normals, void *stream);
+                  float *grad_prim_spans, float *grad_prim_normals, float *grad_scratch, int64_t grad_scratch_floats,
+                  void *stream);
+
+/* Scratch of art_trace_bwd in floats (0 for fields that fill the chip without cutting a point's samples into chunks).
+ * With a 16-byte aligned buffer of at least this size the chunks' partial gradients are written to slabs and added in
+ * chunk order - bit-reproducible gradients; with NULL (or less) the samples of a point stay in one work item, which is
+ * reproducible too but leaves most of the chip idle on a field of a few heliostats. */
+int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P);
 
 /* ---------------------------------------------------------------------------------------------
  * art_blocking_filter - lbvh_filter_blocking_planes (artist/raytracing/blocking.py:832-995, with the tree of

@@ -64,7 +64,7 @@ def main():
                 fn = getattr(handle, fname)
                 fn.argtypes = argtypes
                 fn.restype = (ctypes.c_char_p if fname == "art_strerror"
-                              else ctypes.c_int64 if fname == "art_blocking_workspace_bytes" else ctypes.c_int)
+                              else ctypes.c_int64 if fname in ("art_blocking_workspace_bytes", "art_trace_bwd_scratch_floats") else ctypes.c_int)
             assert handle.art_abi_version() == _lib.ABI_VERSION, (path, handle.art_abi_version())
         variants.append((name, handle, env))
 
