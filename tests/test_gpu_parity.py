@@ -276,6 +276,8 @@ def test_error_behaviour(field):
         rt.trace_rays(inc, torch.zeros_like(mask), tix)           # tests/raytracing/test_heliostat_ray_tracer.py:44-104
     with pytest.raises(IndexError):
         rt.trace_rays(inc, mask, tix + 5)
+    with pytest.raises(IndexError):                                  # the per-target entry point checks too
+        rt.trace_rays_per_target(inc, mask, tix + 5)
     cpu = [torch.zeros(1, 4, 4), torch.zeros(1, 4, 4), torch.zeros(1, 4), torch.zeros(1, 2, 4), torch.zeros(1, 2, 4),
            torch.zeros(1, dtype=torch.long), torch.zeros(1, 4), torch.zeros(1, 4), torch.ones(1, 2)]
     with pytest.raises(ArtistHipError, match="no CPU fallback"):
@@ -806,6 +808,80 @@ def test_blocking_through_ray_tracer_mirror():
     import test_oracle_golden as tog
     _, _, _, g_sfc = tog._chain_primitive_grads(n(points), gpc, gps, gpn)
     assert rel_l2(n(points.grad), go + g_sfc) < 5e-3, rel_l2(n(points.grad), go + g_sfc)
+
+
+@pytest.mark.parametrize("lbvh_compat", [True, False])
+def test_sharded_blocking_equals_single_rank(lbvh_compat):
+    """Heliostat sharding with blocking on (each rank needs the rectangles of ALL heliostats, which the
+    mirror builds on every rank like the reference, heliostat_ray_tracer.py:159-183).  The filtered set F is the union
+    over the rays a rank traces, as in the reference it is the union over a batch (:445-461) - a rectangle that only
+    another rank's rays hit is missing from this rank's F.  That cannot change this rank's flux beyond the soft mask's
+    tails: a ray blocked by rectangle k hits k's box, so k is in the F of the rank that traces the ray; what F may lack
+    are rectangles whose sigmoids contribute < 5e-12 to the exponent.  Asserted: per-heliostat rows
+    and the summed per-target bitmaps agree to 1e-6, blocking factors to one ray."""
+    from artist_amd import HeliostatRayTracer
+    from artist_amd.scene import build_synthetic_scenario
+    H, R = 7, 12
+    scenario, _ = build_synthetic_scenario(H, R, n_eval=12, device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    group.positions = torch.tensor([[0.0, 150.0, 0.0, 1.0], [0.3, 147.2, 0.0, 1.0], [-0.8, 144.0, 0.0, 1.0], [2.0, 141.0, 0.0, 1.0],
+                                    [-25.0, 100.0, 0.0, 1.0], [0.9, 138.5, 0.0, 1.0], [-24.5, 97.0, 0.0, 1.0]], device=DEV)
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    tix = torch.zeros(H, dtype=torch.long, device=DEV)
+    inc = torch.nn.functional.normalize(torch.tensor([0.1, 0.95, -0.1, 0.0], device=DEV), dim=0).expand(H, 4).contiguous()
+    group.activate_heliostats(mask, DEV)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask, DEV)
+    res = torch.tensor([64, 64])
+    whole = HeliostatRayTracer(scenario, group, bitmap_resolution=res)
+    whole.lbvh_compat = lbvh_compat
+    flux, intercept, on_target, blocking = whole.trace_rays(inc, mask, tix)
+    per_target = whole.get_bitmaps_per_target(flux, tix)
+    if not lbvh_compat:
+        assert float(blocking.min()) < 0.8                       # the column does shade itself
+    rays = R * group.active_surface_points.shape[1]
+    acc = torch.zeros_like(per_target)
+    for rank in range(3):
+        part = HeliostatRayTracer(scenario, group, bitmap_resolution=res, world_size=3, rank=rank)
+        part.lbvh_compat = lbvh_compat
+        f, ic, ot, bl = part.trace_rays(inc, mask, tix)
+        idx = part.get_sampler_indices()
+        assert set(part.filtered_blocking_primitive_indices.tolist()) <= set(whole.filtered_blocking_primitive_indices.tolist())
+        np.testing.assert_allclose(n(f), n(flux[idx]), rtol=0, atol=1e-6 * float(flux.max()))
+        np.testing.assert_allclose(n(bl), n(blocking[idx]), rtol=0, atol=1.5 / rays)
+        np.testing.assert_array_equal(n(ot), n(on_target[idx]))
+        acc += part.get_bitmaps_per_target(f, tix[idx])
+    assert rel_l2(n(acc), n(per_target)) < 1e-6, rel_l2(n(acc), n(per_target))
+
+
+def test_target_index_out_of_range_is_reported_not_dereferenced(golden):
+    """The C ABI trusts no index: a stale target index is found ON THE DEVICE (the heliostat is skipped, nothing is read
+    out of bounds), the asynchronous call itself returns ART_OK, art_async_status reports ART_ETARGET, later trace calls
+    refuse to start until the status is cleared - and the other heliostats of the launch are untouched."""
+    from artist_amd import _lib, ops
+    d = golden("small_deg3")
+    inp = trace_inputs(d)
+    good, _ = ops.trace_rays(**inp)
+    bad = dict(inp)
+    bad["target_idx"] = inp["target_idx"].clone()
+    bad["target_idx"][1] = 7                                     # the tables hold one planar area
+    flux, fac = ops.trace_rays(**bad)                            # asynchronous: no error yet
+    stream = torch.cuda.current_stream(DEV).cuda_stream
+    assert _lib.lib().art_async_status(stream, 0) == -2          # ART_ETARGET, still set
+    with pytest.raises(IndexError, match="out of range"):
+        ops.trace_rays(**inp)                                    # refused while the status is set
+    with pytest.raises(IndexError, match="out of range"):
+        ops.check_async_errors(DEV)                              # reports and clears
+    assert _lib.lib().art_async_status(stream, 0) == 0
+    assert float(flux[1].abs().sum()) == 0 and float(fac[:2, 1].abs().sum()) == 0      # (blocking factor: 1 = nothing blocked)
+    for h in (0, 2, 3):
+        np.testing.assert_array_equal(n(flux[h]), n(good[h]))
+    again, _ = ops.trace_rays(**inp)                             # and the library works as before
+    np.testing.assert_array_equal(n(again), n(good))
+    # the mirror checks on the host in BOTH entry points before anything is launched
+    bad["target_idx"][1] = -3
+    flux, fac = ops.trace_rays(**bad)
+    with pytest.raises(IndexError):
+        ops.check_async_errors(DEV)
 
 
 # ---------------------------------------------------------------------------------------------
