@@ -157,6 +157,20 @@ __device__ __forceinline__ float div_noscale(float n, float a)
     return fmaf(r, y, q);
 }
 
+// The same quotient, bit for bit, with the refined reciprocal y ~ 1 / a handed back (the backward pass multiplies by it
+// where autograd divides: gradients are compared with a tolerance, the quotient is not).
+__device__ __forceinline__ float div_noscale_rcp(float n, float a, float& y)
+{
+    const float y0 = __builtin_amdgcn_rcpf(a);
+    const float e = fmaf(-a, y0, 1.0f);
+    y = fmaf(e, y0, y0);
+    float q = n * y;
+    float r = fmaf(-a, q, n);
+    q = fmaf(r, y, q);
+    r = fmaf(-a, q, n);
+    return fmaf(r, y, q);
+}
+
 // heliostat_ray_tracer.py:547-552: 4-term dot products, k = 0..3 sequential; the w column of the
 // matrix is zero for rows 0..2 and d.w is finite, so "+ 0*d.w" is an exact no-op apart from the
 // sign of a zero result, which nothing downstream observes.

@@ -885,8 +885,13 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             resolve_carries(ps, acc, a.W, a.Hh, win.shift);
         };
         // `live`: all ones, or zero for the padding rays of the last ring round (they then fail every mask)
-        auto trace_one = [&](auto small_angles, const float u, const float e, const unsigned long long live) {
-            const Rot m = make_rot_t<decltype(small_angles)::value>(e, u);
+        auto trace_one = [&](const float u, const float e, const unsigned long long live) {
+            // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
+            // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
+            // merge their tails and spill what crossed the join
+            Rot m;
+            if (__builtin_expect(wave_any(!(fmaxf(fabsf(u), fabsf(e)) <= kSmallAngle)), 0)) m = make_rot(e, u);
+            else m = make_rot_t<true>(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
             const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
@@ -954,12 +959,6 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             const int64_t row = (int64_t)min(r, nr - 1) * a.sr;
             load_dist_stream<INTERLEAVED>(bu_ + row, be_ + row, lane_off, u, e);
         };
-        auto trace_ray = [&](const float u, const float e, const unsigned long long live) {
-            // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always and the full-range
-            // sin/cos code stays out of the way behind a wave-uniform branch
-            if (__builtin_expect(wave_any(!(fmaxf(fabsf(u), fabsf(e)) <= kSmallAngle)), 0)) trace_one(std::false_type{}, u, e, live);
-            else trace_one(std::true_type{}, u, e, live);
-        };
 #ifdef ART_LEAN_NO_RING          // A/B build: every sample requested where it is used
         if (false) {
 #else
@@ -978,7 +977,10 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 float u, e;                                                         \
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(u), "=v"(e) : "v"(su##j), "v"(se##j) : "memory"); \
                 request(k + j + 8, su##j, se##j);                                   \
-                trace_ray(u, e, k + j < nr ? ~0ull : 0ull);                         \
+                trace_one(u, e, k + j < nr ? ~0ull : 0ull);                          \
+                /* a ray's arithmetic stays inside its step: hoisting the next step's head above it made the */ \
+                /* compiler spill the ray's live values around the hoisted code */   \
+                __builtin_amdgcn_sched_barrier(0);                                  \
             }
             for (int k = 0; k < nr; k += 8) {
                 ART_RING_STEP(0) ART_RING_STEP(1) ART_RING_STEP(2) ART_RING_STEP(3)
@@ -989,7 +991,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             for (int r = 0; r < nr; ++r) {           // few samples per point (field-scale prediction): nothing to pipeline
                 float u, e;
                 request(r, u, e);
-                trace_ray(u, e, ~0ull);
+                trace_one(u, e, ~0ull);
             }
         }
     }
@@ -1543,9 +1545,248 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     }
 }
 
+
+// --------------------------------------------------------------------------------------------
+// The planar, non-blocking backward item with the lean ray body and the distortion ring of trace_fwd_item_lean:
+// the forward is re-computed with the reference's arithmetic up to the pixel coordinates, the window test and the
+// LDS address are formed in floating point and clamped (a ray outside the window reads some in-range cell and is
+// given zero weight), the gradient arithmetic shares its sub-expressions:
+//   A = chu g1 + clu g4,  B = chu g2 + clu g3   ->  dL/dI = cle A + che B,  dL/dbe = (B - A) I
+//   dL/dbu = (cle (g1 - g4) + che (g2 - g3)) I
+// --------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) float lds_f32;
+
+template <bool INTERLEAVED, bool ATOMIC_OUT>
+__device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const float* __restrict__ grad_flux,
+                                                    float4* __restrict__ grad_origins, float4* __restrict__ grad_normals,
+                                                    const WorkItem item, unsigned int* __restrict__ work_counter, int* s_next)
+{
+    extern __shared__ __attribute__((aligned(16))) float gtile[];
+    __shared__ float s_red[13][16];
+    __shared__ Window s_win;
+
+    const int pblock = item.pblock;
+    const int h = item.h;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const bool atomic_item = !ATOMIC_OUT && item.half;
+    if constexpr (ATOMIC_OUT) {                      // chunk slabs: see trace_bwd_item
+        grad_origins += (int64_t)item.rchunk * a.H * a.P;
+        grad_normals += (int64_t)item.rchunk * a.H * a.P;
+    }
+    const int t = a.target_idx[h];
+    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0) {
+        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+        return;
+    }
+    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    const Cyl cy = {};
+    const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
+    const float4 inc = a.incident[h];
+    const int p0 = pblock * a.p_block;
+    const int p1 = min(p0 + a.p_block, a.P);
+    const int r0 = item.r0;
+    const int r1 = item.r1;
+    const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
+    const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
+    const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
+
+    compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
+    const Window win = s_win;
+    unsigned next_item = 0u;
+    const float kI = (a.mag * a.k_ext) * a.k_refl;
+    const float sx = pl.wm1 / pl.w, sz = pl.hm1 / pl.h;
+    const float Wf = (float)a.W, Hf = (float)a.Hh;
+    const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
+    const float lds_base = (float)(unsigned)(size_t)(lds_f32*)gtile;
+    const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
+    const unsigned twm2_bits = f32_bits((float)(win.tw - 2)), uthm2_bits = f32_bits((float)(win.th - 2));
+    const unsigned tw4 = 4u * (unsigned)win.tw;
+  for (int pass = 0; pass < win.npass; ++pass) {
+    const int pu0 = win.u0 + pass * (win.ths - 1);
+    const int pth = min(win.ths, win.u0 + win.th - pu0);
+    const bool first = pass == 0;
+    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
+    {   // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped: see trace_bwd_item
+        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+        const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;
+        const int64_t dg = (int64_t)nwaves * a.W;
+        const int dt = nwaves * win.tw;
+        const int tw4c = win.tw & ~3;
+        int rb = wave;
+        for (; rb + 3 * nwaves < pth; rb += 4 * nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = 4 * lane; c < tw4c; c += 256) {
+                const F4 v0 = *reinterpret_cast<const F4*>(g0 + c), v1 = *reinterpret_cast<const F4*>(g0 + c - dg);
+                const F4 v2 = *reinterpret_cast<const F4*>(g0 + c - 2 * dg), v3 = *reinterpret_cast<const F4*>(g0 + c - 3 * dg);
+                float* tt_ = t0 + c;
+                tt_[0] = v0.x; tt_[1] = v0.y; tt_[2] = v0.z; tt_[3] = v0.w;
+                tt_[dt] = v1.x; tt_[dt + 1] = v1.y; tt_[dt + 2] = v1.z; tt_[dt + 3] = v1.w;
+                tt_[2 * dt] = v2.x; tt_[2 * dt + 1] = v2.y; tt_[2 * dt + 2] = v2.z; tt_[2 * dt + 3] = v2.w;
+                tt_[3 * dt] = v3.x; tt_[3 * dt + 1] = v3.y; tt_[3 * dt + 2] = v3.z; tt_[3 * dt + 3] = v3.w;
+            }
+            if (lane < 4 * (win.tw - tw4c)) {
+                const int q = lane / (win.tw - tw4c), c = tw4c + lane % (win.tw - tw4c);
+                t0[q * dt + c] = g0[c - q * dg];
+            }
+        }
+        for (; rb < pth; rb += nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = lane; c < win.tw; c += 64) t0[c] = g0[c];
+        }
+    }
+    __syncthreads();
+
+    const float pu0f = (float)pu0;
+    const unsigned thm2_bits = f32_bits((float)(pth - 2));
+    const float addr_hi_f = lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2));
+    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+        const float4 o = org[p];
+        const float4 n = nrm[p];
+        float4 d; float s;
+        reflect(inc, n, d, s);
+        const float numer = plane_numer(pl, o);
+        float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // gox / goz / goy: sums of g_hx / g_hz / g_numer
+        auto trace_one = [&](const float u, const float e, const unsigned long long live) {
+            // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
+            // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
+            // merge their tails and spill what crossed the join
+            Rot m;
+            if (__builtin_expect(wave_any(!(fmaxf(fabsf(u), fabsf(e)) <= kSmallAngle)), 0)) m = make_rot(e, u);
+            else m = make_rot_t<true>(e, u);
+            float rx, ry, rz;
+            scatter(m, d, rx, ry, rz);
+            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
+            const unsigned long long m_front = ballot64(ah < 0.0f) & live;
+            float y;                                                         // ~ 1 / ah
+            // (the denominator is made safe, unlike in the forward: a masked ray's terms are multiplied by zero
+            //  below and must therefore be finite)
+            const float tt = div_noscale_rcp(numer, select_mask(m_front, ah, 1.0f), y);
+            const float hx = o.x + rx * tt, hz = o.z + rz * tt;
+            const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;
+            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;
+            const float be = pl.wm1 - be0;
+            const float tbe = truncf(be), tbu = truncf(bu);
+            const float che = be - tbe, chu = bu - tbu;
+            const float cle = 1.0f - che, clu = 1.0f - chu;
+            const float lef = tbe - e0f, luf = tbu - pu0f;
+            const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
+            const unsigned long long m_in = m_front & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
+            const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
+            const unsigned addr_lo = (unsigned)af;
+            const lds_f32* lo = (const lds_f32*)(size_t)addr_lo;
+            const lds_f32* up = (const lds_f32*)(size_t)(addr_lo + tw4);
+            float g1 = up[0], g2 = up[1], g3 = lo[1], g4 = lo[0];
+            unsigned long long m_use = m_in;
+#ifndef ART_ABLATE_NO_STRAYS
+            if (__builtin_expect((m_valid & ~m_in) != 0ull, 0)) {
+                // valid, outside this pass's window: a stray of the union window gathers from global memory, once
+                const bool valid = (m_valid >> lane) & 1ull, inwin = (m_in >> lane) & 1ull;
+                const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
+                const bool in_union = f32_bits(lef) <= twm2_bits && f32_bits(tbu - u0f) <= uthm2_bits;
+                const bool stray = first && valid && !inwin && on && !in_union;
+                if (stray) {
+                    const float* g_hi = G + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;
+                    const float* g_lo = g_hi + a.W;
+                    g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
+                }
+                m_use |= ballot64(stray);
+            }
+#endif
+            {
+#pragma clang fp contract(fast)
+                const float kIm = select_or_zero(m_use, kI);
+                const float I = -(kIm * ah);                                  // mag (-a) k_ext k_refl (one rounding: gradient side)
+                const float A = chu * g1 + clu * g4, B = chu * g2 + clu * g3;
+                const float gI = cle * A + che * B;
+                const float g_be = (B - A) * I;
+                const float g_bu = (cle * (g1 - g4) + che * (g2 - g3)) * I;
+                const float g_hx = -g_be * sx;
+                const float g_hz = g_bu * sz;
+                const float g_numer = (g_hx * rx + g_hz * rz) * y;
+                const float g_a = -kIm * gI - g_numer * tt;
+                const float grx = g_hx * tt + g_a * pl.mx;
+                const float gry = g_a * pl.my;
+                const float grz = g_hz * tt + g_a * pl.mz;
+                gox += g_hx;
+                goz += g_hz;
+                goy += g_numer;
+                gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
+                gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
+                gdz += m.ce * grz - m.se * gry;
+            }
+            // The sums are pinned here: volatile statements keep their order, so this ray's gradient arithmetic cannot
+            // sink below the next ring step's head (it did, and everything that was alive across it went to scratch).
+            asm volatile("" : "+v"(gdx), "+v"(gdy), "+v"(gdz), "+v"(gox), "+v"(goy), "+v"(goz));
+        };
+        const int lane_off = p * (int)a.sp;
+        const int nr = r1 - r0;
+        const float* __restrict__ bu_ = a.dist_u + dbase;
+        const float* __restrict__ be_ = a.dist_e + dbase;
+        auto request = [&](int r, float& u, float& e) {
+            const int64_t row = (int64_t)min(r, nr - 1) * a.sr;
+            load_dist_stream<INTERLEAVED>(bu_ + row, be_ + row, lane_off, u, e);
+        };
+        if (nr >= 8) {                                // the distortion ring of trace_fwd_item_lean
+            float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
+            request(0, su0, se0); request(1, su1, se1); request(2, su2, se2); request(3, su3, se3);
+            request(4, su4, se4); request(5, su5, se5); request(6, su6, se6); request(7, su7, se7);
+#define ART_RING_STEP(j)                                                            \
+            {                                                                       \
+                float u, e;                                                         \
+                asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(u), "=v"(e) : "v"(su##j), "v"(se##j) : "memory"); \
+                request(k + j + 8, su##j, se##j);                                   \
+                trace_one(u, e, k + j < nr ? ~0ull : 0ull);                          \
+                /* a ray's arithmetic stays inside its step: hoisting the next step's head above it made the */ \
+                /* compiler spill the ray's live values around the hoisted code */   \
+                __builtin_amdgcn_sched_barrier(0);                                  \
+            }
+            for (int k = 0; k < nr; k += 8) {
+                ART_RING_STEP(0) ART_RING_STEP(1) ART_RING_STEP(2) ART_RING_STEP(3)
+                ART_RING_STEP(4) ART_RING_STEP(5) ART_RING_STEP(6) ART_RING_STEP(7)
+            }
+#undef ART_RING_STEP
+        } else {
+            for (int r = 0; r < nr; ++r) {
+                float u, e;
+                request(r, u, e);
+                trace_one(u, e, ~0ull);
+            }
+        }
+        const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
+        // hit = o + t r, t = (c - o).m / (r.m): dL/do = (g_hx, 0, g_hz) - m * sum g_numer
+        const float sn = goy;
+        const float4 go = make_float4(gox - sn * pl.mx, -(sn * pl.my), goz - sn * pl.mz, 0.0f);
+        const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
+                                      -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
+        const int64_t idx = (int64_t)h * a.P + p;
+        if (atomic_item) {
+            float* po = reinterpret_cast<float*>(grad_origins + idx);
+            float* pn = reinterpret_cast<float*>(grad_normals + idx);
+            atomicAdd(po + 0, go.x); atomicAdd(po + 1, go.y); atomicAdd(po + 2, go.z);
+            atomicAdd(pn + 0, gn.x); atomicAdd(pn + 1, gn.y); atomicAdd(pn + 2, gn.z); atomicAdd(pn + 3, gn.w);
+        } else if (first) {
+            grad_origins[idx] = go;
+            grad_normals[idx] = gn;
+        } else {
+            const float4 o0 = grad_origins[idx], n0 = grad_normals[idx];
+            grad_origins[idx] = make_float4(o0.x + go.x, o0.y + go.y, o0.z + go.z, 0.0f);
+            grad_normals[idx] = make_float4(n0.x + gn.x, n0.y + gn.y, n0.z + gn.z, n0.w + gn.w);
+        }
+    }
+    if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
+    __syncthreads();
+  }
+}
+
 // Persistent workgroups over the work-item queue, like the forward kernel.
-template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
-__global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
+// (the lean instantiation runs 768-thread workgroups - three waves per SIMD, 168 registers: the ring of distortion
+//  samples and the gradient sums do not fit the 128 registers of a 1024-thread workgroup, and vector issue is no slower
+//  with three waves than with four, tools/issue_bench.hip)
+constexpr int kLeanBwdThreads = 768;
+template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
+__global__ __launch_bounds__((CYL || BLOCKING) ? 512 : (LEAN ? kLeanBwdThreads : 1024)) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
                                                              float4* __restrict__ grad_normals,
                                                              float* __restrict__ g_corners, float* __restrict__ g_spans,
@@ -1563,8 +1804,12 @@ __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : 1024) void trace_bwd_lds_
     }
     const bool reverse = a.reverse_bwd != 0;
     while (item < n_items) {
-        trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
-                                                               g_pnormals, decode_work_item(a, item, reverse), work_counter, &s_next);
+        if constexpr (LEAN)
+            trace_bwd_item_lean<INTERLEAVED, ATOMIC_OUT>(a, grad_flux, grad_origins, grad_normals, decode_work_item(a, item, reverse),
+                                                         work_counter, &s_next);
+        else
+            trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
+                                                                   g_pnormals, decode_work_item(a, item, reverse), work_counter, &s_next);
         __syncthreads();
         item = s_next;
         __syncthreads();
@@ -1673,6 +1918,7 @@ struct FwdConfig {
     bool p_block_fixed, p_block_bwd_fixed;   // set by the environment: no adaptation to the grid size
     int multipass_ratio;
     int min_rays;       // rays per workgroup worth a window build + flush
+    bool exact_pblock;  // balanced point blocks that need not fill every lane (workgroup sizes that do not divide P)
 };
 
 static FwdConfig fwd_config()
@@ -1695,6 +1941,7 @@ static FwdConfig fwd_config()
     c.p_block_bwd_fixed = getenv("ARTIST_HIP_BWD_PBLOCK") != nullptr;
     c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
     if (c.p_block < 64) c.p_block = 64;
+    c.exact_pblock = env_int("ARTIST_HIP_PBLOCK_EXACT", 0) != 0;
     c.p_block_bwd = env_int("ARTIST_HIP_BWD_PBLOCK", 2048);
     if (c.p_block_bwd < 64) c.p_block_bwd = 64;
     return c;
@@ -1794,7 +2041,7 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     if (p_block_target > a.P) p_block_target = a.P;
     const int nblk = (a.P + p_block_target - 1) / p_block_target;
     // (ARTIST_HIP_PBLOCK_EXACT=1: balanced blocks that need not fill every lane - for workgroup sizes that do not divide P)
-    const int pb = env_int("ARTIST_HIP_PBLOCK_EXACT", 0) ? (a.P + nblk - 1) / nblk : ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
+    const int pb = cfg.exact_pblock ? (a.P + nblk - 1) / nblk : ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
     a.p_block = pb;
     a.n_pblocks = (a.P + pb - 1) / pb;
     a.tile_cap = cfg.tile_cap;
@@ -1992,6 +2239,13 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     FwdConfig cfg = fwd_config();
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
+        // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, two trips of points
+        const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0;
+        if (lean && T > 0 && Tc == 0) {
+            cfg.block = kLeanBwdThreads;
+            cfg.exact_pblock = true;
+            if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = 2 * kLeanBwdThreads;
+        }
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         // A small field is cut into sample chunks to fill the chip; the chunks of a point then write partial gradients
         // to [n_rchunks,H,P] slabs in the caller's scratch buffer and reduce_chunks_kernel adds them in chunk order
@@ -2018,29 +2272,31 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             ART_HIP(hipMemsetAsync(grad_origins + 4 * start, 0, sizeof(float) * 4 * (H * P - start), stream));
             ART_HIP(hipMemsetAsync(grad_normals + 4 * start, 0, sizeof(float) * 4 * (H * P - start), stream));
         }
-#define ART_LAUNCH_BWD(IL, AT, CY, BL)                                                                           \
+#define ART_LAUNCH_BWD(IL, AT, CY, BL, LN)                                                                       \
         do {                                                                                                     \
             const int64_t blocks = (CY || BL) ? items : persistent_blocks;                                       \
-            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL>),    \
+            ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL, LN>),\
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = next_work_counter(stream);                                                  \
             if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
-            hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL>), dim3((unsigned)blocks),                   \
+            hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL, LN>), dim3((unsigned)blocks),               \
                                dim3((CY || BL) && cfg.block > 512 ? 512 : cfg.block), lds, stream, a, grad_flux, \
                                go, gn,                                                                           \
                                grad_prim_corners, grad_prim_spans, grad_prim_normals, work_counter);             \
         } while (0)
-#define ART_LAUNCH_BWD_BL(CY, BL)                                                                                \
+#define ART_LAUNCH_BWD_BL(CY, BL, LN)                                                                            \
         do {                                                                                                     \
-            if (il && atomic_out) ART_LAUNCH_BWD(true, true, CY, BL);                                            \
-            else if (il) ART_LAUNCH_BWD(true, false, CY, BL);                                                    \
-            else if (atomic_out) ART_LAUNCH_BWD(false, true, CY, BL);                                            \
-            else ART_LAUNCH_BWD(false, false, CY, BL);                                                           \
+            if (il && atomic_out) ART_LAUNCH_BWD(true, true, CY, BL, LN);                                        \
+            else if (il) ART_LAUNCH_BWD(true, false, CY, BL, LN);                                                \
+            else if (atomic_out) ART_LAUNCH_BWD(false, true, CY, BL, LN);                                        \
+            else ART_LAUNCH_BWD(false, false, CY, BL, LN);                                                       \
         } while (0)
 #define ART_LAUNCH_BWD_TYPE(CY)                                                                                  \
         do {                                                                                                     \
-            if (blocking) ART_LAUNCH_BWD_BL(CY, true); else ART_LAUNCH_BWD_BL(CY, false);                        \
+            if (blocking) ART_LAUNCH_BWD_BL(CY, true, false); else ART_LAUNCH_BWD_BL(CY, false, false);          \
         } while (0)
+        if (T > 0 && Tc == 0 && lean) ART_LAUNCH_BWD_BL(false, false, true);
+        else
         if (T > 0) ART_LAUNCH_BWD_TYPE(false);
         if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
 #ifdef ART_DEBUG_TIMELINE
@@ -2086,10 +2342,16 @@ extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P)
     if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26)) return 0;
     TraceArgs a = {};
     a.H = (int)H; a.R = (int)R; a.P = (int)P;
-    const FwdConfig cfg = fwd_config();
+    FwdConfig cfg = fwd_config();
     if (cfg.variant != 0) return 0;
     window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
-    return a.n_rchunks > 1 ? (int64_t)a.n_rchunks * H * P * 8 : 0;
+    int64_t chunks = a.n_rchunks;
+    cfg.block = kLeanBwdThreads;                   // the lean kernel's geometry (art_trace_bwd picks one of the two)
+    cfg.exact_pblock = true;
+    if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = 2 * kLeanBwdThreads;
+    window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+    chunks = std::max<int64_t>(chunks, a.n_rchunks);
+    return chunks > 1 ? chunks * H * P * 8 : 0;
 }
 
 extern "C" int art_per_target_sum(const float* bitmaps, const int32_t* target_idx, int64_t H, int64_t T,
