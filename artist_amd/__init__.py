@@ -16,7 +16,7 @@ All arithmetic runs in hand-written HIP kernels (``artist_amd/csrc``) reached th
 """
 from ._lib import ArtistHipError, build, lib  # noqa: F401
 from .nurbs import NURBSSurfaces, create_nurbs_evaluation_grid, create_planar_nurbs_control_points  # noqa: F401
-from .flux import KLDivergenceLoss, PixelLoss, crop_flux_distributions_around_center  # noqa: F401
+from .flux import KLDivergenceLoss, PixelLoss, crop_and_pixel_loss, crop_flux_distributions_around_center  # noqa: F401
 from .kinematics import Actuators, RigidBody  # noqa: F401
 from .ops import align_surfaces, nurbs_surface_points_and_normals, per_target_sum, trace_rays  # noqa: F401
 from .raytracing import HeliostatRayTracer  # noqa: F401

@@ -322,16 +322,23 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     const float wx0 = s_wx[tx][0], wx1 = s_wx[tx][1], wx2 = s_wx[tx][2], wx3 = s_wx[tx][3];
     const int c0 = min(j0, W - 1), c1 = min(j0 + 1, W - 1), c2 = min(j0 + 2, W - 1), c3 = min(j0 + 3, W - 1);   // weight 0 there
     // horizontal pass over the output rows this tile's input rows sampled from
-    for (int r = threadIdx.x / kTileX; r <= ihi - ilo; r += 256 / kTileX) {
-        float v = 0.0f;
-        if (in_x) {
-            const float* __restrict__ row = g + (int64_t)(ilo + r) * W;
-            if (wx0 != 0.0f) v += row[c0] * wx0;
-            if (wx1 != 0.0f) v += row[c1] * wx1;
-            if (wx2 != 0.0f) v += row[c2] * wx2;
-            if (wx3 != 0.0f) v += row[c3] * wx3;
+    // (all four taps are loaded and weighted unconditionally - absent taps have weight 0 and a clamped, valid index - so
+    //  that the loads of several rows are in flight together: with a branch per tap every load was waited for in turn
+    //  and a workgroup took 26 us for 6 000 loads)
+    const int xr = in_x ? 1 : 0;
+    for (int r = threadIdx.x / kTileX; r <= ihi - ilo; r += 4 * (256 / kTileX)) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = min(r + q * (256 / kTileX), ihi - ilo);
+            const float* __restrict__ row = g + (int64_t)(ilo + rr) * W;
+            v[q] = ((row[c0 * xr] * wx0 + row[c1 * xr] * wx1) + row[c2 * xr] * wx2) + row[c3 * xr] * wx3;
         }
-        s_t[r][tx] = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = r + q * (256 / kTileX);
+            if (rr <= ihi - ilo) s_t[rr][tx] = in_x ? v[q] : 0.0f;
+        }
     }
     __syncthreads();
     if (!in_x) return;
@@ -422,6 +429,200 @@ __global__ __launch_bounds__(kReduceBlock) void flux_loss_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused epilogue of a reconstruction epoch: crop around the centre of mass + PixelLoss, one workgroup per bitmap.
+//   forward   centre of mass (one streaming pass) -> every output pixel of the crop is sampled (four gathers that hit
+//             L2: the workgroup has just read the bitmap) and compared with the measured flux on the fly; the cropped
+//             bitmap never goes to HBM.  Traffic: the bitmap and the measured flux once each (the separate kernels:
+//             bitmap twice, cropped bitmap written and read, measured flux once).
+//   backward  one pass re-samples the crop, forms dL/dcrop = gl 2 (crop - truth) / sum(truth), writes it for the
+//             tiled gather below and accumulates the gradient of the two centre coordinates in the same loop;
+//             flux_crop_bwd_tiled_kernel then turns it into dL/dflux as before.
+// Same arithmetic as flux_com_kernel / flux_crop_fwd_kernel / flux_loss_kernel / flux_crop_bwd_com_kernel: results
+// are bit-identical to the separate calls (tests/test_gpu_parity.py::test_fused_crop_pixel_loss).
+// ---------------------------------------------------------------------------------------------------
+struct CropTap { int x0, y0; float tx, ty; bool xa, xb, ya, yb; };
+__device__ __forceinline__ float crop_sample(const float* __restrict__ f, const CropMap& m, int i, int j, float& v00, float& v01,
+                                             float& v10, float& v11, float& tx, float& ty)
+{
+    const float ix = m.ix(j), iy = m.iy(i);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    tx = ix - x0f; ty = iy - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const bool xa = x0 >= 0 && x0 < m.W, xb = x0 + 1 >= 0 && x0 + 1 < m.W;
+    const bool ya = y0 >= 0 && y0 < m.Hh, yb = y0 + 1 >= 0 && y0 + 1 < m.Hh;
+    v00 = ya && xa ? f[y0 * m.W + x0] : 0.0f; v01 = ya && xb ? f[y0 * m.W + x0 + 1] : 0.0f;
+    v10 = yb && xa ? f[(y0 + 1) * m.W + x0] : 0.0f; v11 = yb && xb ? f[(y0 + 1) * m.W + x0 + 1] : 0.0f;
+    // the accumulation order of flux_crop_fwd_kernel (absent taps add nothing there either)
+    float acc = 0.0f;
+    if (ya && xa) acc += v00 * ((1.0f - tx) * (1.0f - ty));
+    if (ya && xb) acc += v01 * (tx * (1.0f - ty));
+    if (yb && xa) acc += v10 * ((1.0f - tx) * ty);
+    if (yb && xb) acc += v11 * (tx * ty);
+    return acc;
+}
+
+
+// The same sample with the column's part of the work done once per thread: when the workgroup size is a multiple of
+// the bitmap width a thread stays in ONE column (pixel k = tid + n * blockDim: j = tid % W, i = tid / W + n * blockDim / W),
+// so ix(j), its floor, weights and bounds leave the loop, and the row's iy(i) is wave-uniform.
+struct CropColumn { int x0; float tx; bool xa, xb; };
+__device__ __forceinline__ CropColumn crop_column(const CropMap& m, int j)
+{
+    CropColumn c;
+    const float ix = m.ix(j);
+    const float x0f = floorf(ix);
+    c.tx = ix - x0f; c.x0 = (int)x0f;
+    c.xa = c.x0 >= 0 && c.x0 < m.W; c.xb = c.x0 + 1 >= 0 && c.x0 + 1 < m.W;
+    return c;
+}
+__device__ __forceinline__ float crop_sample_col(const float* __restrict__ f, const CropMap& m, const CropColumn& c, int i, float& v00,
+                                                 float& v01, float& v10, float& v11, float& ty)
+{
+    const float iy = m.iy(i);
+    const float y0f = floorf(iy);
+    ty = iy - y0f;
+    const int y0 = (int)y0f;
+    const bool ya = y0 >= 0 && y0 < m.Hh, yb = y0 + 1 >= 0 && y0 + 1 < m.Hh;
+    v00 = ya && c.xa ? f[y0 * m.W + c.x0] : 0.0f; v01 = ya && c.xb ? f[y0 * m.W + c.x0 + 1] : 0.0f;
+    v10 = yb && c.xa ? f[(y0 + 1) * m.W + c.x0] : 0.0f; v11 = yb && c.xb ? f[(y0 + 1) * m.W + c.x0 + 1] : 0.0f;
+    float acc = 0.0f;
+    if (ya && c.xa) acc += v00 * ((1.0f - c.tx) * (1.0f - ty));
+    if (ya && c.xb) acc += v01 * (c.tx * (1.0f - ty));
+    if (yb && c.xa) acc += v10 * ((1.0f - c.tx) * ty);
+    if (yb && c.xb) acc += v11 * (c.tx * ty);
+    return acc;
+}
+
+// com4[b] = (x centre, y centre, sum + 1e-8, sum of the measured flux)
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(const float* __restrict__ flux,
+                                                                               const float* __restrict__ dims,
+                                                                               const float* __restrict__ truth, int Hh, int W,
+                                                                               float crop_w, float crop_h, float* __restrict__ loss,
+                                                                               float* __restrict__ com4)
+{
+    __shared__ double s_red[16];
+    __shared__ float s_com[3];
+    const int b = blockIdx.x;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
+    {   // centre of mass: flux_com_kernel's loop
+        double s = 0.0, xs = 0.0, ys = 0.0;
+        if ((W & 3) == 0) {
+            const int W4 = W >> 2;
+            int x4 = threadIdx.x % W4, y = threadIdx.x / W4;
+            const int dx = blockDim.x % W4, dy = blockDim.x / W4;
+            const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f);
+            for (int k = threadIdx.x; k < Hh * W4; k += blockDim.x) {
+                const float4 v = f4[k];
+                const int x = 4 * x4;
+                s += (double)((v.x + v.y) + (v.z + v.w));
+                xs += (double)((lin11(x, W) * v.x + lin11(x + 1, W) * v.y) + (lin11(x + 2, W) * v.z + lin11(x + 3, W) * v.w));
+                ys += (double)(lin11(y, Hh) * ((v.x + v.y) + (v.z + v.w)));
+                x4 += dx; y += dy;
+                if (x4 >= W4) { x4 -= W4; ++y; }
+            }
+        } else {
+            int x = threadIdx.x % W, y = threadIdx.x / W;
+            const int dx = blockDim.x % W, dy = blockDim.x / W;
+            for (int k = threadIdx.x; k < Hh * W; k += blockDim.x) {
+                const float v = f[k];
+                s += (double)v; xs += (double)(lin11(x, W) * v); ys += (double)(lin11(y, Hh) * v);
+                x += dx; y += dy;
+                if (x >= W) { x -= W; ++y; }
+            }
+        }
+        s = block_sum(s, s_red); xs = block_sum(xs, s_red); ys = block_sum(ys, s_red);
+        if (threadIdx.x == 0) {
+            const float S = (float)s + 1e-8f;
+            s_com[0] = (float)(xs / (double)S); s_com[1] = (float)(ys / (double)S); s_com[2] = S;
+        }
+        __syncthreads();
+    }
+    CropMap m;
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.xc = s_com[0]; m.yc = s_com[1]; m.W = W; m.Hh = Hh;
+    double se = 0.0, sg = 0.0;
+    const int npx = Hh * W;
+    if ((int)blockDim.x % W == 0) {                 // a thread owns one column (the per-thread summation order is unchanged)
+        const int j = threadIdx.x % W, di = blockDim.x / W;
+        const CropColumn col = crop_column(m, j);
+        for (int i = threadIdx.x / W; i < Hh; i += di) {
+            float v00, v01, v10, v11, ty;
+            const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
+            const float t = g[i * W + j];
+            const float d = c - t;
+            se += (double)(d * d); sg += (double)t;
+        }
+    } else
+    for (int k = threadIdx.x; k < npx; k += blockDim.x) {
+        const int i = k / W, j = k - i * W;
+        float v00, v01, v10, v11, tx, ty;
+        const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
+        const float t = g[k];
+        const float d = c - t;
+        se += (double)(d * d); sg += (double)t;
+    }
+    se = block_sum(se, s_red);
+    const float sgf = (float)block_sum(sg, s_red);
+    if (threadIdx.x == 0) {
+        loss[b] = (float)se / sgf;                              // loss.py:312-318
+        com4[4 * b] = s_com[0]; com4[4 * b + 1] = s_com[1]; com4[4 * b + 2] = s_com[2]; com4[4 * b + 3] = sgf;
+    }
+}
+
+// grad_crop[b] = gl[b] 2 (crop - truth) / sum(truth) (written), gcom[b] = its gradient w.r.t. the two centre coordinates
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_bwd_kernel(const float* __restrict__ flux,
+                                                                               const float* __restrict__ dims,
+                                                                               const float* __restrict__ truth,
+                                                                               const float* __restrict__ com4,
+                                                                               const float* __restrict__ grad_loss, int Hh, int W,
+                                                                               float crop_w, float crop_h,
+                                                                               float* __restrict__ grad_crop, float* __restrict__ com3,
+                                                                               float* __restrict__ gcom)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.x;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
+    float* __restrict__ gc = grad_crop + (int64_t)b * Hh * W;
+    CropMap m;
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.xc = com4[4 * b]; m.yc = com4[4 * b + 1]; m.W = W; m.Hh = Hh;
+    const float sgf = com4[4 * b + 3], gl = grad_loss[b];
+    double gx = 0.0, gy = 0.0;
+    const int npx = Hh * W;
+    if ((int)blockDim.x % W == 0) {
+        const int j = threadIdx.x % W, di = blockDim.x / W;
+        const CropColumn col = crop_column(m, j);
+        for (int i = threadIdx.x / W; i < Hh; i += di) {
+            float v00, v01, v10, v11, ty;
+            const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
+            const int k = i * W + j;
+            const float go = gl * (2.0f * (c - g[k])) / sgf;
+            gc[k] = go;
+            gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
+            gy += (double)(go * ((v10 - v00) * (1.0f - col.tx) + (v11 - v01) * col.tx));
+        }
+    } else
+    for (int k = threadIdx.x; k < npx; k += blockDim.x) {
+        const int i = k / W, j = k - i * W;
+        float v00, v01, v10, v11, tx, ty;
+        const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
+        const float go = gl * (2.0f * (c - g[k])) / sgf;          // flux_loss_kernel's gradient
+        gc[k] = go;
+        gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));     // flux_crop_bwd_com_kernel
+        gy += (double)(go * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
+    }
+    gx = block_sum(gx, s_red);
+    gy = block_sum(gy, s_red);
+    if (threadIdx.x == 0) {
+        gcom[2 * b] = (float)(gx * (double)((float)(W - 1) / 2.0f));
+        gcom[2 * b + 1] = (float)(gy * (double)((float)(Hh - 1) / 2.0f));
+        com3[3 * b] = m.xc; com3[3 * b + 1] = m.yc; com3[3 * b + 2] = com4[4 * b + 2];     // the layout the tiled kernel reads
+    }
+}
+
 }  // namespace art
 
 using namespace art;
@@ -473,6 +674,41 @@ extern "C" int art_flux_loss(const float* prediction, const float* ground_truth,
     if (B == 0) return ART_OK;
     hipLaunchKernelGGL(flux_loss_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, prediction, ground_truth, npix,
                        kind, loss, grad_loss, grad_prediction);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_crop_pixel_loss_fwd(const float* flux, const float* target_dims, const float* ground_truth, int64_t B,
+                                            int64_t Hh, int64_t W, double crop_width, double crop_height, float* loss,
+                                            float* centers4, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(flux, target_dims, ground_truth, loss, B, Hh, W) || !centers4) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    hipLaunchKernelGGL(flux_crop_pixel_loss_fwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
+                       ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, loss, centers4);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_crop_pixel_loss_bwd(const float* flux, const float* target_dims, const float* ground_truth,
+                                            const float* centers4, const float* grad_loss, int64_t B, int64_t Hh, int64_t W,
+                                            double crop_width, double crop_height, float* grad_flux, float* workspace,
+                                            void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(flux, target_dims, ground_truth, centers4, B, Hh, W) || !grad_loss || !grad_flux || !workspace) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    float* grad_crop = workspace;                      // [B,Hh,W]
+    float* com3 = workspace + B * Hh * W;              // [B,3]
+    float* gcom = com3 + 3 * B;                        // [B,2]
+    hipLaunchKernelGGL(flux_crop_pixel_loss_bwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
+                       ground_truth, centers4, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height, grad_crop, com3,
+                       gcom);
+    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel,
+                       dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),
+                       dim3(256), 0, stream, target_dims, com3, gcom, grad_crop, (int)Hh, (int)W, (float)crop_width,
+                       (float)crop_height, grad_flux);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

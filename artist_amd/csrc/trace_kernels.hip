@@ -1028,8 +1028,12 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
 // needs from the kernarg segment instead of carrying it in registers.
 struct FwdLaunch { TraceArgs a; float* flux; unsigned int* counts; unsigned int* work_counter; };
 
+#ifndef ART_LEAN_FWD_THREADS
+#define ART_LEAN_FWD_THREADS 1024
+#endif
+constexpr int kLeanFwdThreads = ART_LEAN_FWD_THREADS;
 template <bool INTERLEAVED, bool CYL, bool BLOCKING, bool LEAN = false>
-__global__ __launch_bounds__(1024) void trace_fwd_lds_kernel(FwdLaunch launch)
+__global__ __launch_bounds__(LEAN ? kLeanFwdThreads : 1024) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
     static_assert(!LEAN || (!CYL && !BLOCKING), "the lean ray body is the planar, non-blocking one");
     __shared__ int s_next, s_reverse;
@@ -2120,6 +2124,11 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // factors - then a valid ray is known to carry intensity and one counter serves both factors
         const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
                           a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
+        if (lean && T > 0 && Tc == 0 && kLeanFwdThreads != 1024) {
+            cfg.block = kLeanFwdThreads;
+            cfg.exact_pblock = true;
+            if (!cfg.p_block_fixed) cfg.p_block = kLeanFwdThreads;
+        }
         window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
         if (items > 2147483647LL - 65536) return ART_EINVAL;

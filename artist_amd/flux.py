@@ -112,6 +112,54 @@ class _FluxLoss(torch.autograd.Function):
         return grad_prediction, None, None
 
 
+class FluxCropPixelLoss(torch.autograd.Function):
+    """``PixelLoss()(crop_flux_distributions_around_center(flux, ...), ground_truth, reduction_dimensions=(1, 2))`` as one
+    pass per direction (``art_flux_crop_pixel_loss_fwd/bwd``): the same numbers, bit for bit, without the cropped
+    bitmaps' round trip through HBM.  Differentiable w.r.t. ``flux``."""
+
+    @staticmethod
+    def forward(ctx, flux, dims, ground_truth, crop_width, crop_height):
+        dev = _require_cuda(flux, dims, ground_truth)
+        flux, dims, ground_truth = _f32c(flux), _f32c(dims), _f32c(ground_truth)
+        if flux.dim() != 3 or dims.shape != (flux.shape[0], 2) or ground_truth.shape != flux.shape:
+            raise ValueError("flux and ground truth must be [B,Hh,W] and the target dimensions [B,2]")
+        B, Hh, W = flux.shape
+        loss = torch.empty((B,), dtype=torch.float32, device=dev)
+        centers = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_flux_crop_pixel_loss_fwd(flux.data_ptr(), dims.data_ptr(), ground_truth.data_ptr(), B, Hh, W,
+                                                         float(crop_width), float(crop_height), loss.data_ptr(),
+                                                         centers.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_flux_crop_pixel_loss_fwd")
+        ctx.save_for_backward(flux, dims, ground_truth, centers)
+        ctx.crop = (float(crop_width), float(crop_height))
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        flux, dims, ground_truth, centers = ctx.saved_tensors
+        dev = flux.device
+        B, Hh, W = flux.shape
+        grad_loss = _f32c(grad_loss)
+        grad_flux = torch.empty_like(flux)
+        workspace = torch.empty((B * Hh * W + 5 * B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_flux_crop_pixel_loss_bwd(flux.data_ptr(), dims.data_ptr(), ground_truth.data_ptr(),
+                                                         centers.data_ptr(), grad_loss.data_ptr(), B, Hh, W, *ctx.crop,
+                                                         grad_flux.data_ptr(), workspace.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_flux_crop_pixel_loss_bwd")
+        return grad_flux, None, None, None, None
+
+
+def crop_and_pixel_loss(flux_distributions: torch.Tensor, solar_tower, target_area_indices: torch.Tensor,
+                        ground_truth: torch.Tensor, crop_width: float = 6, crop_height: float = 6) -> torch.Tensor:
+    """Per-sample pixel loss of the flux cropped around its centre of mass against the measured (cropped) flux: the
+    epilogue of ``SurfaceReconstructor``'s epoch (surface_reconstructor.py:575-590, 664-676) in one fused pass."""
+    dims = target_dimensions(solar_tower, target_area_indices.to(flux_distributions.device))
+    return FluxCropPixelLoss.apply(flux_distributions, dims, ground_truth, crop_width, crop_height)
+
+
 def _check_reduction(kwargs: dict, what: str) -> None:
     if "reduction_dimensions" not in kwargs:          # same messages as artist/optim/loss.py:300-311, 376-383
         if what == "pixel":

@@ -230,7 +230,7 @@ def main():
     dist_u, dist_e = both[..., 0], both[..., 1]
 
     from artist_amd import ops
-    from artist_amd.flux import FluxCrop, PixelLoss
+    from artist_amd.flux import FluxCrop, FluxCropPixelLoss
     target = None
 
     def forward():
@@ -249,8 +249,7 @@ def main():
             if backward:
                 # the epoch's epilogue (surface_reconstructor.py:575-590, 664-676): crop around the centre of mass,
                 # pixel loss against the (cropped) measured flux
-                cropped = FluxCrop.apply(flux, crop_dims, 6.0, 6.0)
-                loss = pixel_loss(cropped, target, reduction_dimensions=(1, 2)).sum()
+                loss = FluxCropPixelLoss.apply(flux, crop_dims, target, 6.0, 6.0).sum()      # one fused pass per direction
                 loss.backward()
                 # surface_reconstructor.py:767-777: every rank ends with the field's gradient.  The shards are
                 # row-disjoint, so the reference's all_reduce(SUM) is an all-gather of the own rows (half the bytes)
@@ -267,7 +266,6 @@ def main():
     except (RuntimeError, TypeError):
         optimizer = torch.optim.Adam([cp], lr=1e-6)
     crop_dims = planar.dimensions.index_select(0, tix.long()).contiguous()
-    pixel_loss = PixelLoss()
     with torch.no_grad():
         f0, _ = forward()
         target = (FluxCrop.apply(f0, crop_dims, 6.0, 6.0) * 1.05 + 1e-3).detach()     # stands in for the measured flux

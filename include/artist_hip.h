@@ -243,6 +243,25 @@ int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B,
                   float *loss, const float *grad_loss, float *grad_prediction, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * art_flux_crop_pixel_loss_fwd / _bwd - the two calls every surface-reconstruction epoch makes on the tracer's
+ * bitmaps, crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246) followed by PixelLoss
+ * (artist/optim/loss.py:251-318; surface_reconstructor.py:575-590, 664-676), as ONE pass per direction: the cropped
+ * bitmaps never reach HBM.  Results are bit-identical to art_flux_crop_fwd + art_flux_loss(kind 0) and to their
+ * backward calls.
+ *   flux [B,Hh,W], target_dims [B,2], ground_truth [B,Hh,W] (the measured, already cropped flux)
+ *   loss [B] out; centers4 [B,4] out (centre of mass x, y, bitmap sum + 1e-8, sum of the measured flux): pass it
+ *   back to the backward call.
+ *   grad_loss [B]; grad_flux [B,Hh,W] out; workspace B*Hh*W + 5*B floats.
+ * ------------------------------------------------------------------------------------------- */
+int art_flux_crop_pixel_loss_fwd(const float *flux, const float *target_dims, const float *ground_truth, int64_t B,
+                                 int64_t Hh, int64_t W, double crop_width, double crop_height, float *loss,
+                                 float *centers4, void *stream);
+int art_flux_crop_pixel_loss_bwd(const float *flux, const float *target_dims, const float *ground_truth,
+                                 const float *centers4, const float *grad_loss, int64_t B, int64_t Hh, int64_t W,
+                                 double crop_width, double crop_height, float *grad_flux, float *workspace,
+                                 void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * art_rigid_body_fwd - RigidBody kinematics of H heliostats in one launch
  * (artist/field/kinematics_rigid_body.py:194-634 with artist/field/actuators_ideal.py:66-111 and
  * actuators_linear.py:79-370).

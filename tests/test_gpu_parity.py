@@ -939,6 +939,35 @@ def test_flux_losses(golden):
             loss_cls()(pred, truth)
 
 
+def test_fused_crop_pixel_loss():
+    """art_flux_crop_pixel_loss_fwd/bwd (crop + PixelLoss in one pass per direction) against the two separate ops the
+    reference's epoch calls (bitmap.py:121-246, loss.py:251-318): the same bits, forward and gradient, incl. an empty
+    bitmap, a spot cut by the border and non-square resolutions."""
+    from artist_amd import PixelLoss
+    from artist_amd.flux import FluxCrop, FluxCropPixelLoss
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    for (B, Hh, W) in [(5, 256, 256), (3, 60, 100), (2, 33, 17)]:
+        ys, xs = torch.meshgrid(torch.arange(Hh, device=DEV, dtype=torch.float32), torch.arange(W, device=DEV, dtype=torch.float32),
+                                indexing="ij")
+        cx = torch.rand(B, generator=gen, device=DEV) * W
+        cy = torch.rand(B, generator=gen, device=DEV) * Hh
+        sig = 3.0 + 10.0 * torch.rand(B, generator=gen, device=DEV)
+        flux = torch.exp(-((xs[None] - cx[:, None, None]) ** 2 + (ys[None] - cy[:, None, None]) ** 2) / (2 * sig[:, None, None] ** 2))
+        flux = flux * (0.5 + torch.rand((B, Hh, W), generator=gen, device=DEV))
+        flux[0] = 0.0                                            # an empty bitmap
+        truth = torch.rand((B, Hh, W), generator=gen, device=DEV) + 0.1
+        dims = torch.tensor([[8.0, 8.0], [7.0, 9.0], [3.0, 5.0], [12.0, 4.0], [6.0, 6.0]], device=DEV)[:B].contiguous()
+        a = flux.clone().requires_grad_(True)
+        loss_a = PixelLoss()(FluxCrop.apply(a, dims, 6.0, 5.0), truth, reduction_dimensions=(1, 2))
+        b = flux.clone().requires_grad_(True)
+        loss_b = FluxCropPixelLoss.apply(b, dims, truth, 6.0, 5.0)
+        np.testing.assert_array_equal(n(loss_b), n(loss_a))
+        w = torch.rand(B, generator=gen, device=DEV)
+        (loss_a * w).sum().backward()
+        (loss_b * w).sum().backward()
+        np.testing.assert_array_equal(n(b.grad), n(a.grad))
+
+
 def test_flux_epilogue_full_size_properties():
     """256 x 256 bitmaps of a traced field: crop of a centred symmetric spot with crop size = target size is the
     identity, the crop is translation-equivariant, and the whole epilogue is differentiable back to the mirror."""

@@ -1,20 +1,21 @@
 #!/usr/bin/env python3
 """gpurun_out/ -> profiles/: the rocprofv3 summaries the bench's roofline object cites.
 
-usage: python tools/make_profiles.py <tag>      (after `bash tools/prof_pass.sh <tag>` and `bash tools/pmc_hbm.sh <tag>`
-                                                 ran on the GPU box and gpurun merged their output back)
-  gpurun_out/prof_<tag>/**/_kernel_stats.csv                 -> profiles/r01_kernel_stats_bench_default.csv
-  gpurun_out/hbm_<tag>_{FETCH_SIZE,WRITE_SIZE,...}/**/*.csv  -> profiles/r01_hbm_traffic.json (bytes per launch)
+usage: python tools/make_profiles.py <tag> [round]   (after `bash tools/prof_pass.sh <tag>` and `bash tools/pmc_hbm.sh <tag>`
+                                                 ran on the GPU box and gpurun merged their output back; round = r02)
+  gpurun_out/prof_<tag>/**/_kernel_stats.csv                 -> profiles/<round>_kernel_stats_bench_default.csv
+  gpurun_out/hbm_<tag>_{FETCH_SIZE,WRITE_SIZE,...}/**/*.csv  -> profiles/<round>_hbm_traffic.json (bytes per launch)
 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts TCC_EA0_RDREQ x 64 B while the requests are 128 B, so it
 is doubled (MI355X_MICROARCH.md, HBM section) and cross-checked against TCC_EA0_RDREQ_sum x 128 B.
 """
 import collections, csv, glob, json, pathlib, shutil, sys
 
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 root = pathlib.Path(__file__).resolve().parent.parent
 stats = sorted(glob.glob(str(root / f"gpurun_out/prof_{tag}/*/*_kernel_stats.csv")))
 if stats:
-    shutil.copy(stats[-1], root / "profiles/r01_kernel_stats_bench_default.csv")
+    shutil.copy(stats[-1], root / f"profiles/{rnd}_kernel_stats_bench_default.csv")
     print("kernel stats <-", stats[-1])
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(str(root / f"gpurun_out/hbm_{tag}_*/*/*_counter_collection.csv")):
@@ -35,5 +36,5 @@ for k, v in agg.items():
     if mean("TCC_EA0_RDREQ_sum") is not None and rd:
         out[k]["rdreq_x128_over_read_bytes"] = mean("TCC_EA0_RDREQ_sum") * 128 / rd
 if agg:
-    json.dump(out, open(root / "profiles/r01_hbm_traffic.json", "w"), indent=1)
+    json.dump(out, open(root / f"profiles/{rnd}_hbm_traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
