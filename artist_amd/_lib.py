@@ -58,9 +58,9 @@ SIGNATURES = {
                             _ptr, _ptr, _c_i64, _c_dbl, _c_int, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_per_target_sum": [_ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr],
     "art_nurbs_fwd": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_i64,
-                      _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr],
-    "art_nurbs_bwd": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_i64,
                       _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr],
+    "art_nurbs_bwd": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_i64,
+                      _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_align_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr],
     "art_align_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr],
     "art_abi_version": [],

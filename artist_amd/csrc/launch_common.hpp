@@ -33,4 +33,26 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return v;
 }
 
+// out_j = sum_k x_k M[j][k], k sequential (row vector times M^T)
+__device__ __forceinline__ float4 apply_mt(const float4 x, const float* __restrict__ M)
+{
+    float4 o;
+    o.x = ((x.x * M[0] + x.y * M[1]) + x.z * M[2]) + x.w * M[3];
+    o.y = ((x.x * M[4] + x.y * M[5]) + x.z * M[6]) + x.w * M[7];
+    o.z = ((x.x * M[8] + x.y * M[9]) + x.z * M[10]) + x.w * M[11];
+    o.w = ((x.x * M[12] + x.y * M[13]) + x.z * M[14]) + x.w * M[15];
+    return o;
+}
+
+// g_x_k = sum_j g_j M[j][k]
+__device__ __forceinline__ float4 apply_m(const float4 g, const float* __restrict__ M)
+{
+    float4 o;
+    o.x = ((g.x * M[0] + g.y * M[4]) + g.z * M[8]) + g.w * M[12];
+    o.y = ((g.x * M[1] + g.y * M[5]) + g.z * M[9]) + g.w * M[13];
+    o.z = ((g.x * M[2] + g.y * M[6]) + g.z * M[10]) + g.w * M[14];
+    o.w = ((g.x * M[3] + g.y * M[7]) + g.z * M[11]) + g.w * M[15];
+    return o;
+}
+
 }  // namespace art

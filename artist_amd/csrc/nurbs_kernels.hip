@@ -33,6 +33,8 @@ struct NurbsArgs {
     const float* knots_v;   // [H,F,nv+q+1]
     const float* canting;   // [H,F,2,4] or null
     const float* transl;    // [H,F,4] or null
+    const float* orientation;   // [H,4,4] or null: the alignment (points @ M^T, normals @ M^T) applied in the epilogue /
+                                // undone in the backward's prologue (heliostat_group_rigid_body.py:217-222, 265-270)
     int p, q, uniform;
     int n_unique_u, n_unique_v;
     int H, F, M, nu, nv;
@@ -236,6 +238,11 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, flo
         po = make_float4(px, py, pz, 1.0f);
         no = make_float4(nx, ny, nz, 0.0f);
     }
+    if (a.orientation) {          // the arithmetic of align_fwd_kernel: the fused result equals the two-kernel one bit for bit
+        const float* Mo = a.orientation + (int64_t)h * 16;
+        po = apply_mt(po, Mo);
+        no = apply_mt(no, Mo);
+    }
     points[(int64_t)hf * a.M + m] = po;
     normals[(int64_t)hf * a.M + m] = no;
 }
@@ -273,8 +280,13 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
         const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * m);
         Eval<DEG> E;
         evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
-        const float4 gp = g_points[(int64_t)hf * a.M + m];
-        const float4 gn = g_normals[(int64_t)hf * a.M + m];
+        float4 gp = g_points[(int64_t)hf * a.M + m];
+        float4 gn = g_normals[(int64_t)hf * a.M + m];
+        if (a.orientation) {      // align_bwd_kernel's arithmetic
+            const float* Mo = a.orientation + (int64_t)h * 16;
+            gp = apply_m(gp, Mo);
+            gn = apply_m(gn, Mo);
+        }
         float gpt[3], gnr[3];
         if (a.canting) {   // out_j = sum_k data_k B[k][j]  ->  g_data_k = sum_j g_out_j B[k][j]
 #pragma unroll
@@ -334,7 +346,7 @@ static bool fill_nurbs(NurbsArgs& a, const float* cp, const float* uv, int64_t u
     if (H < 0 || F <= 0 || M <= 0 || nu > 4096 || nv > 4096 || H * F > 2147483647LL || M > 2147483647LL) return false;
     if (uniform && (nuq_u < 2 || nuq_v < 2)) return false;
     a.cp = cp; a.uv = uv; a.uv_sh = uv_sh; a.uv_sf = uv_sf; a.knots_u = ku; a.knots_v = kv;
-    a.canting = canting; a.transl = transl; a.p = p; a.q = q; a.uniform = uniform;
+    a.canting = canting; a.transl = transl; a.orientation = nullptr; a.p = p; a.q = q; a.uniform = uniform;
     a.n_unique_u = (int)nuq_u; a.n_unique_v = (int)nuq_v;
     a.H = (int)H; a.F = (int)F; a.M = (int)M; a.nu = (int)nu; a.nv = (int)nv;
     a.n_mtiles = (int)((M + kNurbsBlock - 1) / kNurbsBlock);
@@ -369,7 +381,7 @@ extern "C" int art_nurbs_fwd(const float* control_points, const float* eval_poin
                              const float* knots_u, const float* knots_v, const float* canting,
                              const float* translations, int p, int q, int uniform, int64_t n_unique_u,
                              int64_t n_unique_v, int64_t H, int64_t F, int64_t M, int64_t nu, int64_t nv,
-                             float* points, float* normals, void* stream_)
+                             const float* orientation, float* points, float* normals, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     NurbsArgs a;
@@ -378,6 +390,7 @@ extern "C" int art_nurbs_fwd(const float* control_points, const float* eval_poin
         !fill_nurbs(a, control_points, eval_points, uv_sh, uv_sf, knots_u, knots_v, canting, translations, p, q,
                     uniform, n_unique_u, n_unique_v, H, F, M, nu, nv))
         return ART_EINVAL;
+    a.orientation = orientation;
     if (H == 0) return ART_OK;
     const size_t lds = nurbs_lds_bytes(a, false);
     if (lds > 64 * 1024) return ART_EUNSUPPORTED;
@@ -392,8 +405,8 @@ extern "C" int art_nurbs_fwd(const float* control_points, const float* eval_poin
 extern "C" int art_nurbs_bwd(const float* control_points, const float* eval_points, int64_t uv_sh, int64_t uv_sf,
                              const float* knots_u, const float* knots_v, const float* canting, int p, int q,
                              int uniform, int64_t n_unique_u, int64_t n_unique_v, int64_t H, int64_t F, int64_t M,
-                             int64_t nu, int64_t nv, const float* grad_points, const float* grad_normals,
-                             float* grad_control_points, void* stream_)
+                             int64_t nu, int64_t nv, const float* orientation, const float* grad_points,
+                             const float* grad_normals, float* grad_control_points, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     NurbsArgs a;
@@ -404,6 +417,7 @@ extern "C" int art_nurbs_bwd(const float* control_points, const float* eval_poin
                     canting ? dummy_transl : nullptr, p, q, uniform, n_unique_u, n_unique_v, H, F, M, nu, nv))
         return ART_EINVAL;
     a.transl = nullptr;   // unused by the backward
+    a.orientation = orientation;
     if (H == 0) return ART_OK;
     const size_t lds = nurbs_lds_bytes(a, true);
     if (lds > 64 * 1024) return ART_EUNSUPPORTED;

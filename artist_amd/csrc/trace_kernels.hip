@@ -526,7 +526,8 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
     ART_TIMELINE(2);
-    const unsigned twm1 = (unsigned)(win.tw - 1), uthm1 = (unsigned)(win.th - 1);
+    // (an empty window - no chief ray reaches the target - must hold no ray: bounds of 0, not of (unsigned)-1)
+    const unsigned twm1 = (unsigned)max(win.tw - 1, 0), uthm1 = (unsigned)max(win.th - 1, 0);
     const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     // lean mode needs I0 > 0 and I > 0 to be implied by `valid`: positive, sanely scaled intensity factors
@@ -538,7 +539,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
     const int pth = min(win.ths, win.u0 + win.th - pu0);                 // rows held in LDS in this pass
-    const unsigned thm1 = (unsigned)(pth - 1);
+    const unsigned thm1 = (unsigned)max(pth - 1, 0);
     const bool first = pass == 0;
     unsigned n_valid = 0, n_int = 0;     // rays with I0 > 0 / I > 0 among the valid ones (wave totals)
     unsigned n_free = 0;                 // rays with blocked < 1e-3 (heliostat_ray_tracer.py:501-503)
@@ -845,6 +846,8 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const bool first = pass == 0;
     const float pu0f = (float)pu0;
     const unsigned thm2_bits = f32_bits((float)(pth - 2));
+    // an empty window (no chief ray of the block reaches the target) holds no ray: every valid ray is then a stray
+    const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
     // largest byte address a ray of this pass can produce for its LOW row; rays outside the window are clamped into
     // [cell 0, that] and add zero there
     const float addr_hi_f = lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2));
@@ -907,7 +910,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             const float lef = tbe - e0f, luf = tbu - pu0f;                     // window coordinates of the low pixel
             // :178-184 on the bit patterns: 0 <= x <= hi  <=>  bits(x) <= bits(hi) unsigned (negative, NaN: larger)
             const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
-            const unsigned long long m_in = m_front & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
+            const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
             n_valid += __popcll(m_valid);
             const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
             const unsigned addr_lo = (unsigned)af;
@@ -940,7 +943,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             if (__builtin_expect(m_out != 0ull, 0)) {
                 if (!first) m_out = 0ull;
                 else if (win.npass > 1)                         // banded sweep: only what no band holds
-                    m_out &= ~(ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(tbu - u0f) <= uthm2_bits));
+                    m_out &= ~(win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(tbu - u0f) <= uthm2_bits));
                 if (m_out & m_parked) unpark();
                 pk_be = select_mask(m_out, be, pk_be); pk_bu = select_mask(m_out, bu, pk_bu); pk_ah = select_mask(m_out, ah, pk_ah);
                 m_parked |= m_out;
@@ -1330,7 +1333,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     float sx = 0.0f, sz = 0.0f;
     if constexpr (!CYL) { sx = pl.wm1 / pl.w; sz = pl.hm1 / pl.h; }
     const float Wf = (float)a.W, Hf = (float)a.Hh;
-    const unsigned twm1 = (unsigned)(win.tw - 1), thm1 = (unsigned)(pth - 1), uthm1 = (unsigned)(win.th - 1);
+    const unsigned twm1 = (unsigned)max(win.tw - 1, 0), thm1 = (unsigned)max(pth - 1, 0), uthm1 = (unsigned)max(win.th - 1, 0);
     const int dummy = a.tile_cap;                    // two spare cells holding 0
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
         const float4 o = org[p];
@@ -1644,6 +1647,8 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
 
     const float pu0f = (float)pu0;
     const unsigned thm2_bits = f32_bits((float)(pth - 2));
+    // an empty window (no chief ray of the block reaches the target) holds no ray: every valid ray is then a stray
+    const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
     const float addr_hi_f = lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2));
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
         const float4 o = org[p];
@@ -1676,7 +1681,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             const float cle = 1.0f - che, clu = 1.0f - chu;
             const float lef = tbe - e0f, luf = tbu - pu0f;
             const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
-            const unsigned long long m_in = m_front & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
+            const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
             const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
             const unsigned addr_lo = (unsigned)af;
             const lds_f32* lo = (const lds_f32*)(size_t)addr_lo;
@@ -1688,7 +1693,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 // valid, outside this pass's window: a stray of the union window gathers from global memory, once
                 const bool valid = (m_valid >> lane) & 1ull, inwin = (m_in >> lane) & 1ull;
                 const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
-                const bool in_union = f32_bits(lef) <= twm2_bits && f32_bits(tbu - u0f) <= uthm2_bits;
+                const bool in_union = win_ok != 0ull && f32_bits(lef) <= twm2_bits && f32_bits(tbu - u0f) <= uthm2_bits;
                 const bool stray = first && valid && !inwin && on && !in_union;
                 if (stray) {
                     const float* g_hi = G + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;

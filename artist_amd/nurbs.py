@@ -101,12 +101,21 @@ class NURBSSurfaces(torch.nn.Module):
 
     def calculate_surface_points_and_normals(self, evaluation_points: torch.Tensor, canting: torch.Tensor | None,
                                              facet_translations: torch.Tensor | None,
-                                             device: torch.device | None = None) -> tuple[torch.Tensor, torch.Tensor]:
-        """Surface points and unit normals ``[H,F,M,4]`` (artist/nurbs/surfaces.py:475-689)."""
+                                             device: torch.device | None = None,
+                                             orientations: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+        """Surface points and unit normals ``[H,F,M,4]`` (artist/nurbs/surfaces.py:475-689).
+
+        ``orientations`` (an addition to the reference signature): ``[H,4,4]`` alignment matrices applied in the same
+        kernel - ``points @ M^T``, ``normals @ M^T`` as in ``heliostat_group_rigid_body.py:217-222`` - for the epoch of
+        the surface reconstructor, which aligns right after evaluating (surface_reconstructor.py:516-546).  The result
+        equals evaluation + ``artist_amd.align_surfaces`` bit for bit; the matrices are constants to autograd (a
+        kinematics that learns passes through ``align_surfaces``)."""
         p, q = self._degrees_host
         nuq = self._unique_counts()
+        if orientations is not None and orientations.requires_grad:
+            raise ValueError("orientations that require grad go through artist_amd.align_surfaces, not the fused evaluation")
         return ops.NurbsEval.apply(self.control_points, evaluation_points, self.knot_vectors_u, self.knot_vectors_v,
-                                   canting, facet_translations, p, q, bool(self.uniform), nuq[0], nuq[1])
+                                   canting, facet_translations, p, q, bool(self.uniform), nuq[0], nuq[1], orientations)
 
     def forward(self, evaluation_points, canting, facet_translations, device=None):
         """Alias of :meth:`calculate_surface_points_and_normals` (artist/nurbs/surfaces.py:691-727)."""

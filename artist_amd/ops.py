@@ -285,7 +285,7 @@ class NurbsEval(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, control_points, eval_points, knots_u, knots_v, canting, translations, p, q, uniform,
-                n_unique_u, n_unique_v):
+                n_unique_u, n_unique_v, orientation=None):
         dev = _require_cuda(control_points, eval_points, knots_u, knots_v)
         cp = _f32c(control_points)
         H, F, nu, nv, three = cp.shape
@@ -303,22 +303,28 @@ class NurbsEval(torch.autograd.Function):
         tr = None if canting is None else _f32c(translations.reshape(H, F, 4))
         points = torch.empty((H, F, M, 4), dtype=torch.float32, device=dev)
         normals = torch.empty((H, F, M, 4), dtype=torch.float32, device=dev)
+        ori = None
+        if orientation is not None:      # fused alignment (a constant here: a learning kinematics takes align_surfaces)
+            ori = _f32c(orientation.detach())
+            if ori.shape != (H, 4, 4) or ori.device != dev:
+                raise ValueError("orientation must be [H,4,4] on the control points' device")
         with torch.cuda.device(dev):
             rc = _lib.lib().art_nurbs_fwd(
                 cp.data_ptr(), uv.data_ptr(), uv.stride(0), uv.stride(1), ku.data_ptr(), kv.data_ptr(),
                 None if cant is None else cant.data_ptr(), None if tr is None else tr.data_ptr(),
                 p, q, 1 if uniform else 0, n_unique_u, n_unique_v, H, F, M, nu, nv,
-                points.data_ptr(), normals.data_ptr(), _stream(dev))
+                None if ori is None else ori.data_ptr(), points.data_ptr(), normals.data_ptr(), _stream(dev))
         _lib.check(rc, "art_nurbs_fwd")
-        ctx.save_for_backward(cp, uv, ku, kv, cant if cant is not None else cp.new_empty(0))
-        ctx.meta = (p, q, bool(uniform), n_unique_u, n_unique_v, cant is not None)
+        ctx.save_for_backward(cp, uv, ku, kv, cant if cant is not None else cp.new_empty(0),
+                              ori if ori is not None else cp.new_empty(0))
+        ctx.meta = (p, q, bool(uniform), n_unique_u, n_unique_v, cant is not None, ori is not None)
         return points, normals
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_points, g_normals):
-        cp, uv, ku, kv, cant = ctx.saved_tensors
-        p, q, uniform, nuq_u, nuq_v, has_cant = ctx.meta
+        cp, uv, ku, kv, cant, ori = ctx.saved_tensors
+        p, q, uniform, nuq_u, nuq_v, has_cant, has_ori = ctx.meta
         dev = cp.device
         H, F, nu, nv, _ = cp.shape
         M = uv.shape[2]
@@ -328,19 +334,20 @@ class NurbsEval(torch.autograd.Function):
             rc = _lib.lib().art_nurbs_bwd(
                 cp.data_ptr(), uv.data_ptr(), uv.stride(0), uv.stride(1), ku.data_ptr(), kv.data_ptr(),
                 cant.data_ptr() if has_cant else None, p, q, 1 if uniform else 0, nuq_u, nuq_v, H, F, M, nu, nv,
-                g_points.data_ptr(), g_normals.data_ptr(), g_cp.data_ptr(), _stream(dev))
+                ori.data_ptr() if has_ori else None, g_points.data_ptr(), g_normals.data_ptr(), g_cp.data_ptr(),
+                _stream(dev))
         _lib.check(rc, "art_nurbs_bwd")
-        return (g_cp,) + (None,) * 10
+        return (g_cp,) + (None,) * 11
 
 
 def nurbs_surface_points_and_normals(control_points, eval_points, knots_u, knots_v, degrees, canting=None,
-                                     translations=None, uniform=True, n_unique=None):
+                                     translations=None, uniform=True, n_unique=None, orientation=None):
     p, q = int(degrees[0]), int(degrees[1])
     nu, nv = control_points.shape[2], control_points.shape[3]
     if n_unique is None:
         n_unique = (nu - p + 1, nv - q + 1)
     return NurbsEval.apply(control_points, eval_points, knots_u, knots_v, canting, translations, p, q,
-                           bool(uniform), int(n_unique[0]), int(n_unique[1]))
+                           bool(uniform), int(n_unique[0]), int(n_unique[1]), orientation)
 
 
 class AlignSurfaces(torch.autograd.Function):

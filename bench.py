@@ -234,10 +234,11 @@ def main():
     target = None
 
     def forward():
-        pts, nrm = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl)
-        ap, an = ops.align_surfaces(pts.reshape(H, P, 4), nrm.reshape(H, P, 4), orientation)
-        flux, factors = ops.trace_rays(ap, an, inc, dist_u, dist_e, tix, planar.centers, planar.normals,
-                                       planar.dimensions, 1.0, 0.0, 0.935, (256, 256))
+        # evaluation + alignment in one kernel (the kinematics is fixed during a surface reconstruction)
+        ap, an = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl,
+                                                                                             orientations=orientation)
+        flux, factors = ops.trace_rays(ap.reshape(H, P, 4), an.reshape(H, P, 4), inc, dist_u, dist_e, tix, planar.centers,
+                                       planar.normals, planar.dimensions, 1.0, 0.0, 0.935, (256, 256))
         return flux, factors
 
     def step(backward=True):

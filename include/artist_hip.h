@@ -187,19 +187,25 @@ int art_per_target_sum(const float *bitmaps, const int32_t *target_idx, int64_t 
  *   uniform != 0: span = floor(x*(n_unique-1)) + degree (surfaces.py:198-207), else the
  *   linear search of :209-243;  canting [H,F,2,4] or NULL; translations [H,F,4] (used only
  *   with canting);  outputs points, normals [H,F,M,4].   Degrees 1..7.
+ *   orientation [H,4,4] or NULL: when given, the alignment of art_align_fwd (points @ M^T, normals @ M^T,
+ *   artist/field/heliostat_group_rigid_body.py:217-222) is applied in the kernel's epilogue - what
+ *   SurfaceReconstructor's epoch does right after the evaluation (surface_reconstructor.py:516-546) - with the same
+ *   arithmetic, so the outputs equal art_nurbs_fwd + art_align_fwd bit for bit without the [H,P,4] x 2 round trip.
  * ------------------------------------------------------------------------------------------- */
 int art_nurbs_fwd(const float *control_points, const float *eval_points, int64_t uv_sh, int64_t uv_sf,
                   const float *knots_u, const float *knots_v, const float *canting, const float *translations,
                   int p, int q, int uniform, int64_t n_unique_u, int64_t n_unique_v,
                   int64_t H, int64_t F, int64_t M, int64_t nu, int64_t nv,
-                  float *points, float *normals, void *stream);
+                  const float *orientation, float *points, float *normals, void *stream);
 
 /* art_nurbs_bwd - autograd of art_nurbs_fwd w.r.t. the control points.
- *   grad_points, grad_normals [H,F,M,4] -> grad_control_points [H,F,nu,nv,3] (fully written). */
+ *   grad_points, grad_normals [H,F,M,4] -> grad_control_points [H,F,nu,nv,3] (fully written);
+ *   orientation as in the forward call (the gradients are then those of the ALIGNED points / normals; the
+ *   orientation itself gets no gradient through this entry point: use art_align_bwd when the kinematics learns). */
 int art_nurbs_bwd(const float *control_points, const float *eval_points, int64_t uv_sh, int64_t uv_sf,
                   const float *knots_u, const float *knots_v, const float *canting,
                   int p, int q, int uniform, int64_t n_unique_u, int64_t n_unique_v,
-                  int64_t H, int64_t F, int64_t M, int64_t nu, int64_t nv,
+                  int64_t H, int64_t F, int64_t M, int64_t nu, int64_t nv, const float *orientation,
                   const float *grad_points, const float *grad_normals, float *grad_control_points, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -141,6 +141,31 @@ def test_nurbs_forward_backward(golden, name):
         assert rel_l2(n(cp.grad), d["grad_control_points"]) < 2e-5
 
 
+@pytest.mark.parametrize("name", STAGE_CASES)
+def test_nurbs_with_fused_alignment(golden, name):
+    """``calculate_surface_points_and_normals(..., orientations=M)`` = evaluation + ``align_surfaces`` in one kernel:
+    the same bits forward, the same control-point gradients (surfaces.py:475-689 + heliostat_group_rigid_body.py:217-222)."""
+    from artist_amd import NURBSSurfaces, align_surfaces
+    d = golden(name)
+    ori = t(d["orientation"])
+    H = ori.shape[0]
+    args = (t(d["eval_points"]), t(d["canting"]), t(d["facet_translations"]))
+    cp_a = t(d["control_points"]).requires_grad_(True)
+    pts, nrm = NURBSSurfaces(torch.from_numpy(d["degrees"]), cp_a, device=DEV)(*args)
+    ap, an = align_surfaces(pts.reshape(H, -1, 4), nrm.reshape(H, -1, 4), ori)
+    cp_b = t(d["control_points"]).requires_grad_(True)
+    fp, fn = NURBSSurfaces(torch.from_numpy(d["degrees"]), cp_b, device=DEV).calculate_surface_points_and_normals(
+        *args, orientations=ori)
+    np.testing.assert_array_equal(n(fp.reshape(H, -1, 4)), n(ap))
+    np.testing.assert_array_equal(n(fn.reshape(H, -1, 4)), n(an))
+    np.testing.assert_allclose(n(ap), d["aligned_points"], rtol=0, atol=2e-5)          # the reference's aligned surface
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    wp, wn = torch.rand(ap.shape, generator=gen, device=DEV), torch.rand(an.shape, generator=gen, device=DEV)
+    ((ap * wp).sum() + (an * wn).sum()).backward()
+    ((fp.reshape(H, -1, 4) * wp).sum() + (fn.reshape(H, -1, 4) * wn).sum()).backward()
+    assert rel_l2(n(cp_b.grad), n(cp_a.grad)) < 1e-6          # (fp64 LDS sums in a different order: a last-bit difference)
+
+
 def test_nurbs_broadcast_grid_and_no_canting(golden):
     """Expanded (stride-0) evaluation grid, canting=None branch (surfaces.py:689), mixed degrees (generic kernel)."""
     from artist_amd import NURBSSurfaces
@@ -449,6 +474,41 @@ def test_ragged_shapes(H, R, P, W, Hh):
                               tix.numpy(), c.numpy(), pn.numpy(), dims.numpy(), res, n(w), 0.7, 0.05, 0.9)
     if np.linalg.norm(go) > 0:
         assert rel_l2(n(od.grad), go) < 5e-3 and rel_l2(n(nd.grad), gn) < 5e-3   # cell flips at pixel borders
+
+
+def test_chief_rays_miss_but_scattered_rays_hit():
+    """A heliostat aimed just beside the target: no chief ray reaches it (the workgroup's window is EMPTY), but the sun
+    shape scatters part of the rays onto the edge.  Those rays must all be handled as strays - forward (accumulators)
+    and backward (gathers) - and none may touch the never-staged LDS window (this case produced NaN gradients once)."""
+    from artist_amd import trace_rays
+    H, R, P, res = 2, 48, 700, (64, 48)
+    g = torch.Generator().manual_seed(9)
+    origins = torch.cat([torch.rand(H, P, 3, generator=g) * 2 - 1 + torch.tensor([0.0, 50.0, 0.0]), torch.ones(H, P, 1)], -1)
+    centers = torch.tensor([[0.0, 0.0, 30.0, 1.0]])
+    dims = torch.tensor([[4.0, 3.0]])
+    pn = torch.tensor([[0.0, 1.0, 0.0, 0.0]])
+    aim = torch.tensor([[2.25, 0.0, 30.0], [0.0, 0.0, 31.7]])            # 0.25 m right of / 0.2 m above the plane's edge
+    to_aim = torch.nn.functional.normalize(aim[:, None, :] - origins[..., :3], dim=-1)
+    nrm = torch.nn.functional.normalize(to_aim - torch.tensor([0.0, 1.0, 0.0]), dim=-1)
+    normals = torch.cat([nrm, torch.zeros(H, P, 1)], -1)
+    incident = torch.tensor([[0.0, 1.0, 0.0, 0.0]]).repeat(H, 1)
+    both = 3e-3 * torch.randn(H, R, P, 2, generator=g)                     # sigma 0.17 m on the target
+    tix = torch.zeros(H, dtype=torch.long)
+    bd = both.to(DEV)
+    od, nd = origins.to(DEV).requires_grad_(True), normals.to(DEV).requires_grad_(True)
+    flux, fac = trace_rays(od, nd, incident.to(DEV), bd[..., 0], bd[..., 1], tix.to(DEV), centers.to(DEV), pn.to(DEV), dims.to(DEV),
+                           resolution=res)
+    args = (origins.numpy(), normals.numpy(), incident.numpy(), both[..., 0].numpy(), both[..., 1].numpy(), tix.numpy(),
+            centers.numpy(), pn.numpy(), dims.numpy(), res)
+    o_flux, o_fac = oracle.trace_fwd(*args)
+    assert 0.02 < float(fac[0].min()) and float(fac[0].max()) < 0.5       # some rays hit, most miss
+    np.testing.assert_array_equal(n(fac), o_fac)
+    assert rel_l2(n(flux), o_flux) < 1e-5
+    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    (flux * w).sum().backward()
+    go, gn = oracle.trace_bwd(*args, n(w))
+    assert bool(torch.isfinite(od.grad).all()) and bool(torch.isfinite(nd.grad).all())
+    assert rel_l2(n(od.grad), go) < 2e-4 and rel_l2(n(nd.grad), gn) < 2e-4
 
 
 def test_empty_field_and_all_rays_missing():
