@@ -45,8 +45,6 @@ struct TraceArgs {
     int reverse_bwd;          // backward queue order (experiment knob; the list order measured best)
     int reverse_items;        // forward queue order: 0 first-to-last, 1 last-to-first, -1 decided on the device (the end
                               // of the list whose heliostat is farther from its target goes first)
-    int n_tail;               // windowed kernels: the LAST n_tail (heliostat, point block, sample chunk) items are
-                              // handed out as two half-chunks each (a short tail for the persistent workgroups)
     int n_ptiles;             // ceil(P / kBlock)
     int p_block;              // points per workgroup (LDS-window kernel)
     int n_pblocks;            // ceil(P / p_block)

@@ -26,8 +26,20 @@
 
 namespace art {
 
+// round-half-up float -> int32 in one instruction (floor(x + 0.5)); 0 <= x < 2^22 by construction.
+__device__ __forceinline__ unsigned cvt_nearest_u32(float x)
+{
+    int q;
+    asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(q) : "v"(x));
+    return (unsigned)q;
+}
+
+// A contribution that bypasses the window (a stray ray): |v| in accumulator units, rounded to nearest.
+__device__ __forceinline__ unsigned long long to_accum(float v, float scale_g) { return (unsigned long long)cvt_nearest_u32(fabsf(v) * scale_g); }
+
 // --------------------------------------------------------------------------------------------
-// Forward, global-atomic splat.
+// Forward, global-atomic splat (ARTIST_HIP_FWD=global: the plain formulation, kept as an independent cross-check of the
+// windowed kernels; same integer accumulators, so also bit-reproducible).
 // grid.x = H * n_rchunks * n_ptiles ; block = 256.
 // counts: uint32 [2,H] (aliases rows 0,1 of the factors output until finalize_factors runs).
 // --------------------------------------------------------------------------------------------
@@ -45,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
     const int t = a.target_idx[h];
     if (!target_in_range(a, t) || t >= a.T) return;   // planar receivers only (host refuses cylinders for this variant)
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
-    float* __restrict__ bitmap = flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
+    unsigned long long* __restrict__ bitmap = a.accum + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;   // integer accumulators
 
     unsigned n_on = 0, n_int = 0;
     if (active) {
@@ -72,12 +84,12 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
             const Splat sp = splat_weights(hit.be, hit.bu, a.W, a.Hh);
             if (sp.on) {
                 // flat row k is output row Hh-1-k (flip, heliostat_ray_tracer.py:778)
-                float* row_hi = bitmap + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;   // flat row iu+1
-                float* row_lo = row_hi + a.W;                                          // flat row iu
-                atomicAdd(row_hi, sp.cle * sp.chu * I);        // pixel 1
-                atomicAdd(row_hi + 1, sp.che * sp.chu * I);    // pixel 2
-                atomicAdd(row_lo + 1, sp.che * sp.clu * I);    // pixel 3
-                atomicAdd(row_lo, sp.cle * sp.clu * I);        // pixel 4
+                unsigned long long* row_hi = bitmap + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;   // flat row iu+1
+                unsigned long long* row_lo = row_hi + a.W;                                          // flat row iu
+                atomicAdd(row_hi, to_accum(sp.cle * sp.chu * I, a.scale_g));        // pixel 1
+                atomicAdd(row_hi + 1, to_accum(sp.che * sp.chu * I, a.scale_g));    // pixel 2
+                atomicAdd(row_lo + 1, to_accum(sp.che * sp.clu * I, a.scale_g));    // pixel 3
+                atomicAdd(row_lo, to_accum(sp.cle * sp.clu * I, a.scale_g));        // pixel 4
             }
         }
     }
@@ -185,14 +197,6 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return v;
 }
 
-// round-half-up float -> int32 in one instruction (floor(x + 0.5)); 0 <= x < 2^22 by construction.
-__device__ __forceinline__ unsigned cvt_nearest_u32(float x)
-{
-    int q;
-    asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(q) : "v"(x));
-    return (unsigned)q;
-}
-
 // q = round(|v| S) as an unsigned fixed-point increment.
 __device__ __forceinline__ unsigned to_fixed(float v, float scale) { return cvt_nearest_u32(fabsf(v) * scale); }
 
@@ -221,9 +225,6 @@ __device__ __forceinline__ void resolve_carries(const PendingSplat& ps, unsigned
         if (c4) atomicAdd(row_lo, carry);
     }
 }
-
-// A contribution that bypasses the window (a stray ray): |v| in accumulator units, rounded to nearest.
-__device__ __forceinline__ unsigned long long to_accum(float v, float scale_g) { return (unsigned long long)cvt_nearest_u32(fabsf(v) * scale_g); }
 
 // Phase 1 of the windowed kernels: bounding box (in un-flipped bitmap coordinates) of where the
 // workgroup's rays can land, clipped to `tile_cap` pixels, plus the fixed-point scale of the forward
@@ -417,11 +418,10 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
 // PERSISTENT workgroup per CU that pulls (heliostat, point block, sample chunk) items from a counter in global memory:
 //   * no dispatcher between two items (measured with tools/timeline.sh: 5 us mean, 30 % of the hand-overs > 5 us),
 //   * the eight XCDs share one queue (the hardware deals every eighth workgroup to an XCD, whatever their length),
-//   * optionally (ARTIST_HIP_TAIL=1) the last n_tail items are dealt as two halves of their sample range, so that the
-//     kernel ends within half an item; neutral on the metric field, off by default.
-// Item numbering: [0, n_base - n_tail) whole items, then 2 n_tail halves.
-struct WorkItem { int h, pblock, rchunk, r0, r1; bool half; };   // half: one of the two halves of a tail item
-__device__ __forceinline__ int work_item_count(const TraceArgs& a) { return a.H * a.n_pblocks * a.n_rchunks + a.n_tail; }
+//     (Dealing the last items as two halves of their sample range, so that the kernel ends within half an item, measured
+//     neutral at 1000 and 125 heliostats in round 1 and needed float atomics in the backward kernel: removed.)
+struct WorkItem { int h, pblock, rchunk, r0, r1; };
+__device__ __forceinline__ int work_item_count(const TraceArgs& a) { return a.H * a.n_pblocks * a.n_rchunks; }
 // Longest items first: an item's cost grows with the distance between heliostat and target (wider image, more rays
 // beyond the window: 83 -> 115 us from the nearest to the farthest tenth of the metric field), and a queue that ends
 // with the long items ends with idle CUs.  Fields are usually listed row by row, so the cheap test is which END of the
@@ -443,10 +443,8 @@ __device__ __forceinline__ bool farther_end_is_last(const TraceArgs& a)
 
 __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int item, bool reverse = false)
 {
-    const int n_whole = a.H * a.n_pblocks * a.n_rchunks - a.n_tail;
     if (reverse) item = work_item_count(a) - 1 - item;
-    int base = item, half = -1;
-    if (item >= n_whole) { base = n_whole + ((item - n_whole) >> 1); half = (item - n_whole) & 1; }
+    const int base = item;
     WorkItem w;
     const int rchunk = base % a.n_rchunks;
     w.pblock = (base / a.n_rchunks) % a.n_pblocks;
@@ -454,11 +452,6 @@ __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int ite
     w.rchunk = rchunk;
     w.r0 = rchunk * a.r_chunk;
     w.r1 = min(w.r0 + a.r_chunk, a.R);
-    w.half = half >= 0;
-    if (half >= 0) {
-        const int mid = min(w.r0 + (((w.r1 - w.r0) / 2 + 3) & ~3), w.r1);      // whole groups of four samples first
-        if (half == 0) w.r1 = mid; else w.r0 = mid;
-    }
     return w;
 }
 
@@ -1098,10 +1091,10 @@ __global__ void finalize_factors_kernel(float* factors, int H, float rays_per_he
 }
 
 // --------------------------------------------------------------------------------------------
-// Backward: thread owns a point, accumulates dL/dd and dL/do over its samples in registers.
-// ATOMIC_OUT: several sample-chunks per point -> atomicAdd into (pre-zeroed) outputs.
+// Backward of the plain formulation (ARTIST_HIP_FWD=global): thread owns a point and ALL its samples, accumulates dL/dd and
+// dL/do in registers, plain stores.
 // --------------------------------------------------------------------------------------------
-template <bool INTERLEAVED, bool ATOMIC_OUT>
+template <bool INTERLEAVED>
 __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                            float4* __restrict__ grad_origins,
                                                            float4* __restrict__ grad_normals)
@@ -1172,15 +1165,8 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
     float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                             -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
     const int64_t idx = (int64_t)h * a.P + p;
-    if constexpr (ATOMIC_OUT) {
-        float* po = reinterpret_cast<float*>(grad_origins + idx);
-        float* pn = reinterpret_cast<float*>(grad_normals + idx);
-        atomicAdd(po + 0, go.x); atomicAdd(po + 1, go.y); atomicAdd(po + 2, go.z);
-        atomicAdd(pn + 0, gn.x); atomicAdd(pn + 1, gn.y); atomicAdd(pn + 2, gn.z); atomicAdd(pn + 3, gn.w);
-    } else {
-        grad_origins[idx] = go;
-        grad_normals[idx] = gn;
-    }
+    grad_origins[idx] = go;
+    grad_normals[idx] = gn;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1243,9 +1229,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     // ATOMIC_OUT (a name from round 1): the samples of a point are split over several items.  Each sample chunk then
     // writes its partial gradients with plain stores to a slab of its own - `grad_origins` / `grad_normals` point at
     // [n_rchunks,H,P] scratch arrays - and reduce_chunks_kernel adds the slabs in chunk order: bit-reproducible, where
-    // float atomics onto one row were not.  (The two halves of a tail item - an experiment knob, never combined with
-    // chunking - still add with atomics to rows the host has zeroed.)
-    const bool atomic_item = !ATOMIC_OUT && item.half;
+    // float atomics onto one row were not.
     if constexpr (ATOMIC_OUT) {
         grad_origins += (int64_t)item.rchunk * a.H * a.P;
         grad_normals += (int64_t)item.rchunk * a.H * a.P;
@@ -1514,12 +1498,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
         const int64_t idx = (int64_t)h * a.P + p;
-        if (atomic_item) {
-            float* po = reinterpret_cast<float*>(grad_origins + idx);
-            float* pn = reinterpret_cast<float*>(grad_normals + idx);
-            atomicAdd(po + 0, go.x); atomicAdd(po + 1, go.y); atomicAdd(po + 2, go.z);
-            atomicAdd(pn + 0, gn.x); atomicAdd(pn + 1, gn.y); atomicAdd(pn + 2, gn.z); atomicAdd(pn + 3, gn.w);
-        } else if (first) {
+        if (first) {
             grad_origins[idx] = go;
             grad_normals[idx] = gn;
         } else {                                      // this thread owns the point in every pass: plain add
@@ -1575,7 +1554,6 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const int pblock = item.pblock;
     const int h = item.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const bool atomic_item = !ATOMIC_OUT && item.half;
     if constexpr (ATOMIC_OUT) {                      // chunk slabs: see trace_bwd_item
         grad_origins += (int64_t)item.rchunk * a.H * a.P;
         grad_normals += (int64_t)item.rchunk * a.H * a.P;
@@ -1770,12 +1748,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
         const int64_t idx = (int64_t)h * a.P + p;
-        if (atomic_item) {
-            float* po = reinterpret_cast<float*>(grad_origins + idx);
-            float* pn = reinterpret_cast<float*>(grad_normals + idx);
-            atomicAdd(po + 0, go.x); atomicAdd(po + 1, go.y); atomicAdd(po + 2, go.z);
-            atomicAdd(pn + 0, gn.x); atomicAdd(pn + 1, gn.y); atomicAdd(pn + 2, gn.z); atomicAdd(pn + 3, gn.w);
-        } else if (first) {
+        if (first) {
             grad_origins[idx] = go;
             grad_normals[idx] = gn;
         } else {
@@ -2076,12 +2049,8 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     if (chunk > a.R) chunk = a.R;
     a.r_chunk = chunk;
     a.n_rchunks = (a.R + chunk - 1) / chunk;
-    // the last items of the queue are dealt in halves (decode_work_item) when a chunk has samples to split
-    const int64_t n_base = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
     a.reverse_bwd = env_int("ARTIST_HIP_BWD_REVERSE", 0);
     a.reverse_items = env_int("ARTIST_HIP_REVERSE", -1);       // -1: decided on the device (farther_end_is_last)
-    // (measured neutral on the metric field - 1000 and 125 heliostats - so it is off unless ARTIST_HIP_TAIL=1)
-    a.n_tail = chunk >= 8 && env_int("ARTIST_HIP_TAIL", 0) != 0 ? (int)std::min<int64_t>(n_base, resident_workgroups()) : 0;
 }
 
 }  // namespace art
@@ -2127,17 +2096,17 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
     FwdConfig cfg = fwd_config();
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
+    if (accum == nullptr || (reinterpret_cast<uintptr_t>(accum) % 16) != 0) return ART_EINVAL;
+    // unit of the pixel accumulators: 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|
+    {
+        const float kI = (a.mag * a.k_ext) * a.k_refl;
+        int ex = 0;
+        if (kI != 0.0f && fabsf(kI) < 3.0e38f) (void)frexpf(fabsf(kI) * 1.001f, &ex);
+        a.ex_g = std::min(std::max(ex, -80), 80);
+        a.scale_g = ldexpf(1.0f, 28 - a.ex_g);
+        a.accum = reinterpret_cast<unsigned long long*>(accum);
+    }
     if (cfg.variant == 0) {
-        if (accum == nullptr || (reinterpret_cast<uintptr_t>(accum) % 16) != 0) return ART_EINVAL;
-        // unit of the pixel accumulators: 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|
-        {
-            const float kI = (a.mag * a.k_ext) * a.k_refl;
-            int ex = 0;
-            if (kI != 0.0f && fabsf(kI) < 3.0e38f) (void)frexpf(fabsf(kI) * 1.001f, &ex);
-            a.ex_g = std::min(std::max(ex, -80), 80);
-            a.scale_g = ldexpf(1.0f, 28 - a.ex_g);
-            a.accum = reinterpret_cast<unsigned long long*>(accum);
-        }
         // the lean ray body (trace_fwd_item_lean): planar receivers, no blocking, positive and sanely scaled intensity
         // factors - then a valid ray is known to carry intensity and one counter serves both factors
         const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
@@ -2148,7 +2117,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             if (!cfg.p_block_fixed) cfg.p_block = kLeanFwdThreads;
         }
         window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
-        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
+        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
 #ifdef ART_FWD_SINGLE_ITEM
@@ -2187,16 +2156,8 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
 #undef ART_LAUNCH_FWD_TYPE
 #undef ART_LAUNCH_FWD
         ART_HIP(hipGetLastError());
-        {   // accumulators -> fp32 bitmaps (every pixel is written: no memset of `flux`); accumulators back to zero
-            const int64_t npix = n_maps * Hh * W;
-            const float kI = (a.mag * a.k_ext) * a.k_refl;
-            const float sign_unit = (kI < 0.0f ? -1.0f : 1.0f) * ldexpf(1.0f, a.ex_g - 28);
-            hipLaunchKernelGGL(accum_to_flux_kernel, dim3((unsigned)((npix / 2 + 1 + 255) / 256)), dim3(256), 0, stream, a.accum, flux, npix,
-                               sign_unit);
-        }
     } else {
         if (Tc > 0 || blocking) return ART_EUNSUPPORTED;   // the global-atomic A/B variant: planar, no blocking
-        ART_HIP(hipMemsetAsync(flux, 0, sizeof(float) * n_maps * Hh * W, stream));
         choose_chunks(a, 4096, 8);
         const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
         if (blocks > 2147483647LL) return ART_EINVAL;
@@ -2206,12 +2167,19 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             hipLaunchKernelGGL(trace_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, flux, counts);
     }
     ART_HIP(hipGetLastError());
+    {   // accumulators -> fp32 bitmaps (every pixel is written: no memset of `flux`); accumulators back to zero
+        const int64_t npix = n_maps * Hh * W;
+        const float kI = (a.mag * a.k_ext) * a.k_refl;
+        const float sign_unit = (kI < 0.0f ? -1.0f : 1.0f) * ldexpf(1.0f, a.ex_g - 28);
+        hipLaunchKernelGGL(accum_to_flux_kernel, dim3((unsigned)((npix / 2 + 1 + 255) / 256)), dim3(256), 0, stream, a.accum, flux, npix,
+                           sign_unit);
+    }
     hipLaunchKernelGGL(finalize_factors_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, factors,
                        (int)H, (float)(R * P), blocking ? 1 : 0);
     ART_HIP(hipGetLastError());
 #ifdef ART_DEBUG_TIMELINE
     if (const char* out = getenv("ART_TIMELINE_OUT")) {     // the last call's records: [blocks][8] u64, raw
-        const int64_t n = std::min<int64_t>((int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail, kTimelineSlots);
+        const int64_t n = std::min<int64_t>((int64_t)a.H * a.n_pblocks * a.n_rchunks, kTimelineSlots);
         std::vector<unsigned long long> host(8 * n);
         ART_HIP(hipStreamSynchronize(stream));
         ART_HIP(hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * n));
@@ -2282,22 +2250,14 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             cfg.target_blocks = 1;
             window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         }
-        const bool atomic_out = a.n_rchunks > 1;
-        if (atomic_out) a.n_tail = 0;
-        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks + a.n_tail;
+        const bool atomic_out = a.n_rchunks > 1;      // (round 1's name: today the chunks write slabs, nothing is atomic)
+        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float);
         if (atomic_out) {
             go = reinterpret_cast<float4*>(grad_scratch);
             gn = go + (int64_t)a.n_rchunks * H * P;
-        } else if (a.n_tail > 0) {
-            // the tail items are dealt as two halves that ADD their gradients: zero the rows of their points - the
-            // suffix of the arrays that starts at the first tail item's (heliostat, point block)
-            const int64_t first_tail = (int64_t)a.H * a.n_pblocks - a.n_tail;
-            const int64_t start = (first_tail / a.n_pblocks) * P + (first_tail % a.n_pblocks) * a.p_block;
-            ART_HIP(hipMemsetAsync(grad_origins + 4 * start, 0, sizeof(float) * 4 * (H * P - start), stream));
-            ART_HIP(hipMemsetAsync(grad_normals + 4 * start, 0, sizeof(float) * 4 * (H * P - start), stream));
         }
 #define ART_LAUNCH_BWD(IL, AT, CY, BL, LN)                                                                       \
         do {                                                                                                     \
@@ -2348,18 +2308,11 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         return ART_OK;
     }
     if (Tc > 0 || blocking) return ART_EUNSUPPORTED;
-    choose_chunks(a, 2048, 16);
-    const int64_t blocks = (int64_t)a.H * a.n_rchunks * a.n_ptiles;
+    a.r_chunk = a.R; a.n_rchunks = 1;                       // a thread owns all samples of its point: no atomics
+    const int64_t blocks = (int64_t)a.H * a.n_ptiles;
     if (blocks > 2147483647LL) return ART_EINVAL;
-    if (a.n_rchunks > 1) {
-        ART_HIP(hipMemsetAsync(grad_origins, 0, sizeof(float) * 4 * H * P, stream));
-        ART_HIP(hipMemsetAsync(grad_normals, 0, sizeof(float) * 4 * H * P, stream));
-        if (il) hipLaunchKernelGGL((trace_bwd_kernel<true, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, grad_flux, go, gn);
-        else hipLaunchKernelGGL((trace_bwd_kernel<false, true>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, grad_flux, go, gn);
-    } else {
-        if (il) hipLaunchKernelGGL((trace_bwd_kernel<true, false>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, grad_flux, go, gn);
-        else hipLaunchKernelGGL((trace_bwd_kernel<false, false>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, grad_flux, go, gn);
-    }
+    if (il) hipLaunchKernelGGL(trace_bwd_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, grad_flux, go, gn);
+    else hipLaunchKernelGGL(trace_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, grad_flux, go, gn);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

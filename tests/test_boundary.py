@@ -72,3 +72,47 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libartist_hip.so")
     with pytest.raises(_lib.ArtistHipError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_no_float_atomics_in_the_planar_trace_kernels(tmp_path):
+    """Determinism by construction: the device code of libartist_hip.so holds no `global_atomic_add_f32`
+    in any trace kernel that serves planar receivers without blocking - flux goes through 64-bit integer accumulators,
+    gradients through plain stores and chunk slabs.  (The blocking instantiations still flush the rectangle gradients with
+    one float atomic per workgroup and component; the cylinder instantiations share the planar code paths.)"""
+    import shutil
+    import subprocess
+    llvm = pathlib.Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "llvm-objdump").exists() or not (llvm / "clang-offload-bundler").exists():
+        pytest.skip("ROCm LLVM tools not installed")
+    lib = ROOT / "artist_amd" / "libartist_hip.so"
+    fat = tmp_path / "fat.bin"
+    subprocess.run([str(llvm / "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", str(lib), str(tmp_path / "stripped.so")], check=True)
+    blob = fat.read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    assert starts, "no offload bundles in the library"
+    per_kernel, seen_trace = {}, False
+    for k, start in enumerate(starts):
+        part = tmp_path / f"bundle{k}.bin"
+        part.write_bytes(blob[start: starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        code = tmp_path / f"code{k}.co"
+        subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={part}", f"--output={code}"], check=True)
+        if not code.exists() or code.stat().st_size == 0:
+            continue
+        text = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(code)], check=True, capture_output=True, text=True).stdout
+        current = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+            if m:
+                current = m.group(1)
+                seen_trace |= "trace_fwd_lds_kernel" in current
+            elif "global_atomic_add_f32" in line and current:
+                per_kernel[current] = per_kernel.get(current, 0) + 1
+    assert seen_trace, "trace kernels not found in the device code"
+    # template arguments: trace_fwd_lds_kernel<IL, CYL, BLOCKING, LEAN>, trace_bwd_lds_kernel<IL, SLABS, CYL, BLOCKING, LEAN>
+    def blocking(name):
+        m = re.search(r"trace_fwd_lds_kernelILb\dELb\dELb(\d)", name) or re.search(r"trace_bwd_lds_kernelILb\dELb\dELb\dELb(\d)", name)
+        return bool(m) and m.group(1) == "1"
+    offenders = {k: v for k, v in per_kernel.items() if "trace_" in k and not blocking(k)}
+    assert not offenders, offenders

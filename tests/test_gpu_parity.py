@@ -473,7 +473,9 @@ def test_ragged_shapes(H, R, P, W, Hh):
     go, gn = oracle.trace_bwd(o.numpy(), nrm.numpy(), inc.numpy(), both[..., 0].numpy(), both[..., 1].numpy(),
                               tix.numpy(), c.numpy(), pn.numpy(), dims.numpy(), res, n(w), 0.7, 0.05, 0.9)
     if np.linalg.norm(go) > 0:
-        assert rel_l2(n(od.grad), go) < 5e-3 and rel_l2(n(nd.grad), gn) < 5e-3   # cell flips at pixel borders
+        # measured 1e-7 ... 1.1e-6: the forward is recomputed op for op, only the gradient arithmetic (FMAs, v_rcp) differs.
+        # (For scale: the fp32 oracle is 1e-5 ... 1.7e-2 from the fp64 oracle on these scenes - cell flips at pixel borders.)
+        assert rel_l2(n(od.grad), go) < 1e-5 and rel_l2(n(nd.grad), gn) < 1e-5, (rel_l2(n(od.grad), go), rel_l2(n(nd.grad), gn))
 
 
 def test_chief_rays_miss_but_scattered_rays_hit():
@@ -1175,7 +1177,7 @@ def test_random_scenes_all_features(seed, H, P, R, res, interleaved, lbvh_compat
     o_flux, o_fac, dbg = oracle.trace_fwd(*oracle_args, 0.7, 0.05, 0.9, debug=True, **okw)
     np.testing.assert_array_equal(np.nonzero(n(flags))[0], np.nonzero(dbg["filter_flags"])[0])
     assert o_flux.sum() > 0 and (dbg["blocked"] > 0.5).any() == bool((n(fac[2]) < 1).any())
-    assert rel_l2(n(flux), o_flux) < 5e-4, rel_l2(n(flux), o_flux)
+    assert rel_l2(n(flux), o_flux) < 1e-5, rel_l2(n(flux), o_flux)           # measured 1e-6 ... 1.8e-6
     np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=3.0 / (R * P))
     # fused per-target mode on the same scene
     flux_t, _, _ = trace_rays(*args, per_target=True, **kw)
@@ -1185,10 +1187,11 @@ def test_random_scenes_all_features(seed, H, P, R, res, interleaved, lbvh_compat
     w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(seed)).to(DEV)
     (flux * w).sum().backward()
     go, gn, gpc, gps, gpn = oracle.trace_bwd(*oracle_args, f32(w), 0.7, 0.05, 0.9, **okw)
-    assert rel_l2(n(o.grad), go) < 3e-3, rel_l2(n(o.grad), go)
-    assert rel_l2(n(nn_.grad), gn) < 3e-3, rel_l2(n(nn_.grad), gn)
+    # measured 3e-7 ... 3.4e-6 (corners 1e-7 ... 1.7e-6); the fp32 oracle itself is 4e-5 ... 1.7e-2 from the fp64 oracle here
+    assert rel_l2(n(o.grad), go) < 2e-5, rel_l2(n(o.grad), go)
+    assert rel_l2(n(nn_.grad), gn) < 2e-5, rel_l2(n(nn_.grad), gn)
     if np.linalg.norm(gpc) > 0:
-        assert rel_l2(n(prims["corners"].grad), gpc) < 3e-3, rel_l2(n(prims["corners"].grad), gpc)
+        assert rel_l2(n(prims["corners"].grad), gpc) < 2e-5, rel_l2(n(prims["corners"].grad), gpc)
 
 
 @pytest.mark.parametrize("res", [(700, 40), (40, 700), (2, 2), (3, 1500)])
@@ -1450,8 +1453,12 @@ def test_scenario_file_to_flux(golden, name):
     np.testing.assert_array_equal(n(aim), d["aim_points"])
     group.align_surfaces_with_incident_ray_directions(aim_points=aim, incident_ray_directions=incident,
                                                       active_heliostats_mask=mask, device=DEV)
-    np.testing.assert_allclose(n(group.active_surface_points), d["aligned_points"], rtol=0, atol=3e-4)
-    np.testing.assert_allclose(n(group.active_surface_normals), d["aligned_normals"], rtol=0, atol=1e-4)
+    # yardstick: the reference's own fp32 run against its fp64 run of the same file (fp32 `acos` in the actuator law moves the
+    # mirror by up to 3e-5 m); the HIP chain has to be as close to the fp64 truth as the reference's fp32 chain is (x2)
+    d64 = golden(name + "_f64")
+    for got, key, floor in ((group.active_surface_points, "aligned_points", 1e-6), (group.active_surface_normals, "aligned_normals", 3e-7)):
+        yard = float(np.abs(d[key] - d64[key]).max())
+        assert float(np.abs(n(got) - d64[key]).max()) <= 2.0 * yard + floor, (key, float(np.abs(n(got) - d64[key]).max()), yard)
     scenario.set_number_of_rays(number_of_rays=run["rays"])
     tracer = HeliostatRayTracer(scenario=scenario, heliostat_group=group, blocking_active=run["blocking"], batch_size=100,
                                 bitmap_resolution=torch.tensor(run["resolution"]))
@@ -1460,22 +1467,25 @@ def test_scenario_file_to_flux(golden, name):
     tracer.distortions_dataset.distortions_u, tracer.distortions_dataset.distortions_e = interleave(d["distortions_u"], d["distortions_e"])
     flux, intercept, on_target, unblocked = tracer.trace_rays(incident_ray_directions=incident, active_heliostats_mask=mask,
                                                               target_area_indices=target_idx, device=DEV)
-    # fp32 kinematics move the image by a few mm (2e-5 rad x range, see test_real_scenario_end_to_end_kinematic_gradients)
-    assert rel_l2(n(flux), d["flux"]) < 3e-2, rel_l2(n(flux), d["flux"])
-    np.testing.assert_allclose(n(flux).sum((1, 2)), d["flux"].sum((1, 2)), rtol=2e-3)
+    # bitmaps: within 2x the reference's fp32-vs-fp64 distance (4.5e-5 ... 5.8e-4 on these files) of the fp64 run; energy to 1e-5;
+    # the ray-count factors within one ray of the reference's fp32 run
+    yard = rel_l2(d["flux"].astype(np.float64), d64["flux"])
+    assert rel_l2(n(flux), d64["flux"]) < 2.0 * yard, (rel_l2(n(flux), d64["flux"]), yard)
+    np.testing.assert_allclose(n(flux).sum((1, 2)), d64["flux"].sum((1, 2)), rtol=1e-5, atol=1e-5 * float(d64["flux"].sum((1, 2)).max()))
     rays = d["distortions_u"][0].size
     for got, key in ((intercept, "intercept"), (on_target, "on_target"), (unblocked, "blocking")):
-        np.testing.assert_allclose(n(got), d[key], rtol=0, atol=max(5e-3, 2.5 / rays))
+        np.testing.assert_allclose(n(got), d[key], rtol=0, atol=1.0 / rays + 1e-7)
     if run["blocking"]:
         np.testing.assert_array_equal(n(tracer.filtered_blocking_primitive_indices), d["filter_indices"])
 
 
-@pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_TAIL="1"), dict(ARTIST_HIP_PERSISTENT="0"), dict(ARTIST_HIP_PERSISTENT="0", ARTIST_HIP_TAIL="1")])
+@pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_PERSISTENT="0"), dict(ARTIST_HIP_LEAN="0"), dict(ARTIST_HIP_FWD_PBLOCK="512", ARTIST_HIP_BWD_PBLOCK="640"),
+                                   dict(ARTIST_HIP_FWD_BLOCKS="4096")])
 def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     """The windowed kernels hand out (heliostat, point block, sample chunk) items through a work queue: persistent
-    workgroups (default), one workgroup per item, and the tail items split into two halves (whose gradients are added
-    with atomics onto rows the host zeroes).  Every variant must produce the default's bitmaps (integer accumulation:
-    bit-exact but for the stray rays' float atomics) and gradients."""
+    workgroups (default) or one workgroup per item, the lean or the generic ray body, other point-block sizes, samples cut
+    into more chunks.  However the items are dealt, the bitmaps are the same BITS (integer pixel accumulators); the
+    gradients are the same bits as long as a point's samples are summed in the same order (everything but the chunking)."""
     from artist_amd import trace_rays
     d = golden("mid_256")
 
@@ -1494,14 +1504,19 @@ def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     other = run()
-    # the pixel accumulators are integers: however the items are dealt, the bitmaps are the same bits
-    np.testing.assert_array_equal(other[0], base[0])
+    if "ARTIST_HIP_LEAN" in knobs:                    # the generic body rounds the four weights in another order before it quantises them
+        assert rel_l2(other[0], base[0]) < 1e-6, rel_l2(other[0], base[0])
+    else:
+        np.testing.assert_array_equal(other[0], base[0])
     np.testing.assert_array_equal(other[1], base[1])
-    if "ARTIST_HIP_TAIL" in knobs:                    # halved tail items add their gradients with float atomics (experiment knob)
-        assert rel_l2(other[2], base[2]) < 1e-5 and rel_l2(other[3], base[3]) < 1e-5
+    if "ARTIST_HIP_FWD_BLOCKS" in knobs or "ARTIST_HIP_LEAN" in knobs:   # another summation order / another gradient arithmetic
+        assert rel_l2(other[2], base[2]) < 2e-6 and rel_l2(other[3], base[3]) < 2e-6, (rel_l2(other[2], base[2]), rel_l2(other[3], base[3]))
     else:
         np.testing.assert_array_equal(other[2], base[2])
         np.testing.assert_array_equal(other[3], base[3])
+    again = run()                                     # and every variant repeats itself
+    for x, y in zip(other, again):
+        np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize("name", ["small_deg3", "mid_256", "mid_cyl", "mid_blocking"])
