@@ -1399,6 +1399,8 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
                     const float* g_hi = G + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
                     const float* g_lo = g_hi + a.W;
                     g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
+                    // wait for the gather HERE (see trace_bwd_item_lean)
+                    asm volatile("" : "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4));
                     use = true;
                 }
 #endif
@@ -1677,6 +1679,11 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                     const float* g_hi = G + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;
                     const float* g_lo = g_hi + a.W;
                     g1 = g_hi[0]; g2 = g_hi[1]; g3 = g_lo[1]; g4 = g_lo[0];
+                    // The wait for these four loads has to stand INSIDE the branch: the (empty) statement reads them, so the
+                    // compiler puts its s_waitcnt vmcnt(0) here.  Without it the wait lands after the join, before the first
+                    // use of g1 - on the path of EVERY ray, where vmcnt(0) also waits for the whole distortion ring (loads
+                    // retire in order): the ring was drained at every step and the kernel ran 20 % slower.
+                    asm volatile("" : "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4));
                 }
                 m_use |= ballot64(stray);
             }
