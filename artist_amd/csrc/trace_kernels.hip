@@ -777,6 +777,9 @@ __device__ __forceinline__ float select_mask(unsigned long long mask, float a, f
 __device__ __forceinline__ unsigned f32_bits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
+#ifndef ART_RING_DEPTH
+#define ART_RING_DEPTH 8       // (4: A/B build that prices the prefetch distance)
+#endif
 template <bool INTERLEAVED>
 __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
                                                     const int bid, const WorkItem item, unsigned int* __restrict__ work_counter,
@@ -972,15 +975,17 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 /* SAME registers: otherwise the slots rotate and the loop's back-edge has to copy (= wait for) all of them */ \
                 float u, e;                                                         \
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(u), "=v"(e) : "v"(su##j), "v"(se##j) : "memory"); \
-                request(k + j + 8, su##j, se##j);                                   \
+                request(k + j + ART_RING_DEPTH, su##j, se##j);                      \
                 trace_one(u, e, k + j < nr ? ~0ull : 0ull);                          \
                 /* a ray's arithmetic stays inside its step: hoisting the next step's head above it made the */ \
                 /* compiler spill the ray's live values around the hoisted code */   \
                 __builtin_amdgcn_sched_barrier(0);                                  \
             }
-            for (int k = 0; k < nr; k += 8) {
+            for (int k = 0; k < nr; k += ART_RING_DEPTH) {
                 ART_RING_STEP(0) ART_RING_STEP(1) ART_RING_STEP(2) ART_RING_STEP(3)
+#if ART_RING_DEPTH == 8
                 ART_RING_STEP(4) ART_RING_STEP(5) ART_RING_STEP(6) ART_RING_STEP(7)
+#endif
             }
 #undef ART_RING_STEP
         } else {
@@ -1917,9 +1922,9 @@ static FwdConfig fwd_config()
     c.variant = (v && v[0] == 'g') ? 1 : 0;
     c.block = env_int("ARTIST_HIP_FWD_BLOCK", 1024);
     if (c.block < 64 || c.block > 1024 || (c.block % 64) != 0) c.block = 1024;
-    int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 152);
+    int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 158);
     if (kb < 4) kb = 4;
-    if (kb > 152) kb = 152;
+    if (kb > 158) kb = 158;   // 160 KB per CU minus < 1 KB of static LDS (the blocking instantiations cap it further)
     c.tile_cap = kb * 256;   // 4-byte fixed-point cells
     c.target_blocks = env_int("ARTIST_HIP_FWD_BLOCKS", 512);
     c.min_chunk = env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
