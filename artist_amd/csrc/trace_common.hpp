@@ -111,18 +111,23 @@ __device__ __forceinline__ void load_dist_stream(const float* __restrict__ row_u
     return;
 #endif
     typedef float v2f __attribute__((ext_vector_type(2)));
+    // scalar base + zero-extended 32-bit byte offset: the form `global_load ... v_off, s[base:base+1]` takes without any
+    // 64-bit vector arithmetic (lane_off >= 0: an element offset inside one heliostat's row)
+    const unsigned byte_off = (unsigned)lane_off * 4u;
+    const char* pu = reinterpret_cast<const char*>(row_u) + byte_off;
     if constexpr (INTERLEAVED) {
 #ifdef ART_STREAM_PLAIN_LOADS
-        const v2f v = *reinterpret_cast<const v2f*>(row_u + lane_off);
+        const v2f v = *reinterpret_cast<const v2f*>(pu);
 #else
-        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(row_u + lane_off));
+        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(pu));
 #endif
         u = v.x; e = v.y;
     } else {
+        const char* pe = reinterpret_cast<const char*>(row_e) + byte_off;
 #ifdef ART_STREAM_PLAIN_LOADS
-        u = row_u[lane_off]; e = row_e[lane_off];
+        u = *reinterpret_cast<const float*>(pu); e = *reinterpret_cast<const float*>(pe);
 #else
-        u = __builtin_nontemporal_load(row_u + lane_off); e = __builtin_nontemporal_load(row_e + lane_off);
+        u = __builtin_nontemporal_load(reinterpret_cast<const float*>(pu)); e = __builtin_nontemporal_load(reinterpret_cast<const float*>(pe));
 #endif
     }
 }

@@ -888,9 +888,10 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
             // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
             // merge their tails and spill what crossed the join
-            Rot m;
-            if (__builtin_expect(wave_any(!(fmaxf(fabsf(u), fabsf(e)) <= kSmallAngle)), 0)) m = make_rot(e, u);
-            else m = make_rot_t<true>(e, u);
+            // (the Taylor values are computed first and REPLACED on the rare path: as two arms of a branch the common arm ended
+            //  in register copies; |u| + |e| bounds the larger angle with one instruction instead of three)
+            Rot m = make_rot_t<true>(e, u);
+            if (__builtin_expect(wave_any(!(fabsf(u) + fabsf(e) <= kSmallAngle)), 0)) m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
             const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
@@ -952,11 +953,15 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         // ahead, the waves waited for this stream 40 % of the forward and 60 % of the backward kernel's time.
         const int lane_off = p * (int)a.sp;
         const int nr = r1 - r0;
+        // the stream's addresses: a wave-uniform row pointer that walks from sample to sample on the scalar unit (and stops
+        // at the last row: the padding requests of the last ring round re-read it) + the lane's 32-bit byte offset
         const float* __restrict__ bu_ = a.dist_u + dbase;     // wave-uniform
         const float* __restrict__ be_ = a.dist_e + dbase;
-        auto request = [&](int r, float& u, float& e) {
-            const int64_t row = (int64_t)min(r, nr - 1) * a.sr;
-            load_dist_stream<INTERLEAVED>(bu_ + row, be_ + row, lane_off, u, e);
+        int next_r = 0;
+        auto request = [&](int, float& u, float& e) {         // requests are made in sample order
+            load_dist_stream<INTERLEAVED>(bu_, be_, lane_off, u, e);
+            const int64_t step = next_r + 1 < nr ? a.sr : 0;
+            bu_ += step; be_ += step; ++next_r;
         };
 #ifdef ART_LEAN_NO_RING          // A/B build: every sample requested where it is used
         if (false) {
@@ -1646,9 +1651,10 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
             // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
             // merge their tails and spill what crossed the join
-            Rot m;
-            if (__builtin_expect(wave_any(!(fmaxf(fabsf(u), fabsf(e)) <= kSmallAngle)), 0)) m = make_rot(e, u);
-            else m = make_rot_t<true>(e, u);
+            // (the Taylor values are computed first and REPLACED on the rare path: as two arms of a branch the common arm ended
+            //  in register copies; |u| + |e| bounds the larger angle with one instruction instead of three)
+            Rot m = make_rot_t<true>(e, u);
+            if (__builtin_expect(wave_any(!(fabsf(u) + fabsf(e) <= kSmallAngle)), 0)) m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
             const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
@@ -1721,11 +1727,13 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         };
         const int lane_off = p * (int)a.sp;
         const int nr = r1 - r0;
-        const float* __restrict__ bu_ = a.dist_u + dbase;
+        const float* __restrict__ bu_ = a.dist_u + dbase;     // walks from sample to sample (see trace_fwd_item_lean)
         const float* __restrict__ be_ = a.dist_e + dbase;
-        auto request = [&](int r, float& u, float& e) {
-            const int64_t row = (int64_t)min(r, nr - 1) * a.sr;
-            load_dist_stream<INTERLEAVED>(bu_ + row, be_ + row, lane_off, u, e);
+        int next_r = 0;
+        auto request = [&](int, float& u, float& e) {
+            load_dist_stream<INTERLEAVED>(bu_, be_, lane_off, u, e);
+            const int64_t step = next_r + 1 < nr ? a.sr : 0;
+            bu_ += step; be_ += step; ++next_r;
         };
         if (nr >= 8) {                                // the distortion ring of trace_fwd_item_lean
             float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Instruction counts per ray step of the lean trace kernels, from the compiler's assembly.
+
+usage: python tools/loop_stats.py [trace_kernels.s]   (default: compile artist_amd/csrc/trace_kernels.hip to /tmp first)
+A ray step of the ring loop starts at its `s_waitcnt vmcnt(7)`; the eight steps of a round are averaged.
+"""
+import collections
+import pathlib
+import re
+import subprocess
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+if len(sys.argv) > 1:
+    asm = pathlib.Path(sys.argv[1])
+else:
+    asm = pathlib.Path("/tmp/trace_kernels_stats.s")
+    flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize".split()
+    subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-S", "--cuda-device-only", "-o", str(asm), "trace_kernels.hip"],
+                   cwd=ROOT / "artist_amd" / "csrc", check=True, stderr=subprocess.DEVNULL)
+lines = asm.read_text().split("\n")
+
+
+def stats(name, pat):
+    s = [i for i, l in enumerate(lines) if l.startswith(pat)][0]
+    e = next(i for i in range(s, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
+    w = [i for i in range(s, e) if "s_waitcnt vmcnt(7)" in lines[i]]
+    span = None
+    for k in range(len(w) - 7):
+        d = [w[k + i + 1] - w[k + i] for i in range(7)]
+        if max(d) - min(d) < 40:
+            span = (w[k], w[k + 7] + sum(d) // 7)
+            break
+    if span is None:
+        print(name, "ring loop not found")
+        return
+    ins = [l.split()[0] for l in lines[span[0]:span[1]] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+    c = collections.Counter()
+    for k in ins:
+        if k.startswith("v_"):
+            c["valu"] += 1
+        elif k.startswith(("s_waitcnt", "s_nop")):
+            c["wait"] += 1
+        elif k.startswith("s_"):
+            c["salu"] += 1
+        elif k.startswith("ds_"):
+            c["lds"] += 1
+        elif k.startswith(("global_", "scratch_", "buffer_")):
+            c["vmem"] += 1
+    meta = {}
+    for i, l in enumerate(lines):
+        if l.strip().startswith(".name:") and pat.rstrip(":") in l:
+            for j in range(i - 70, i + 30):
+                m = re.match(r"\s+\.(vgpr_count|private_segment_fixed_size|sgpr_count):\s+(\d+)", lines[j])
+                if m:
+                    meta[m.group(1)] = int(m.group(2))
+            break
+    print(f"{name}: per ray " + ", ".join(f"{k} {v / 8:.1f}" for k, v in sorted(c.items())) +
+          f"; v_mov {sum(k.startswith('v_mov') for k in ins) / 8:.1f}, scratch in loop {sum(k.startswith('scratch') for k in ins)}; {meta}")
+
+
+stats("forward lean (interleaved)", "_ZN3art20trace_fwd_lds_kernelILb1ELb0ELb0ELb1EEEv")
+stats("backward lean (interleaved)", "_ZN3art20trace_bwd_lds_kernelILb1ELb0ELb0ELb0ELb1EEEv")
