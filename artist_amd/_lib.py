@@ -15,7 +15,7 @@ _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ArtistHipError(RuntimeError):
@@ -33,15 +33,15 @@ SIGNATURES = {
     "art_trace_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_dbl,
-                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
+                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr, _ptr],
     "art_async_status": [_ptr, _c_int],
     "art_trace_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_dbl,
-                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
+                      _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr],
-    "art_trace_bwd_scratch_floats": [_c_i64, _c_i64, _c_i64],
+    "art_trace_bwd_scratch_floats": [_c_i64, _c_i64, _c_i64, _c_i64],
     "art_flux_crop_fwd": [_ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],
     "art_flux_crop_bwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr],
     "art_flux_loss": [_ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr],

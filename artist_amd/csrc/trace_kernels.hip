@@ -421,6 +421,15 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
 //     (Dealing the last items as two halves of their sample range, so that the kernel ends within half an item, measured
 //     neutral at 1000 and 125 heliostats in round 1 and needed float atomics in the backward kernel: removed.)
 struct WorkItem { int h, pblock, rchunk, r0, r1; };
+// Points [p0, p1) of point block `pblock`: blocks never straddle two facets (a.facet_points consecutive points - the
+// caller's facet size, a whole multiple of it when blocks are larger than a facet, or P when no facet structure is
+// known) - two facets' images are two blobs and one window serves them badly.
+__device__ __forceinline__ void block_range(const TraceArgs& a, int pblock, int& p0, int& p1)
+{
+    const int f = pblock / a.blocks_per_facet, i = pblock - f * a.blocks_per_facet;
+    p0 = f * a.facet_points + i * a.p_block;
+    p1 = min(p0 + a.p_block, min((f + 1) * a.facet_points, a.P));
+}
 __device__ __forceinline__ int work_item_count(const TraceArgs& a) { return a.H * a.n_pblocks * a.n_rchunks; }
 // Longest items first: an item's cost grows with the distance between heliostat and target (wider image, more rays
 // beyond the window: 83 -> 115 us from the nearest to the farthest tenth of the metric field), and a queue that ends
@@ -482,8 +491,8 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     const float k_ext = a.k_ext, k_refl = a.k_refl;
     unsigned long long* __restrict__ acc = a.accum + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;   // this bitmap's accumulators
     const float4 inc = a.incident[h];
-    const int p0 = pblock * a.p_block;
-    const int p1 = min(p0 + a.p_block, a.P);
+    int p0, p1;
+    block_range(a, pblock, p0, p1);
     const int r0 = item.r0;
     const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
@@ -777,6 +786,7 @@ __device__ __forceinline__ float select_mask(unsigned long long mask, float a, f
 __device__ __forceinline__ unsigned f32_bits(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
+constexpr int kLeanFwdPoints = 2560;   // points per item of the lean forward kernel when the facet structure is known
 #ifndef ART_RING_DEPTH
 #define ART_RING_DEPTH 8       // (4: A/B build that prices the prefetch distance)
 #endif
@@ -802,8 +812,8 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const Cyl cy = {};
     unsigned long long* __restrict__ acc = a.accum + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;   // this bitmap's accumulators
     const float4 inc = a.incident[h];
-    const int p0 = pblock * a.p_block;
-    const int p1 = min(p0 + a.p_block, a.P);
+    int p0, p1;
+    block_range(a, pblock, p0, p1);
     const int r0 = item.r0;
     const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
@@ -1256,8 +1266,8 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     else pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
     const float4 inc = a.incident[h];
-    const int p0 = pblock * a.p_block;
-    const int p1 = min(p0 + a.p_block, a.P);
+    int p0, p1;
+    block_range(a, pblock, p0, p1);
     const int r0 = item.r0;
     const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
@@ -1579,8 +1589,8 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const Cyl cy = {};
     const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
     const float4 inc = a.incident[h];
-    const int p0 = pblock * a.p_block;
-    const int p1 = min(p0 + a.p_block, a.P);
+    int p0, p1;
+    block_range(a, pblock, p0, p1);
     const int r0 = item.r0;
     const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
@@ -1787,6 +1797,12 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
 //  samples and the gradient sums do not fit the 128 registers of a 1024-thread workgroup, and vector issue is no slower
 //  with three waves than with four, tools/issue_bench.hip)
 constexpr int kLeanBwdThreads = 768;
+// Points per item: every item stages a 158 KB gradient window and runs a window phase (~16 us), so fewer, larger blocks pay
+// as long as the chip still gets its rounds (window_geometry adds blocks when it does not).  Same-box sweep on the metric
+// field (10 000 points per heliostat): 7 blocks of 1429 points 4.16 ms, 5 x 2000 3.92, 4 x 2500 3.85-3.94, 3 x 3334 4.09-4.35,
+// 2 x 5000 4.08.  The trips of a block need not be full: 2500 points = 768 + 768 + 768 + 196 threads beat four equal trips of
+// 640 threads (4.28 ms) - a trip costs what its active waves issue, not a fixed time.
+constexpr int kLeanBwdPoints = 2560;
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
 __global__ __launch_bounds__((CYL || BLOCKING) ? 512 : (LEAN ? kLeanBwdThreads : 1024)) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
@@ -1921,6 +1937,7 @@ struct FwdConfig {
     int multipass_ratio;
     int min_rays;       // rays per workgroup worth a window build + flush
     bool exact_pblock;  // balanced point blocks that need not fill every lane (workgroup sizes that do not divide P)
+    int facet_points;   // the caller's hint: consecutive points that form one facet (0: unknown)
 };
 
 static FwdConfig fwd_config()
@@ -1944,6 +1961,7 @@ static FwdConfig fwd_config()
     c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
     if (c.p_block < 64) c.p_block = 64;
     c.exact_pblock = env_int("ARTIST_HIP_PBLOCK_EXACT", 0) != 0;
+    c.facet_points = 0;
     c.p_block_bwd = env_int("ARTIST_HIP_BWD_PBLOCK", 2048);
     if (c.p_block_bwd < 64) c.p_block_bwd = 64;
     return c;
@@ -2023,8 +2041,11 @@ static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_targ
     auto cost = [&](const TraceArgs& g) {
         const int64_t wgs = (int64_t)g.H * g.n_pblocks * g.n_rchunks;
         const int64_t rounds = (wgs + resident_workgroups() - 1) / resident_workgroups();
-        const int points = (g.P + g.n_pblocks - 1) / g.n_pblocks;
-        return (double)rounds * ((double)points * g.r_chunk + 1.5e4);
+        const int points = (g.facet_points + g.blocks_per_facet - 1) / g.blocks_per_facet;
+        // + 0.5: the queue ends when the slowest CU has finished its last item, about half an item after the average one
+        // (measured at 125 heliostats, lean backward: 8 blocks per heliostat 0.635 ms < 6 blocks 0.669 < 4 blocks 0.671 <
+        //  7 blocks 0.699, the order this expression gives)
+        return ((double)rounds + 0.5) * ((double)points * g.r_chunk + 1.5e4);
     };
     if (cfg.exact_pblock) {
         // balanced blocks of any size: also try one to three blocks more per heliostat (measured, 125 heliostats, lean
@@ -2032,10 +2053,10 @@ static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_targ
         const TraceArgs base = a;
         double best = 0.97 * cost(base);
         for (int extra = 1; extra <= 3; ++extra) {
-            const int nblk = base.n_pblocks + extra;
+            const int nblk = base.blocks_per_facet + extra;
             TraceArgs g = base;
-            window_geometry_for(g, cfg, (base.P + nblk - 1) / nblk);
-            if (g.n_pblocks == nblk && cost(g) < best) { best = cost(g); a = g; }
+            window_geometry_for(g, cfg, (base.facet_points + nblk - 1) / nblk);
+            if (g.blocks_per_facet == nblk && cost(g) < best) { best = cost(g); a = g; }
         }
         return;
     }
@@ -2054,11 +2075,24 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     // few samples per point (R = 1 field-scale prediction: one workgroup per heliostat)
     if ((int64_t)p_block_target * a.R < cfg.min_rays) p_block_target = (int)((cfg.min_rays + a.R - 1) / a.R);
     if (p_block_target > a.P) p_block_target = a.P;
-    const int nblk = (a.P + p_block_target - 1) / p_block_target;
-    // (ARTIST_HIP_PBLOCK_EXACT=1: balanced blocks that need not fill every lane - for workgroup sizes that do not divide P)
-    const int pb = cfg.exact_pblock ? (a.P + nblk - 1) / nblk : ((a.P + nblk - 1) / nblk + bs - 1) / bs * bs;
+    // the unit that blocks subdivide: a facet (the caller's hint), several whole facets when a block is to hold more points
+    // than a facet has, or the whole heliostat
+    int unit = a.P;
+    if (cfg.facet_points > 0 && cfg.facet_points < a.P && a.P % cfg.facet_points == 0)
+        unit = (int)std::min<int64_t>(a.P, (int64_t)cfg.facet_points * std::max(1, p_block_target / cfg.facet_points));
+    if (p_block_target > unit) p_block_target = unit;
+    int nblk = (unit + p_block_target - 1) / p_block_target;
+    // a field too small to fill the chip is cut into more POINT blocks first (down to half a trip of the workgroup) and
+    // into sample chunks only then: a chunk pays a window build and a flush like a block, and in the backward pass a
+    // slab of partial gradients on top
+    const int64_t units = ((int64_t)a.P + unit - 1) / unit * a.H;
+    while (units * nblk < cfg.target_blocks && (unit + nblk) / (nblk + 1) >= bs / 2) ++nblk;
+    // (exact: balanced blocks that need not fill every lane - for workgroup sizes that do not divide the unit)
+    const int pb = cfg.exact_pblock ? (unit + nblk - 1) / nblk : ((unit + nblk - 1) / nblk + bs - 1) / bs * bs;
     a.p_block = pb;
-    a.n_pblocks = (a.P + pb - 1) / pb;
+    a.facet_points = unit;
+    a.blocks_per_facet = (unit + pb - 1) / pb;
+    a.n_pblocks = (a.P + unit - 1) / unit * a.blocks_per_facet;
     a.tile_cap = cfg.tile_cap;
     a.multipass_ratio = cfg.multipass_ratio;
     const int64_t base = (int64_t)a.H * a.n_pblocks;
@@ -2086,7 +2120,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                              const float* prim_spans, const float* prim_normals, const int32_t* cand,
                              const int32_t* cand_count, int64_t Cmax, double max_scatter_angle,
                              double ray_magnitude, double extinction, double reflectivity, int64_t H, int64_t R,
-                             int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux,
+                             int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux,
                              float* factors, uint64_t* accum, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -2115,6 +2149,8 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     ART_HIP(hipMemsetAsync(factors, 0, sizeof(float) * 3 * H, stream));
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
     FwdConfig cfg = fwd_config();
+    if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
+    cfg.facet_points = (int)facet_points;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (accum == nullptr || (reinterpret_cast<uintptr_t>(accum) % 16) != 0) return ART_EINVAL;
     // unit of the pixel accumulators: 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|
@@ -2131,12 +2167,21 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // factors - then a valid ray is known to carry intensity and one counter serves both factors
         const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
                           a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
-        if (lean && T > 0 && Tc == 0 && kLeanFwdThreads != 1024) {
+        if (lean && T > 0 && Tc == 0) {
+            // Balanced blocks whose trips need not be full (a trip costs what its active waves issue), and - when the
+            // caller says where the facets are - one block per facet or per equal part of a facet: every item pays a window
+            // phase, a clear and a flush (~17 us), so fewer and larger blocks win as long as no block straddles two facets.
+            // Same-box sweep on the metric field (4 facets of 2500 points; blocks per heliostat -> forward ms):
+            // 4 -> 3.32, 6 -> 3.43, 8 -> 3.52, 10 -> 3.57 (the round-1 geometry, 1024-point blocks: 3.75), and with most
+            // blocks across a facet boundary 5 -> 4.04, 7 -> 3.85, 9 -> 3.96.
             cfg.block = kLeanFwdThreads;
             cfg.exact_pblock = true;
-            if (!cfg.p_block_fixed) cfg.p_block = kLeanFwdThreads;
+            if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanFwdThreads;
         }
         window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
+        if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
+            fprintf(stderr, "art_trace_fwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
+                    a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean);
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
@@ -2218,7 +2263,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                              const float* prim_spans, const float* prim_normals, const int32_t* cand,
                              const int32_t* cand_count, int64_t Cmax, int64_t N, double max_scatter_angle,
                              double ray_magnitude,
-                             double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t T,
+                             double extinction, double reflectivity, int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t T,
                              int64_t Tc, int64_t W, int64_t Hh, int mode, const float* grad_flux, float* grad_origins,
                              float* grad_normals, float* grad_prim_corners, float* grad_prim_spans,
                              float* grad_prim_normals, float* grad_scratch, int64_t grad_scratch_floats, void* stream_)
@@ -2252,6 +2297,8 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     float4* gn = reinterpret_cast<float4*>(grad_normals);
     const bool il = interleaved_layout(a);
     FwdConfig cfg = fwd_config();
+    if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
+    cfg.facet_points = (int)facet_points;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
         // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, two trips of points
@@ -2259,7 +2306,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         if (lean) {
             cfg.block = kLeanBwdThreads;
             cfg.exact_pblock = true;
-            if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = 2 * kLeanBwdThreads;
+            if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
         }
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         // A small field is cut into sample chunks to fill the chip; the chunks of a point then write partial gradients
@@ -2270,6 +2317,9 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             cfg.target_blocks = 1;
             window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         }
+        if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
+            fprintf(stderr, "art_trace_bwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
+                    a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean);
         const bool atomic_out = a.n_rchunks > 1;      // (round 1's name: today the chunks write slabs, nothing is atomic)
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
@@ -2337,18 +2387,21 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     return ART_OK;
 }
 
-extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P)
+extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points)
 {
     if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26)) return 0;
     TraceArgs a = {};
     a.H = (int)H; a.R = (int)R; a.P = (int)P;
     FwdConfig cfg = fwd_config();
     if (cfg.variant != 0) return 0;
+    if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return 0;
+    cfg.facet_points = (int)facet_points;
+    a.facet_points = (int)P; a.blocks_per_facet = 1;
     window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
     int64_t chunks = a.n_rchunks;
     cfg.block = kLeanBwdThreads;                   // the lean kernel's geometry (art_trace_bwd picks one of the two)
     cfg.exact_pblock = true;
-    if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = 2 * kLeanBwdThreads;
+    if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
     window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
     chunks = std::max<int64_t>(chunks, a.n_rchunks);
     return chunks > 1 ? chunks * H * P * 8 : 0;

@@ -122,12 +122,17 @@ class TraceRays(torch.autograd.Function):
     def forward(ctx, origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                 ray_magnitude, extinction, reflectivity, width, height, per_target, cyl=None,
                 prim_corners=None, prim_spans=None, prim_normals=None, owner=None, max_scatter_angle=-1.0,
-                lbvh_compat=True):
+                lbvh_compat=True, points_per_facet=0):
         dev = _require_cuda(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims)
         origins, normals, incident = _f32c(origins), _f32c(normals), _f32c(incident)
         H, P = origins.shape[0], origins.shape[1]
         if origins.shape != (H, P, 4) or normals.shape != (H, P, 4) or incident.shape != (H, 4):
             raise ValueError("origins/normals must be [H,P,4] and incident [H,4]")
+        # a performance hint, never a semantic one: the kernels cut a heliostat's points into blocks that share an LDS
+        # window, and blocks that do not straddle two facets (two separate images) fit their windows better
+        points_per_facet = int(points_per_facet or 0)
+        if points_per_facet < 0 or (points_per_facet and P % points_per_facet):
+            raise ValueError("points_per_facet must divide the number of surface points per heliostat")
         R = dist_u.shape[1] if dist_u.dim() == 3 else -1
         dist_u, dist_e, (sh, sr, sp) = _dist_views(dist_u, dist_e, (H, R, P))
         target_idx = target_idx.to(torch.int32).contiguous()
@@ -177,7 +182,7 @@ class TraceRays(torch.autograd.Function):
             rc = _lib.lib().art_trace_fwd(
                 *geometry, *block_ptrs, Cmax, float(max_scatter_angle), float(ray_magnitude), float(extinction),
                 float(reflectivity),
-                H, R, P, T, Tc, width, height, 1 if per_target else 0, flux.data_ptr(), factors.data_ptr(),
+                H, R, P, points_per_facet, T, Tc, width, height, 1 if per_target else 0, flux.data_ptr(), factors.data_ptr(),
                 accum.data_ptr(), _stream(dev))
         if rc != 0:
             _ACCUM.clear()
@@ -189,7 +194,7 @@ class TraceRays(torch.autograd.Function):
                               *cyl_tabs, *block_tabs)
         ctx.n_cyl = len(cyl_tabs)
         ctx.scalars = (float(ray_magnitude), float(extinction), float(reflectivity), width, height, bool(per_target),
-                       Cmax, N, float(max_scatter_angle))
+                       Cmax, N, float(max_scatter_angle), points_per_facet)
         ctx.mark_non_differentiable(factors, flags)
         return flux, factors, flags
 
@@ -202,7 +207,7 @@ class TraceRays(torch.autograd.Function):
         cyl_ptrs = tuple(t.data_ptr() for t in cyl_tabs) if cyl_tabs else (None,) * 6
         block_ptrs = tuple(t.data_ptr() for t in block_tabs) if block_tabs else (None,) * 5
         Tc = cyl_tabs[0].shape[0] if cyl_tabs else 0
-        mag, ext, refl, width, height, per_target, Cmax, N, max_scatter = ctx.scalars
+        mag, ext, refl, width, height, per_target, Cmax, N, max_scatter, points_per_facet = ctx.scalars
         dev = origins.device
         H, P = origins.shape[0], origins.shape[1]
         R = dist_u.shape[1]
@@ -213,38 +218,41 @@ class TraceRays(torch.autograd.Function):
         g_pc = g_ps = g_pn = None
         if block_tabs:
             g_pc, g_ps, g_pn = (torch.empty_like(t) for t in block_tabs[:3])
-        n_scratch = int(_lib.lib().art_trace_bwd_scratch_floats(H, R, P))
+        n_scratch = int(_lib.lib().art_trace_bwd_scratch_floats(H, R, P, points_per_facet))
         scratch = torch.empty((n_scratch,), dtype=torch.float32, device=dev) if n_scratch else None
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_bwd(
                 origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
                 sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,
-                *block_ptrs, Cmax, N, max_scatter, mag, ext, refl, H, R, P, centers.shape[0], Tc, width, height,
+                *block_ptrs, Cmax, N, max_scatter, mag, ext, refl, H, R, P, points_per_facet, centers.shape[0], Tc, width, height,
                 1 if per_target else 0, grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(),
                 *(t.data_ptr() if t is not None else None for t in (g_pc, g_ps, g_pn)),
                 None if scratch is None else scratch.data_ptr(), n_scratch, _stream(dev))
         _lib.check(rc, "art_trace_bwd")
-        return (g_o, g_n) + (None,) * 14 + (g_pc, g_ps, g_pn, None, None, None)
+        return (g_o, g_n) + (None,) * 14 + (g_pc, g_ps, g_pn, None, None, None, None)
 
 
 def trace_rays(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                ray_magnitude=1.0, extinction=0.0, reflectivity=0.935, resolution=(256, 256), per_target=False,
-               cyl=None, blocking=None):
+               cyl=None, blocking=None, points_per_facet=0):
     """Functional form.  Returns ``(flux, factors)`` with ``flux`` ``[H,Hh,W]`` (or ``[T+Tc,Hh,W]`` when
     ``per_target``) and ``factors`` ``[3,H]`` = intercept, on-target, blocking fractions.  ``cyl`` = the six
     ``TowerTargetAreasCylindrical`` tensors (centers, normals, axes, radii, heights, opening_angles) or None.
     ``blocking`` = None or a dict with ``corners [N,4,4]``, ``spans [N,2,4]``, ``normals [N,4]``, ``owner [H]`` and
-    optionally ``max_scatter_angle`` / ``lbvh_compat``; the filtered set is then returned as a third value."""
+    optionally ``max_scatter_angle`` / ``lbvh_compat``; the filtered set is then returned as a third value.
+    ``points_per_facet`` (optional, performance only): the surface points of a heliostat are F runs of that many points,
+    one run per facet (ARTIST's ``[H, F * M, 4]`` layout) - results do not depend on it."""
     if blocking is None:
         flux, factors, _ = TraceRays.apply(origins, normals, incident, dist_u, dist_e, target_idx, centers,
                                            plane_normals, dims, ray_magnitude, extinction, reflectivity,
-                                           int(resolution[0]), int(resolution[1]), bool(per_target), cyl)
+                                           int(resolution[0]), int(resolution[1]), bool(per_target), cyl,
+                                           None, None, None, None, -1.0, True, points_per_facet)
         return flux, factors
     return TraceRays.apply(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                            ray_magnitude, extinction, reflectivity, int(resolution[0]), int(resolution[1]),
                            bool(per_target), cyl, blocking["corners"], blocking["spans"], blocking["normals"],
                            blocking["owner"], float(blocking.get("max_scatter_angle", -1.0)),
-                           bool(blocking.get("lbvh_compat", True)))
+                           bool(blocking.get("lbvh_compat", True)), points_per_facet)
 
 
 def per_target_sum(bitmaps: torch.Tensor, target_idx: torch.Tensor, n_targets: int) -> torch.Tensor:

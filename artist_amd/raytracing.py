@@ -184,10 +184,18 @@ class HeliostatRayTracer:
         flux, factors, flags = ops.TraceRays.apply(
             points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
             ray_magnitude, float(ray_extinction_factor), float(mirror_reflectivity), width, height, False,
-            _cylinder_tables(tower), *self._blocking_arguments(idx, active_heliostats_mask))
+            _cylinder_tables(tower), *(self._blocking_arguments(idx, active_heliostats_mask) or (None, None, None, None, -1.0, True)),
+            self._points_per_facet(points))
         if self.blocking_active:
             self.filtered_blocking_primitive_indices = torch.nonzero(flags, as_tuple=True)[0]
         return flux, factors[0], factors[1], factors[2]
+
+    def _points_per_facet(self, points) -> int:
+        """The group's surface tensors are facet-major ``[H, F * M, 4]`` (heliostat_group.py:26-63): tell the kernels M, so
+        that a block of points never holds two facets' images (a layout hint - results do not depend on it)."""
+        facets = int(getattr(self.heliostat_group, "number_of_facets_per_heliostat", 0) or 0)
+        n_points = int(points.shape[1])
+        return n_points // facets if facets > 1 and n_points % facets == 0 else 0
 
     def _validate_targets(self, target_area_indices, tower) -> None:
         """The kernels index the target tables with these: validated on the host, once per tensor object and version
@@ -249,7 +257,8 @@ class HeliostatRayTracer:
         flux, factors, flags = ops.TraceRays.apply(
             points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
             float(self.ray_magnitude), float(ray_extinction_factor), float(mirror_reflectivity), width, height, True,
-            _cylinder_tables(tower), *self._blocking_arguments(idx, active_heliostats_mask))
+            _cylinder_tables(tower), *(self._blocking_arguments(idx, active_heliostats_mask) or (None, None, None, None, -1.0, True)),
+            self._points_per_facet(points))
         if self.blocking_active:
             self.filtered_blocking_primitive_indices = torch.nonzero(flags, as_tuple=True)[0]
         return flux, factors[0], factors[1], factors[2]

@@ -125,7 +125,7 @@ def torch_eager_baseline(args, ap, an, inc, planar, seconds):
                       f"torch {torch.__version__}, {threads} threads"}
 
 
-def correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops):
+def correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops, points_per_facet=0):
     """Four heliostats of the field that was just timed (first, one third, two thirds, last of this rank's list = near to far)
     through the HIP kernels once more and through the oracle: flux relative L2, ray counters, gradient relative L2."""
     import numpy as np
@@ -139,7 +139,7 @@ def correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops):
     du, de = both[..., 0], both[..., 1]
     ag, ng = a.clone().requires_grad_(True), n_.clone().requires_grad_(True)
     flux, factors = ops.trace_rays(ag, ng, i_, du, de, t_, planar.centers, planar.normals, planar.dimensions, 1.0, 0.0, 0.935,
-                                   (256, 256))
+                                   (256, 256), points_per_facet=points_per_facet)
     gen = torch.Generator(device=ap.device).manual_seed(11)
     w = torch.rand(flux.shape, generator=gen, device=ap.device)
     go, gn = torch.autograd.grad(flux, (ag, ng), w)
@@ -238,7 +238,8 @@ def main():
         ap, an = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl,
                                                                                              orientations=orientation)
         flux, factors = ops.trace_rays(ap.reshape(H, P, 4), an.reshape(H, P, 4), inc, dist_u, dist_e, tix, planar.centers,
-                                       planar.normals, planar.dimensions, 1.0, 0.0, 0.935, (256, 256))
+                                       planar.normals, planar.dimensions, 1.0, 0.0, 0.935, (256, 256),
+                                       points_per_facet=n_eval * n_eval)   # the surfaces' [H, F, M] layout (heliostat_group.py:26-63)
         return flux, factors
 
     def step(backward=True):
@@ -309,10 +310,10 @@ def main():
         pts, nrm = NURBSSurfaces(degrees, cp, device=dev).calculate_surface_points_and_normals(uv_local, canting, transl)
         ap, an = ops.align_surfaces(pts.reshape(H, P, 4), nrm.reshape(H, P, 4), orientation)
     ms_fwd = kernel_ms(lambda: ops.trace_rays(ap, an, inc, dist_u, dist_e, tix, planar.centers, planar.normals,
-                                              planar.dimensions, 1.0, 0.0, 0.935, (256, 256)))
+                                              planar.dimensions, 1.0, 0.0, 0.935, (256, 256), points_per_facet=n_eval * n_eval))
     apg, ang = ap.clone().requires_grad_(True), an.clone().requires_grad_(True)
     flux, _ = ops.trace_rays(apg, ang, inc, dist_u, dist_e, tix, planar.centers, planar.normals, planar.dimensions,
-                             1.0, 0.0, 0.935, (256, 256))
+                             1.0, 0.0, 0.935, (256, 256), points_per_facet=n_eval * n_eval)
     gflux = torch.ones_like(flux)
     ms_bwd = kernel_ms(lambda: torch.autograd.grad(flux, (apg, ang), gflux, retain_graph=True))
     del flux, gflux, apg, ang
@@ -348,7 +349,7 @@ def main():
     # ---- correctness stamp, outside every timed region: the rays just timed against the oracle ---------------
     check = None
     if rank == 0 and not args.no_check:
-        check = correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops)
+        check = correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops, n_eval * n_eval)
 
     if rank == 0:
         total_rays = H_total * R * P

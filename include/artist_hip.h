@@ -71,6 +71,10 @@ int art_last_hip_error(void);
  *                     skip the rectangles that none of its scattered rays can reach - speed only, never results
  *   ray_magnitude     Rays.ray_magnitudes fill value (heliostat_ray_tracer.py:185-203)
  *   extinction, reflectivity  trace_rays(ray_extinction_factor, mirror_reflectivity)
+ *   facet_points      0, or the number M of consecutive surface points that form one facet (ARTIST's surface tensors are
+ *                     [H, F * M, 4], facet-major: artist/field/surface.py, heliostat_group.py) - P must be a multiple.
+ *                     A layout hint for speed, never for results: the kernels cut a heliostat's points into blocks that
+ *                     share an LDS window, and a block that straddles two facets sees two separate images
  *   W, Hh             bitmap_resolution[0] (east / angle), bitmap_resolution[1] (up)
  *   mode              0: flux is [H,Hh,W] (one bitmap per active heliostat)
  *                     1: flux is [T+Tc,Hh,W] (summed per target area)
@@ -95,8 +99,8 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
                   const float *cyl_opening, const float *prim_corners, const float *prim_spans,
                   const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax,
                   double max_scatter_angle, double ray_magnitude, double extinction, double reflectivity,
-                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
-                  float *flux, float *factors, uint64_t *accum, void *stream);
+                  int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t W, int64_t Hh,
+                  int mode, float *flux, float *factors, uint64_t *accum, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * art_async_status - the entry points are asynchronous, so what only the DEVICE can find out is reported here:
@@ -129,8 +133,8 @@ int art_trace_bwd(const float *origins, const float *normals, const float *incid
                   const float *cyl_opening, const float *prim_corners, const float *prim_spans,
                   const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax, int64_t N,
                   double max_scatter_angle, double ray_magnitude, double extinction, double reflectivity,
-                  int64_t H, int64_t R, int64_t P, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode,
-                  const float *grad_flux, float *grad_origins, float *grad_normals, float *grad_prim_corners,
+                  int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t W, int64_t Hh,
+                  int mode, const float *grad_flux, float *grad_origins, float *grad_normals, float *grad_prim_corners,
                   float *grad_prim_spans, float *grad_prim_normals, float *grad_scratch, int64_t grad_scratch_floats,
                   void *stream);
 
@@ -138,7 +142,7 @@ int art_trace_bwd(const float *origins, const float *normals, const float *incid
  * With a 16-byte aligned buffer of at least this size the chunks' partial gradients are written to slabs and added in
  * chunk order - bit-reproducible gradients; with NULL (or less) the samples of a point stay in one work item, which is
  * reproducible too but leaves most of the chip idle on a field of a few heliostats. */
-int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P);
+int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points);
 
 /* ---------------------------------------------------------------------------------------------
  * art_blocking_filter - lbvh_filter_blocking_planes (artist/raytracing/blocking.py:832-995, with the tree of

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--rays", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-facets", action="store_true", help="do not tell the kernels the facet structure")
     ap.add_argument("variants", nargs="+")
     args = ap.parse_args()
 
@@ -45,6 +46,7 @@ def main():
     group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask)
     ap_, an_ = group.active_surface_points.contiguous(), group.active_surface_normals.contiguous()
     P = ap_.shape[1]
+    ppf = 0 if args.no_facets else P // group.number_of_facets_per_heliostat
     gen = torch.Generator(device=dev).manual_seed(7)
     both = torch.randn((H, R, P, 2), generator=gen, device=dev).mul_(4.3681e-06 ** 0.5)
     du, de = both[..., 0], both[..., 1]
@@ -79,12 +81,12 @@ def main():
                 a.record()
                 for _ in range(args.reps):
                     flux, fac = ops.trace_rays(ap_, an_, inc, du, de, tix, planar.centers, planar.normals, planar.dimensions, 1.0, 0.0,
-                                               0.935, (256, 256))
+                                               0.935, (256, 256), points_per_facet=ppf)
                 b.record()
             else:
                 apg, ang = ap_.clone().requires_grad_(True), an_.clone().requires_grad_(True)
                 flux, fac = ops.trace_rays(apg, ang, inc, du, de, tix, planar.centers, planar.normals, planar.dimensions, 1.0, 0.0,
-                                           0.935, (256, 256))
+                                           0.935, (256, 256), points_per_facet=ppf)
                 a.record()
                 for _ in range(args.reps):
                     torch.autograd.grad(flux, (apg, ang), gflux, retain_graph=True)
