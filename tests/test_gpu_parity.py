@@ -478,6 +478,37 @@ def test_ragged_shapes(H, R, P, W, Hh):
         assert rel_l2(n(od.grad), go) < 1e-5 and rel_l2(n(nd.grad), gn) < 1e-5, (rel_l2(n(od.grad), go), rel_l2(n(nd.grad), gn))
 
 
+@pytest.mark.parametrize("H,R,F,M", [(3, 16, 4, 300), (2, 9, 4, 2500), (400, 8, 2, 640), (1, 40, 6, 77)])
+def test_facet_hint_changes_speed_only(H, R, F, M):
+    """``points_per_facet`` (ABI v9: ``facet_points``) tells the kernels where the facets are, so that no block of points
+    straddles two of them.  A layout hint: the bitmaps are the same BITS with and without it (integer accumulators), the ray
+    counters equal, the gradients equal to rounding (bit-equal when no point's samples are cut into chunks); a hint that does
+    not divide P is refused."""
+    from artist_amd import trace_rays
+    P = F * M
+    o, nrm, inc, both, tix, c, pn, dims, res = _random_scene(H, R, P, 64, 48, seed=F * 100 + M)
+    bd = both.to(DEV)
+    w = torch.rand((H, 48, 64), generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def run(**kw):
+        od, nd = o.to(DEV).requires_grad_(True), nrm.to(DEV).requires_grad_(True)
+        flux, fac = trace_rays(od, nd, inc.to(DEV), bd[..., 0], bd[..., 1], tix.to(DEV), c.to(DEV), pn.to(DEV), dims.to(DEV),
+                               ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=res, **kw)
+        (flux * w).sum().backward()
+        return n(flux), n(fac), n(od.grad), n(nd.grad)
+
+    plain, hinted = run(), run(points_per_facet=M)
+    np.testing.assert_array_equal(hinted[0], plain[0])
+    np.testing.assert_array_equal(hinted[1], plain[1])
+    assert rel_l2(hinted[2], plain[2]) < 1e-6 and rel_l2(hinted[3], plain[3]) < 1e-6
+    o_flux, o_fac = oracle.trace_fwd(o.numpy(), nrm.numpy(), inc.numpy(), both[..., 0].numpy(), both[..., 1].numpy(),
+                                     tix.numpy(), c.numpy(), pn.numpy(), dims.numpy(), res, 0.7, 0.05, 0.9)
+    np.testing.assert_array_equal(hinted[1], o_fac)
+    assert rel_l2(hinted[0], o_flux) < 1e-5
+    with pytest.raises(ValueError):
+        run(points_per_facet=M + 1 if P % (M + 1) else M + 2)
+
+
 def test_chief_rays_miss_but_scattered_rays_hit():
     """A heliostat aimed just beside the target: no chief ray reaches it (the workgroup's window is EMPTY), but the sun
     shape scatters part of the rays onto the edge.  Those rays must all be handled as strays - forward (accumulators)
