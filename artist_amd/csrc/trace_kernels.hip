@@ -1960,7 +1960,7 @@ static FwdConfig fwd_config()
     c.p_block_bwd_fixed = getenv("ARTIST_HIP_BWD_PBLOCK") != nullptr;
     c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
     if (c.p_block < 64) c.p_block = 64;
-    c.exact_pblock = env_int("ARTIST_HIP_PBLOCK_EXACT", 0) != 0;
+    c.exact_pblock = env_int("ARTIST_HIP_PBLOCK_EXACT", 1) != 0;   // balanced blocks; a partial trip costs what its active waves issue
     c.facet_points = 0;
     c.p_block_bwd = env_int("ARTIST_HIP_BWD_PBLOCK", 2048);
     if (c.p_block_bwd < 64) c.p_block_bwd = 64;
@@ -2150,7 +2150,6 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
     FwdConfig cfg = fwd_config();
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
-    cfg.facet_points = (int)facet_points;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (accum == nullptr || (reinterpret_cast<uintptr_t>(accum) % 16) != 0) return ART_EINVAL;
     // unit of the pixel accumulators: 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|
@@ -2168,6 +2167,9 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
                           a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
         if (lean && T > 0 && Tc == 0) {
+            // (the facet hint serves the lean kernels only: with blocking on, facet-sized items measured SLOWER - 37.8 vs
+            //  30.5 ms forward + backward on the blocking bench's field - and the cylinder kernels were not measured)
+            cfg.facet_points = (int)facet_points;
             // Balanced blocks whose trips need not be full (a trip costs what its active waves issue), and - when the
             // caller says where the facets are - one block per facet or per equal part of a facet: every item pays a window
             // phase, a clear and a flush (~17 us), so fewer and larger blocks win as long as no block straddles two facets.
@@ -2298,7 +2300,6 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     const bool il = interleaved_layout(a);
     FwdConfig cfg = fwd_config();
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
-    cfg.facet_points = (int)facet_points;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
         // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, two trips of points
@@ -2306,6 +2307,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         if (lean) {
             cfg.block = kLeanBwdThreads;
             cfg.exact_pblock = true;
+            cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
             if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
         }
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
@@ -2395,12 +2397,12 @@ extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P,
     FwdConfig cfg = fwd_config();
     if (cfg.variant != 0) return 0;
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return 0;
-    cfg.facet_points = (int)facet_points;
     a.facet_points = (int)P; a.blocks_per_facet = 1;
     window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
     int64_t chunks = a.n_rchunks;
     cfg.block = kLeanBwdThreads;                   // the lean kernel's geometry (art_trace_bwd picks one of the two)
     cfg.exact_pblock = true;
+    cfg.facet_points = (int)facet_points;
     if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
     window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
     chunks = std::max<int64_t>(chunks, a.n_rchunks);

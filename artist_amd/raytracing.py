@@ -14,6 +14,8 @@ the sum over ranks equals the single-rank result.
 """
 from __future__ import annotations
 
+import os
+
 import logging
 
 import weakref
@@ -193,6 +195,8 @@ class HeliostatRayTracer:
     def _points_per_facet(self, points) -> int:
         """The group's surface tensors are facet-major ``[H, F * M, 4]`` (heliostat_group.py:26-63): tell the kernels M, so
         that a block of points never holds two facets' images (a layout hint - results do not depend on it)."""
+        if os.environ.get("ARTIST_AMD_FACET_HINT", "1") == "0":      # A/B switch
+            return 0
         facets = int(getattr(self.heliostat_group, "number_of_facets_per_heliostat", 0) or 0)
         n_points = int(points.shape[1])
         return n_points // facets if facets > 1 and n_points % facets == 0 else 0
