@@ -513,6 +513,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(
             int x4 = threadIdx.x % W4, y = threadIdx.x / W4;
             const int dx = blockDim.x % W4, dy = blockDim.x / W4;
             const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f);
+#pragma unroll 4
             for (int k = threadIdx.x; k < Hh * W4; k += blockDim.x) {
                 const float4 v = f4[k];
                 const int x = 4 * x4;
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(
     if ((int)blockDim.x % W == 0) {                 // a thread owns one column (the per-thread summation order is unchanged)
         const int j = threadIdx.x % W, di = blockDim.x / W;
         const CropColumn col = crop_column(m, j);
+#pragma unroll 4      // four rows' taps in flight: the loop is a chain of L2 round trips otherwise
         for (int i = threadIdx.x / W; i < Hh; i += di) {
             float v00, v01, v10, v11, ty;
             const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
@@ -595,6 +597,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_bwd_kernel(
     if ((int)blockDim.x % W == 0) {
         const int j = threadIdx.x % W, di = blockDim.x / W;
         const CropColumn col = crop_column(m, j);
+#pragma unroll 4
         for (int i = threadIdx.x / W; i < Hh; i += di) {
             float v00, v01, v10, v11, ty;
             const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);

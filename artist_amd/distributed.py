@@ -38,26 +38,45 @@ def all_reduce_sum_async(tensor: torch.Tensor, group=None):
     return None
 
 
-def gather_owned_rows(local_rows: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+class _PendingRows:
+    """Handle of ``gather_owned_rows(..., async_op=True)``: ``wait()`` returns the gathered tensor."""
+
+    def __init__(self, work, finish):
+        self._work, self._finish = work, finish
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+        return self._finish()
+
+
+def gather_owned_rows(local_rows: torch.Tensor, n_total: int, group=None, async_op: bool = False):
     """Rows owned by each rank (heliostat ``i`` -> rank ``i mod N``) -> the whole ``[n_total, ...]`` tensor on every rank.
 
     This is what the reference's ``all_reduce(SUM)`` of the control-point gradients produces
     (artist/optim/surface_reconstructor.py:767-777) when every heliostat lives on exactly one rank: the summands are
     row-disjoint, so the sum IS a gather - with (N-1)/N of the tensor on the wire instead of 2(N-1)/N, and no zero fill.
-    Ragged shards (``n_total`` not a multiple of the world size) fall back to that all-reduce."""
+    Ragged shards (``n_total`` not a multiple of the world size) fall back to that all-reduce.
+    ``async_op=True`` returns a handle whose ``wait()`` gives the tensor: the exchange then travels while the caller's
+    optimiser step (which needs the own rows only) runs."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return local_rows
+        return _PendingRows(None, lambda: local_rows) if async_op else local_rows
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if n_total % world != 0:
         full = local_rows.new_zeros((n_total,) + tuple(local_rows.shape[1:]))
         full[rank::world] = local_rows
+        if async_op:
+            return _PendingRows(dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group, async_op=True), lambda: full)
         return all_reduce_sum(full, group)
     rows = local_rows.shape[0]
     gathered = local_rows.new_empty((world * rows,) + tuple(local_rows.shape[1:]))     # rank-major concatenation
-    dist.all_gather_into_tensor(gathered, local_rows.contiguous(), group=group)
-    # row r * rows + j of `gathered` is heliostat j * world + r
-    return gathered.reshape((world, rows) + tuple(local_rows.shape[1:])).transpose(0, 1).reshape(
-        (n_total,) + tuple(local_rows.shape[1:]))
+    work = dist.all_gather_into_tensor(gathered, local_rows.contiguous(), group=group, async_op=async_op)
+
+    def finish():
+        # row r * rows + j of `gathered` is heliostat j * world + r
+        return gathered.reshape((world, rows) + tuple(local_rows.shape[1:])).transpose(0, 1).reshape(
+            (n_total,) + tuple(local_rows.shape[1:]))
+    return _PendingRows(work, finish) if async_op else finish()
 
 
 def reduce_flux_per_target(flux_local: torch.Tensor, target_idx_local: torch.Tensor, n_targets: int,

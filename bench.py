@@ -255,9 +255,10 @@ def main():
                 loss.backward()
                 # surface_reconstructor.py:767-777: every rank ends with the field's gradient.  The shards are
                 # row-disjoint, so the reference's all_reduce(SUM) is an all-gather of the own rows (half the bytes)
-                field_grad = gather_owned_rows(cp.grad, H_total)
+                pending_grad = gather_owned_rows(cp.grad, H_total, async_op=True)    # travels during the optimiser step
                 optimizer.step()                                 # :779 - Adam on the rows this rank owns
-                del field_grad
+                field_grad = pending_grad.wait()
+                del field_grad, pending_grad
             if pending is not None:
                 pending.wait()
         return per_target

@@ -75,6 +75,8 @@ def _worker(rank, world, port, case, out_dir):
             want = (torch.arange(n_rows, dtype=torch.float32) + 1)[:, None, None].expand(n_rows, 2, 3)
             got = gather_owned_rows(want[owned_heliostats(n_rows, world, rank)].contiguous(), n_rows)
             assert torch.equal(got, want), (n_rows, got[:, 0, 0])
+            pending = gather_owned_rows(want[owned_heliostats(n_rows, world, rank)].contiguous(), n_rows, async_op=True)
+            assert torch.equal(pending.wait(), want)                     # the overlapped form bench.py uses
         (out_dir / f"ok_{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
