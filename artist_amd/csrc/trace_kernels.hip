@@ -141,6 +141,7 @@ struct Window {
                           // ray splats rows iu and iu+1 and belongs to the pass that holds row iu
     float scale;          // S  (power of two): window cells count units of 1 / S
     int shift;            // log2(global accumulator units per cell unit) = (28 - ex_g) - log2 S  (>= 0)
+    int pad_e, pad_u;     // how far (pixels) a point's scattered rays land from its chief ray (~4.2 sigma of the sun shape)
 };
 
 // Wave reductions on the DPP network (VALU ops, a few cycles each) instead of __shfl_xor (ds_bpermute through the LDS
@@ -317,7 +318,7 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
         usq = row_reduce<kSum>(has ? s_red[12][w] : 0.0f);
     }
     if (tid == 0) {
-        Window win = {0, 0, 0, 0, 0, 1, 1.0f, 0};
+        Window win = {0, 0, 0, 0, 0, 1, 1.0f, 0, 0, 0};
         if (emax >= emin) {
             // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
             // worth keeping in the window (~4.2 sigma); +2 px for the bilinear footprint and rounding.
@@ -353,6 +354,7 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             }
             if (tw > a.tile_cap / 2) { e0 += (tw - a.tile_cap / 2) / 2; tw = a.tile_cap / 2; }   // absurdly wide bitmaps
             win.e0 = e0; win.u0 = u0; win.tw = tw; win.th = th;
+            win.pad_e = (int)pad_e; win.pad_u = (int)pad_u;
             // larger footprints (near, oblique heliostats) are swept in several passes over row bands
             win.ths = min(th, a.tile_cap / tw);
             win.npass = win.ths >= th ? 1 : (th - 1 + win.ths - 2) / (win.ths - 1);
@@ -1563,6 +1565,8 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
 //   dL/dbu = (cle (g1 - g4) + che (g2 - g3)) I
 // --------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) float lds_f32;
+constexpr int kPackTrips = 4;          // a block of the lean backward kernel holds at most this many trips of points
+constexpr int kPackPoints = 2560;      // ... and this many points when its edge points are packed (room for the permutation)
 
 template <bool INTERLEAVED, bool ATOMIC_OUT>
 __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const float* __restrict__ grad_flux,
@@ -1572,6 +1576,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     extern __shared__ __attribute__((aligned(16))) float gtile[];
     __shared__ float s_red[13][16];
     __shared__ Window s_win;
+    __shared__ int s_edge[kPackTrips * 16 + 1];      // edge points per (trip, wave), then their exclusive scan; [last] = total
 
     const int pblock = item.pblock;
     const int h = item.h;
@@ -1603,6 +1608,55 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const float kI = (a.mag * a.k_ext) * a.k_refl;
     const float sx = pl.wm1 / pl.w, sz = pl.hm1 / pl.h;
     const float Wf = (float)a.W, Hf = (float)a.Hh;
+    // ---- edge points to the back of the block --------------------------------------------------------------------
+    // A ray outside the window gathers its four dL/dflux values from global memory and its wave waits for them - and,
+    // loads retiring in order, for its whole distortion ring.  The strays come from the points whose chief ray lands near
+    // the window's border (or beyond it): with the points in mirror order every wave holds a few of them and stalls in
+    // almost half of its ray steps.  A stable partition - interior points first, edge points last, both in mirror order -
+    // gathers them in the block's last waves, so that the other waves run without a stall (and the interior waves' stream
+    // stays coalesced: they skip a point here and there).  perm[j] = index within the block of the point in slot j.
+    unsigned short* perm = reinterpret_cast<unsigned short*>(gtile + a.tile_cap + 2);
+    const int n_pts = p1 - p0;
+    const bool packed = a.pack_edge != 0 && win.npass == 1 && n_pts <= kPackPoints && n_pts <= kPackTrips * (int)blockDim.x &&
+                        win.tw >= 2 && win.th >= 2;
+    if (packed) {
+        const int me = (win.pad_e * a.pack_edge) >> 6, mu = (win.pad_u * a.pack_edge) >> 6;      // margin = pad * pack_edge / 64
+        unsigned long long flags[kPackTrips];
+#pragma unroll
+        for (int k = 0; k < kPackTrips; ++k) {
+            const int i = k * (int)blockDim.x + tid;
+            bool edge = false;
+            if (i < n_pts) {
+                const float4 o = org[p0 + i];
+                float4 d; float s_;
+                reflect(inc, nrm[p0 + i], d, s_);
+                const RaySplat c = hit_and_weights(pl, o, plane_numer(pl, o), d.x, d.y, d.z, Wf, Hf);
+                const int le = c.ie - win.e0, lu = c.iu - win.u0;
+                edge = !c.valid || le < me || le > win.tw - 2 - me || lu < mu || lu > win.th - 2 - mu;
+            }
+            flags[k] = ballot64(edge);
+            if (lane == 0) s_edge[k * 16 + wave] = __popcll(flags[k]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int k = 0; k < kPackTrips; ++k)
+                for (int w = 0; w < nwaves; ++w) { const int c = s_edge[k * 16 + w]; s_edge[k * 16 + w] = run; run += c; }
+            s_edge[kPackTrips * 16] = run;
+        }
+        __syncthreads();
+        const int n_edge = s_edge[kPackTrips * 16];
+#pragma unroll
+        for (int k = 0; k < kPackTrips; ++k) {
+            const int i = k * (int)blockDim.x + tid;
+            if (i < n_pts) {
+                const int before = s_edge[k * 16 + wave] + __popcll(flags[k] & ((1ull << lane) - 1ull));   // edge points ahead of i
+                const bool edge = (flags[k] >> lane) & 1ull;
+                perm[edge ? n_pts - n_edge + before : i - before] = (unsigned short)i;
+            }
+        }
+        __syncthreads();
+    }
     const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
     const float lds_base = (float)(unsigned)(size_t)(lds_f32*)gtile;
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
@@ -1650,7 +1704,8 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     // an empty window (no chief ray of the block reaches the target) holds no ray: every valid ray is then a stray
     const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
     const float addr_hi_f = lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2));
-    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+    for (int j = tid; j < n_pts; j += blockDim.x) {
+        const int p = p0 + (packed ? (int)perm[j] : j);
         const float4 o = org[p];
         const float4 n = nrm[p];
         float4 d; float s;
@@ -2304,11 +2359,18 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     if (cfg.variant == 0) {
         // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, two trips of points
         const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0;
+        size_t perm_bytes = 0;
         if (lean) {
             cfg.block = kLeanBwdThreads;
             cfg.exact_pblock = true;
             cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
             if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
+            // edge points packed into the block's last waves (trace_bwd_item_lean): the permutation lives behind the window
+            a.pack_edge = std::min(std::max(env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
+            if (a.pack_edge != 0) {
+                perm_bytes = 2 * kPackPoints;
+                cfg.tile_cap = std::min<int>(cfg.tile_cap, (int)((160 * 1024 - 1408 - perm_bytes - 8) / 4) / 64 * 64);
+            }
         }
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         // A small field is cut into sample chunks to fill the chip; the chunks of a point then write partial gradients
@@ -2326,7 +2388,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
-        const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float);
+        const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float) + perm_bytes;
         if (atomic_out) {
             go = reinterpret_cast<float4*>(grad_scratch);
             gn = go + (int64_t)a.n_rchunks * H * P;
