@@ -790,7 +790,12 @@ __device__ __forceinline__ unsigned long long ballot64(bool c) { return __builti
 
 constexpr int kLeanFwdPoints = 2560;   // points per item of the lean forward kernel when the facet structure is known
 #ifndef ART_RING_DEPTH
-#define ART_RING_DEPTH 8       // (4: A/B build that prices the prefetch distance)
+#define ART_RING_DEPTH 8       // forward: 2 / 4 / 6 / 8 slots (4 costs the forward 4 %)
+#endif
+#ifndef ART_RING_DEPTH_BWD
+#define ART_RING_DEPTH_BWD 2   // backward: same-box sweep 8 / 6 / 4 / 2 slots = 3.76 / 3.71 / 3.67 / 3.65 ms (125 heliostats: 0.517 -> 0.489):
+                               // with twelve waves of 0.7 us ray steps the stream's latency is covered anyway, and a stray's
+                               // vmcnt(0) has less to wait for
 #endif
 template <bool INTERLEAVED>
 __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
@@ -984,8 +989,16 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             // compiler copy freshly requested slots around and wait for them at once); the rays that pad the last round
             // re-read sample nr - 1 and are masked out.
             float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
-            request(0, su0, se0); request(1, su1, se1); request(2, su2, se2); request(3, su3, se3);
-            request(4, su4, se4); request(5, su5, se5); request(6, su6, se6); request(7, su7, se7);
+            request(0, su0, se0); request(1, su1, se1);
+#if ART_RING_DEPTH >= 4
+            request(2, su2, se2); request(3, su3, se3);
+#endif
+#if ART_RING_DEPTH >= 6
+            request(4, su4, se4); request(5, su5, se5);
+#endif
+#if ART_RING_DEPTH >= 8
+            request(6, su6, se6); request(7, su7, se7);
+#endif
 #define ART_RING_STEP(j)                                                            \
             {                                                                       \
                 /* the slot's value moves to registers of its own first, so that the new request can land in the */ \
@@ -999,9 +1012,15 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 __builtin_amdgcn_sched_barrier(0);                                  \
             }
             for (int k = 0; k < nr; k += ART_RING_DEPTH) {
-                ART_RING_STEP(0) ART_RING_STEP(1) ART_RING_STEP(2) ART_RING_STEP(3)
-#if ART_RING_DEPTH == 8
-                ART_RING_STEP(4) ART_RING_STEP(5) ART_RING_STEP(6) ART_RING_STEP(7)
+                ART_RING_STEP(0) ART_RING_STEP(1)
+#if ART_RING_DEPTH >= 4
+                ART_RING_STEP(2) ART_RING_STEP(3)
+#endif
+#if ART_RING_DEPTH >= 6
+                ART_RING_STEP(4) ART_RING_STEP(5)
+#endif
+#if ART_RING_DEPTH >= 8
+                ART_RING_STEP(6) ART_RING_STEP(7)
 #endif
             }
 #undef ART_RING_STEP
@@ -1811,21 +1830,37 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         };
         if (nr >= 8) {                                // the distortion ring of trace_fwd_item_lean
             float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
-            request(0, su0, se0); request(1, su1, se1); request(2, su2, se2); request(3, su3, se3);
-            request(4, su4, se4); request(5, su5, se5); request(6, su6, se6); request(7, su7, se7);
+            request(0, su0, se0); request(1, su1, se1);
+#if ART_RING_DEPTH_BWD >= 4
+            request(2, su2, se2); request(3, su3, se3);
+#endif
+#if ART_RING_DEPTH_BWD >= 6
+            request(4, su4, se4); request(5, su5, se5);
+#endif
+#if ART_RING_DEPTH_BWD >= 8
+            request(6, su6, se6); request(7, su7, se7);
+#endif
 #define ART_RING_STEP(j)                                                            \
             {                                                                       \
                 float u, e;                                                         \
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(u), "=v"(e) : "v"(su##j), "v"(se##j) : "memory"); \
-                request(k + j + 8, su##j, se##j);                                   \
+                request(k + j + ART_RING_DEPTH_BWD, su##j, se##j);                      \
                 trace_one(u, e, k + j < nr ? ~0ull : 0ull);                          \
                 /* a ray's arithmetic stays inside its step: hoisting the next step's head above it made the */ \
                 /* compiler spill the ray's live values around the hoisted code */   \
                 __builtin_amdgcn_sched_barrier(0);                                  \
             }
-            for (int k = 0; k < nr; k += 8) {
-                ART_RING_STEP(0) ART_RING_STEP(1) ART_RING_STEP(2) ART_RING_STEP(3)
-                ART_RING_STEP(4) ART_RING_STEP(5) ART_RING_STEP(6) ART_RING_STEP(7)
+            for (int k = 0; k < nr; k += ART_RING_DEPTH_BWD) {
+                ART_RING_STEP(0) ART_RING_STEP(1)
+#if ART_RING_DEPTH_BWD >= 4
+                ART_RING_STEP(2) ART_RING_STEP(3)
+#endif
+#if ART_RING_DEPTH_BWD >= 6
+                ART_RING_STEP(4) ART_RING_STEP(5)
+#endif
+#if ART_RING_DEPTH_BWD >= 8
+                ART_RING_STEP(6) ART_RING_STEP(7)
+#endif
             }
 #undef ART_RING_STEP
         } else {

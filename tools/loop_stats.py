@@ -2,7 +2,7 @@
 """Instruction counts per ray step of the lean trace kernels, from the compiler's assembly.
 
 usage: python tools/loop_stats.py [trace_kernels.s]   (default: compile artist_amd/csrc/trace_kernels.hip to /tmp first)
-A ray step of the ring loop starts at its `s_waitcnt vmcnt(7)`; the eight steps of a round are averaged.
+A ray step of the ring loop starts at its `s_waitcnt vmcnt(depth - 1)`; the steps of a round are averaged.
 """
 import collections
 import pathlib
@@ -21,15 +21,24 @@ else:
 lines = asm.read_text().split("\n")
 
 
-def stats(name, pat):
+SRC = (ROOT / "artist_amd" / "csrc" / "trace_kernels.hip").read_text()
+
+
+def ring_depth(macro):
+    m = re.search(r"#define\s+" + macro + r"\s+(\d+)", SRC)
+    return int(m.group(1)) if m else 8
+
+
+def stats(name, pat, depth):
     s = [i for i, l in enumerate(lines) if l.startswith(pat)][0]
     e = next(i for i in range(s, len(lines)) if lines[i].strip().startswith(".Lfunc_end"))
-    w = [i for i in range(s, e) if "s_waitcnt vmcnt(7)" in lines[i]]
+    # a ring step: the wait for its slot, then the (inline asm) copy of the slot into the ray's own registers
+    w = [i for i in range(s, e) if f"s_waitcnt vmcnt({depth - 1})" in lines[i] and "#ASMSTART" in lines[i + 1] and "v_mov_b32" in lines[i + 2]]
     span = None
-    for k in range(len(w) - 7):
-        d = [w[k + i + 1] - w[k + i] for i in range(7)]
+    for k in range(len(w) - depth + 1):
+        d = [w[k + i + 1] - w[k + i] for i in range(depth - 1)]
         if max(d) - min(d) < 40:
-            span = (w[k], w[k + 7] + sum(d) // 7)
+            span = (w[k], w[k + depth - 1] + sum(d) // (depth - 1))
             break
     if span is None:
         print(name, "ring loop not found")
@@ -55,9 +64,9 @@ def stats(name, pat):
                 if m:
                     meta[m.group(1)] = int(m.group(2))
             break
-    print(f"{name}: per ray " + ", ".join(f"{k} {v / 8:.1f}" for k, v in sorted(c.items())) +
-          f"; v_mov {sum(k.startswith('v_mov') for k in ins) / 8:.1f}, scratch in loop {sum(k.startswith('scratch') for k in ins)}; {meta}")
+    print(f"{name} (ring of {depth}): per ray " + ", ".join(f"{k} {v / depth:.1f}" for k, v in sorted(c.items())) +
+          f"; v_mov {sum(k.startswith('v_mov') for k in ins) / depth:.1f}, scratch in loop {sum(k.startswith('scratch') for k in ins)}; {meta}")
 
 
-stats("forward lean (interleaved)", "_ZN3art20trace_fwd_lds_kernelILb1ELb0ELb0ELb1EEEv")
-stats("backward lean (interleaved)", "_ZN3art20trace_bwd_lds_kernelILb1ELb0ELb0ELb0ELb1EEEv")
+stats("forward lean (interleaved)", "_ZN3art20trace_fwd_lds_kernelILb1ELb0ELb0ELb1EEEv", ring_depth("ART_RING_DEPTH"))
+stats("backward lean (interleaved)", "_ZN3art20trace_bwd_lds_kernelILb1ELb0ELb0ELb0ELb1EEEv", ring_depth("ART_RING_DEPTH_BWD"))
