@@ -789,6 +789,68 @@ __device__ __forceinline__ unsigned f32_bits(float x) { return __builtin_bit_cas
 __device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
 constexpr int kLeanFwdPoints = 2560;   // points per item of the lean forward kernel when the facet structure is known
+constexpr int kPackTrips = 4;          // a block whose edge points are packed holds at most this many trips of points
+constexpr int kPackPoints = 2560;      // ... and this many points (room for the permutation)
+
+// Stable partition of a block's points - interior points in mirror order, then (or, see below, just before the partial
+// last trip) the EDGE points: those whose chief ray lands within a.pack_edge / 64 scatter pads of the window's border, or
+// outside it.  perm[j] = index within the block of the point that slot j serves (thread j % blockDim, trip j / blockDim).
+// s_edge: kPackTrips * 16 + 1 ints of LDS.  Ends with a barrier.
+__device__ __forceinline__ void pack_edge_points(const TraceArgs& a, const Plane& pl, const float4 inc, const float4* __restrict__ org,
+                                                 const float4* __restrict__ nrm, const int p0, const int n_pts, const Window& win,
+                                                 const int pack_edge, int* s_edge, unsigned short* perm)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const float Wf = (float)a.W, Hf = (float)a.Hh;
+    {
+        const int me = (win.pad_e * pack_edge) >> 6, mu = (win.pad_u * pack_edge) >> 6;      // margin = pad * pack_edge / 64
+        unsigned long long flags[kPackTrips];
+#pragma unroll
+        for (int k = 0; k < kPackTrips; ++k) {
+            const int i = k * (int)blockDim.x + tid;
+            bool edge = false;
+            if (i < n_pts) {
+                const float4 o = org[p0 + i];
+                float4 d; float s_;
+                reflect(inc, nrm[p0 + i], d, s_);
+                const RaySplat c = hit_and_weights(pl, o, plane_numer(pl, o), d.x, d.y, d.z, Wf, Hf);
+                const int le = c.ie - win.e0, lu = c.iu - win.u0;
+                edge = !c.valid || le < me || le > win.tw - 2 - me || lu < mu || lu > win.th - 2 - mu;
+            }
+            flags[k] = ballot64(edge);
+            if (lane == 0) s_edge[k * 16 + wave] = __popcll(flags[k]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int k = 0; k < kPackTrips; ++k)
+                for (int w = 0; w < nwaves; ++w) { const int c = s_edge[k * 16 + w]; s_edge[k * 16 + w] = run; run += c; }
+            s_edge[kPackTrips * 16] = run;
+        }
+        __syncthreads();
+        const int n_edge = s_edge[kPackTrips * 16];
+        // Where the edge points go.  A small partial trip at the end of the block is the best place: its few waves have the
+        // CU almost to themselves and their stalls cost little (2500 points on 768 threads: 3.71 ms with the edge points there,
+        // 3.84 ms with them at the end of the last full trip).  A large partial trip is a bad one: its waves walk one trip more
+        // than the others and should not be the slow ones as well (1250 points: 0.548 ms at the end, 0.527 ms at the end of
+        // the full trip, 125 heliostats).
+        const int full = (n_pts / (int)blockDim.x) * (int)blockDim.x;
+        const bool at_trip_end = full > 0 && n_edge <= full && 2 * (n_pts - full) >= (int)blockDim.x;
+        const int e_first = at_trip_end ? full - n_edge : n_pts - n_edge;
+#pragma unroll
+        for (int k = 0; k < kPackTrips; ++k) {
+            const int i = k * (int)blockDim.x + tid;
+            if (i < n_pts) {
+                const int before = s_edge[k * 16 + wave] + __popcll(flags[k] & ((1ull << lane) - 1ull));   // edge points ahead of i
+                const bool edge = (flags[k] >> lane) & 1ull;
+                const int q = i - before;                                                                  // interior points ahead of i
+                perm[edge ? e_first + before : (q < e_first ? q : q + n_edge)] = (unsigned short)i;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 #ifndef ART_RING_DEPTH
 #define ART_RING_DEPTH 8       // forward: 2 / 4 / 6 / 8 slots (4 costs the forward 4 %)
 #endif
@@ -843,6 +905,9 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
     const float Wf = (float)a.W, Hf = (float)a.Hh;
+    // (Packing the edge points into the block's last waves, which takes 8 % off the backward kernel, was measured here too:
+    //  3.25 -> 3.32 ... 3.43 ms for margins of 1/4 ... 3/4 of the scatter pad - a stray costs this kernel its atomics, which
+    //  packing does not remove, and the partition is paid by every item.)
     const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
     // |I| S = |r.m| * kS for a front-facing ray:  I = ((mag (-a)) k_ext) k_refl  (heliostat_ray_tracer.py:482-487, geometry.py:139)
     const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
@@ -1584,8 +1649,6 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
 //   dL/dbu = (cle (g1 - g4) + che (g2 - g3)) I
 // --------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) float lds_f32;
-constexpr int kPackTrips = 4;          // a block of the lean backward kernel holds at most this many trips of points
-constexpr int kPackPoints = 2560;      // ... and this many points when its edge points are packed (room for the permutation)
 
 template <bool INTERLEAVED, bool ATOMIC_OUT>
 __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const float* __restrict__ grad_flux,
@@ -1638,53 +1701,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const int n_pts = p1 - p0;
     const bool packed = a.pack_edge != 0 && win.npass == 1 && n_pts <= kPackPoints && n_pts <= kPackTrips * (int)blockDim.x &&
                         win.tw >= 2 && win.th >= 2;
-    if (packed) {
-        const int me = (win.pad_e * a.pack_edge) >> 6, mu = (win.pad_u * a.pack_edge) >> 6;      // margin = pad * pack_edge / 64
-        unsigned long long flags[kPackTrips];
-#pragma unroll
-        for (int k = 0; k < kPackTrips; ++k) {
-            const int i = k * (int)blockDim.x + tid;
-            bool edge = false;
-            if (i < n_pts) {
-                const float4 o = org[p0 + i];
-                float4 d; float s_;
-                reflect(inc, nrm[p0 + i], d, s_);
-                const RaySplat c = hit_and_weights(pl, o, plane_numer(pl, o), d.x, d.y, d.z, Wf, Hf);
-                const int le = c.ie - win.e0, lu = c.iu - win.u0;
-                edge = !c.valid || le < me || le > win.tw - 2 - me || lu < mu || lu > win.th - 2 - mu;
-            }
-            flags[k] = ballot64(edge);
-            if (lane == 0) s_edge[k * 16 + wave] = __popcll(flags[k]);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int k = 0; k < kPackTrips; ++k)
-                for (int w = 0; w < nwaves; ++w) { const int c = s_edge[k * 16 + w]; s_edge[k * 16 + w] = run; run += c; }
-            s_edge[kPackTrips * 16] = run;
-        }
-        __syncthreads();
-        const int n_edge = s_edge[kPackTrips * 16];
-        // Where the edge points go.  A small partial trip at the end of the block is the best place: its few waves have the
-        // CU almost to themselves and their stalls cost little (2500 points on 768 threads: 3.71 ms with the edge points there,
-        // 3.84 ms with them at the end of the last full trip).  A large partial trip is a bad one: its waves walk one trip more
-        // than the others and should not be the slow ones as well (1250 points: 0.548 ms at the end, 0.527 ms at the end of
-        // the full trip, 125 heliostats).
-        const int full = (n_pts / (int)blockDim.x) * (int)blockDim.x;
-        const bool at_trip_end = full > 0 && n_edge <= full && 2 * (n_pts - full) >= (int)blockDim.x;
-        const int e_first = at_trip_end ? full - n_edge : n_pts - n_edge;
-#pragma unroll
-        for (int k = 0; k < kPackTrips; ++k) {
-            const int i = k * (int)blockDim.x + tid;
-            if (i < n_pts) {
-                const int before = s_edge[k * 16 + wave] + __popcll(flags[k] & ((1ull << lane) - 1ull));   // edge points ahead of i
-                const bool edge = (flags[k] >> lane) & 1ull;
-                const int q = i - before;                                                                  // interior points ahead of i
-                perm[edge ? e_first + before : (q < e_first ? q : q + n_edge)] = (unsigned short)i;
-            }
-        }
-        __syncthreads();
-    }
+    if (packed) pack_edge_points(a, pl, inc, org, nrm, p0, n_pts, win, a.pack_edge, s_edge, perm);
     const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
     const float lds_base = (float)(unsigned)(size_t)(lds_f32*)gtile;
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
