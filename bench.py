@@ -387,7 +387,7 @@ def main():
                              "unit": "GB/s", "source": f"replayed from {HBM_PEAK_FILE.relative_to(ROOT)}",
                              "frac_of_measured_read": achieved / measured_peak["read"]},
                          # what binds the kernel (neither of the contract's two roofs): replayed analysis, DESIGN.md 4.0 / 4.1
-                         "limiter_note": "not HBM: ~64 % of the kernel is vector issue of the ray arithmetic (reference operation order, "
+                         "limiter_note": "not HBM: about two thirds of the kernel are vector issue of the ray arithmetic (reference operation order, "
                                          "no FMA contraction), the rest LDS-atomic, stray-ray and stream stalls - ablation table in DESIGN.md "
                                          "section 4.4, issue rates in 4.0 (profiles/r02_issue_bench.json, r02_ablation.txt); stated from "
                                          "profiles/, not measured by this run"},

@@ -1511,11 +1511,13 @@ def test_scenario_file_to_flux(golden, name):
 
 
 @pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_PERSISTENT="0"), dict(ARTIST_HIP_LEAN="0"), dict(ARTIST_HIP_FWD_PBLOCK="512", ARTIST_HIP_BWD_PBLOCK="640"),
-                                   dict(ARTIST_HIP_FWD_BLOCKS="4096")])
+                                   dict(ARTIST_HIP_FWD_BLOCKS="4096"), dict(ARTIST_HIP_BWD_PACK="0"), dict(ARTIST_HIP_BWD_PACK="200"),
+                                   dict(ARTIST_HIP_FWD_TILE_KB="24", ARTIST_HIP_BWD_PACK="64")])
 def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     """The windowed kernels hand out (heliostat, point block, sample chunk) items through a work queue: persistent
     workgroups (default) or one workgroup per item, the lean or the generic ray body, other point-block sizes, samples cut
-    into more chunks.  However the items are dealt, the bitmaps are the same BITS (integer pixel accumulators); the
+    into more chunks, the backward kernel's edge points packed or not (and with a margin that makes every point an edge point,
+    and with a small window).  However the items are dealt, the bitmaps are the same BITS (integer pixel accumulators); the
     gradients are the same bits as long as a point's samples are summed in the same order (everything but the chunking)."""
     from artist_amd import trace_rays
     d = golden("mid_256")
