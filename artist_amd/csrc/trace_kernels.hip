@@ -36,6 +36,10 @@ __device__ __forceinline__ unsigned cvt_nearest_u32(float x)
 
 // A contribution that bypasses the window (a stray ray): |v| in accumulator units, rounded to nearest.
 __device__ __forceinline__ unsigned long long to_accum(float v, float scale_g) { return (unsigned long long)cvt_nearest_u32(fabsf(v) * scale_g); }
+// The windows' cell unit in accumulator units (log2), and a weighted intensity in cell units handed to an accumulator: w * Is
+// with Is = |I| * (cell scale), the very product a window ray adds to its LDS cell.
+constexpr int kCellShift = 7;
+__device__ __forceinline__ unsigned long long cell_to_accum(float w_times_Is) { return (unsigned long long)cvt_nearest_u32(w_times_Is) << kCellShift; }
 
 // --------------------------------------------------------------------------------------------
 // Forward, global-atomic splat (ARTIST_HIP_FWD=global: the plain formulation, kept as an independent cross-check of the
@@ -86,10 +90,13 @@ __global__ __launch_bounds__(kBlock) void trace_fwd_kernel(TraceArgs a, float* _
                 // flat row k is output row Hh-1-k (flip, heliostat_ray_tracer.py:778)
                 unsigned long long* row_hi = bitmap + (int64_t)(a.Hh - 2 - sp.iu) * a.W + sp.ie;   // flat row iu+1
                 unsigned long long* row_lo = row_hi + a.W;                                          // flat row iu
-                atomicAdd(row_hi, to_accum(sp.cle * sp.chu * I, a.scale_g));        // pixel 1
-                atomicAdd(row_hi + 1, to_accum(sp.che * sp.chu * I, a.scale_g));    // pixel 2
-                atomicAdd(row_lo + 1, to_accum(sp.che * sp.clu * I, a.scale_g));    // pixel 3
-                atomicAdd(row_lo, to_accum(sp.cle * sp.clu * I, a.scale_g));        // pixel 4
+                // rounded to the windowed kernels' cell unit, product by product as in trace_fwd_item: the two formulations
+                // then give the same bits
+                const float Is = fabsf(I) * (a.scale_g * (1.0f / (float)(1 << kCellShift)));
+                atomicAdd(row_hi, cell_to_accum(sp.cle * sp.chu * Is));        // pixel 1
+                atomicAdd(row_hi + 1, cell_to_accum(sp.che * sp.chu * Is));    // pixel 2
+                atomicAdd(row_lo + 1, cell_to_accum(sp.che * sp.clu * Is));    // pixel 3
+                atomicAdd(row_lo, cell_to_accum(sp.cle * sp.clu * Is));        // pixel 4
             }
         }
     }
@@ -318,7 +325,13 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
         usq = row_reduce<kSum>(has ? s_red[12][w] : 0.0f);
     }
     if (tid == 0) {
-        Window win = {0, 0, 0, 0, 0, 1, 1.0f, 0, 0, 0};
+        // The cell unit is the SAME for every item of a launch - 2^(kCellShift) accumulator units, i.e. 2^-21 of 2^ex_g
+        // > |mag k_ext k_refl| - and a stray ray is rounded to it like a window ray (to_cell): a ray contributes the same
+        // integer whichever workgroup traces it and whether or not it meets a window, so the bitmap does not depend on
+        // the launch geometry.  |contribution| <= |k| |d| |m| (the scatter matrix is a rotation; cylinder: |d| ||R_xy||_F
+        // = sqrt 2 |d|), i.e. < 2^22 cell units for unit normals; a returning add copes with up to 2^31.
+        // (scale and shift are set even for an EMPTY window: its rays are all strays, and strays are rounded to the cell unit)
+        Window win = {0, 0, 0, 0, 0, 1, a.scale_g * (1.0f / (float)(1 << kCellShift)), kCellShift, 0, 0};
         if (emax >= emin) {
             // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
             // worth keeping in the window (~4.2 sigma); +2 px for the bilinear footprint and rounding.
@@ -358,26 +371,6 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             // larger footprints (near, oblique heliostats) are swept in several passes over row bands
             win.ths = min(th, a.tile_cap / tw);
             win.npass = win.ths >= th ? 1 : (th - 1 + win.ths - 2) / (win.ths - 1);
-            // |contribution| <= |I| = |mag k_ext k_refl| |r.m| <= |mag k_ext k_refl| |d| |m| (the scatter
-            // matrix is a rotation); 2^ex > bound, so |v| * 2^(22-ex) < 2^22.
-            // (cylinder: |I0| <= |mag| |(R d)_xy| <= |mag| |d| ||R_xy||_F)
-            float kI, mnorm;
-            if constexpr (CYL) {
-                kI = (cy.mag * cy.k_ext) * cy.k_refl;
-                mnorm = sqrtf(cy.r00 * cy.r00 + cy.r01 * cy.r01 + cy.r02 * cy.r02 + cy.r10 * cy.r10 + cy.r11 * cy.r11 +
-                              cy.r12 * cy.r12);
-            } else {
-                kI = (pl.mag * pl.k_ext) * pl.k_refl;
-                mnorm = sqrtf(pl.mx * pl.mx + pl.my * pl.my + pl.mz * pl.mz);
-            }
-            const float bound = fabsf(kI) * sqrtf(dmax2) * mnorm * 1.001f;
-            int ex = 0;
-            if (bound > 0.0f && bound < 3.0e38f) (void)frexpf(bound, &ex);
-            // the cell unit is a power-of-two multiple of the accumulator unit (within 2^-6 .. 2^8 of |k|'s own exponent:
-            // |d| |m| is ~1 for unit normals; beyond that range the window is merely coarser or wraps its cells sooner)
-            ex = min(max(ex, a.ex_g - 6), a.ex_g + 8);
-            win.scale = ldexpf(1.0f, 22 - ex);
-            win.shift = 6 + ex - a.ex_g;
         }
         *s_win = win;
     }
@@ -662,8 +655,9 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
                 if (first && valid && on && !in_union) {
                     unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
                     unsigned long long* row_lo = row_hi + a.W;
-                    atomicAdd(row_hi, to_accum(cle * chu * I, a.scale_g)); atomicAdd(row_hi + 1, to_accum(che * chu * I, a.scale_g));
-                    atomicAdd(row_lo + 1, to_accum(che * clu * I, a.scale_g)); atomicAdd(row_lo, to_accum(cle * clu * I, a.scale_g));
+                    const float Iss = fabsf(I) * win.scale;              // as for a window ray
+                    atomicAdd(row_hi, cell_to_accum(cle * chu * Iss)); atomicAdd(row_hi + 1, cell_to_accum(che * chu * Iss));
+                    atomicAdd(row_lo + 1, cell_to_accum(che * clu * Iss)); atomicAdd(row_lo, cell_to_accum(cle * clu * Iss));
                 }
 #endif
             }
@@ -943,12 +937,13 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         if ((m_parked >> lane) & 1ull) {
             const float tbe = truncf(pk_be), tbu = truncf(pk_bu);                              // heliostat_ray_tracer.py:674-675
             if ((tbe + 1.0f < Wf) && (tbu + 1.0f < Hf)) {                                      // :723-728
-                const float che = pk_be - tbe, chu = pk_bu - tbu, cle = (tbe + 1.0f) - pk_be, clu = (tbu + 1.0f) - pk_bu;   // :694-700
-                const float I = (pl.mag * (-pk_ah) * pl.k_ext) * pl.k_refl;                    // :482-487, geometry.py:139
+                const float che = pk_be - tbe, chu = pk_bu - tbu, cle = 1.0f - che, clu = 1.0f - chu;      // :694-700, as in trace_one
+                const float Is = fabsf(pk_ah) * kS;                                            // the products of a window ray:
+                const float wa = chu * Is, wb = clu * Is;                                      // the same integers reach the bitmap
                 unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;   // flat row iu + 1, flipped
                 unsigned long long* row_lo = row_hi + a.W;
-                atomicAdd(row_hi, to_accum(cle * chu * I, a.scale_g)); atomicAdd(row_hi + 1, to_accum(che * chu * I, a.scale_g));
-                atomicAdd(row_lo + 1, to_accum(che * clu * I, a.scale_g)); atomicAdd(row_lo, to_accum(cle * clu * I, a.scale_g));
+                atomicAdd(row_hi, cell_to_accum(cle * wa)); atomicAdd(row_hi + 1, cell_to_accum(che * wa));
+                atomicAdd(row_lo + 1, cell_to_accum(che * wb)); atomicAdd(row_lo, cell_to_accum(cle * wb));
             }
         }
         m_parked = 0ull;
@@ -1053,7 +1048,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             // Every step of a round runs unconditionally (no control flow re-defines a slot: a conditional step made the
             // compiler copy freshly requested slots around and wait for them at once); the rays that pad the last round
             // re-read sample nr - 1 and are masked out.
-            float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
+            [[maybe_unused]] float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
             request(0, su0, se0); request(1, su1, se1);
 #if ART_RING_DEPTH >= 4
             request(2, su2, se2); request(3, su3, se3);
@@ -1846,7 +1841,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             bu_ += step; be_ += step; ++next_r;
         };
         if (nr >= 8) {                                // the distortion ring of trace_fwd_item_lean
-            float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
+            [[maybe_unused]] float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
             request(0, su0, se0); request(1, su1, se1);
 #if ART_RING_DEPTH_BWD >= 4
             request(2, su2, se2); request(3, su3, se3);

@@ -347,6 +347,32 @@ def test_forward_variants_agree(golden, monkeypatch, env):
             assert rel_l2(n(inp["normals"].grad), gn) < tol, (name, env)
 
 
+@pytest.mark.parametrize("name", ["mid_256", "small_deg2_tilted", "small_offtarget", "small_deg3"])
+def test_bitmap_does_not_depend_on_the_launch_geometry(golden, monkeypatch, name):
+    """One cell unit per launch, and a stray ray is rounded to it like a window ray: a ray contributes the same integer
+    whichever workgroup traces it and whether or not it meets a window.  Per ray body (the lean one, and the generic one that
+    also serves blocking and cylinders - whose products the plain global-atomic formulation repeats) every geometry gives
+    the same BITS: full windows, 4 KB windows (most rays stray), many small workgroups, no window at all."""
+    from artist_amd import trace_rays
+    d = golden(name)
+
+    def run(env):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            return n(trace_rays(**trace_inputs(d))[0])
+
+    lean = run({})
+    for env in ({"ARTIST_HIP_FWD_TILE_KB": "4"}, {"ARTIST_HIP_FWD_PBLOCK": "192"},
+                {"ARTIST_HIP_FWD_TILE_KB": "36", "ARTIST_HIP_FWD_BLOCKS": "4096", "ARTIST_HIP_FWD_MINCHUNK": "1"}):
+        np.testing.assert_array_equal(run(env), lean, err_msg=str(env))
+    generic = run({"ARTIST_HIP_LEAN": "0"})
+    for env in ({"ARTIST_HIP_LEAN": "0", "ARTIST_HIP_FWD_TILE_KB": "4"}, {"ARTIST_HIP_LEAN": "0", "ARTIST_HIP_FWD_BLOCK": "256"},
+                {"ARTIST_HIP_FWD": "global"}):
+        np.testing.assert_array_equal(run(env), generic, err_msg=str(env))
+    assert rel_l2(lean, generic) < 1e-6
+
+
 def test_large_scatter_angles_take_the_full_range_path():
     """|angle| > 2^-3 rad leaves the small-angle sin/cos kernel (ray_math.hpp: sincos_angle); force it with a
     0.3 rad sun shape so that most rays use the OCML branch, and compare with the oracle ray by ray via the
@@ -1542,7 +1568,8 @@ def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     else:
         np.testing.assert_array_equal(other[0], base[0])
     np.testing.assert_array_equal(other[1], base[1])
-    if "ARTIST_HIP_FWD_BLOCKS" in knobs or "ARTIST_HIP_LEAN" in knobs:   # another summation order / another gradient arithmetic
+    if "ARTIST_HIP_FWD_BLOCKS" in knobs or "ARTIST_HIP_LEAN" in knobs or "ARTIST_HIP_FWD_TILE_KB" in knobs:
+        # another summation order (sample chunks; the row bands a small window is swept in) / another gradient arithmetic
         assert rel_l2(other[2], base[2]) < 2e-6 and rel_l2(other[3], base[3]) < 2e-6, (rel_l2(other[2], base[2]), rel_l2(other[3], base[3]))
     else:
         np.testing.assert_array_equal(other[2], base[2])
