@@ -17,6 +17,7 @@
 // PyTorch-CPU path (the file is compiled with -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "launch_common.hpp"
 
@@ -39,6 +40,7 @@ struct NurbsArgs {
     int n_unique_u, n_unique_v;
     int H, F, M, nu, nv;
     int n_mtiles;
+    int tiles_per_wg;       // forward: tiles of 256 points one workgroup evaluates
 };
 
 // surfaces.py:198-207 (uniform) / :209-243 (search).
@@ -203,13 +205,17 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, flo
                                                                 float4* __restrict__ normals)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int hf = blockIdx.x / a.n_mtiles;
-    const int mt = blockIdx.x % a.n_mtiles;
+    // a workgroup evaluates tiles_per_wg consecutive tiles of 256 points of one facet: staging the control net and building
+    // the canting basis (one thread, ~100 dependent instructions) cost more than evaluating one tile
+    const int groups = (a.n_mtiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
+    const int hf = blockIdx.x / groups;
+    const int mt0 = (blockIdx.x % groups) * a.tiles_per_wg;
     float *s_cp, *s_ku, *s_kv, *s_B;
     stage_facet(a, hf, lds, s_cp, s_ku, s_kv, s_B);
+    const int h = hf / a.F, f = hf % a.F;
+  for (int mt = mt0; mt < min(mt0 + a.tiles_per_wg, a.n_mtiles); ++mt) {
     const int m = mt * kNurbsBlock + threadIdx.x;
     if (m >= a.M) return;
-    const int h = hf / a.F, f = hf % a.F;
     const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * m);
     Eval<DEG> E;
     evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, flo
     }
     points[(int64_t)hf * a.M + m] = po;
     normals[(int64_t)hf * a.M + m] = no;
+  }
 }
 
 // One workgroup per (h,f); threads stride over the M evaluation points; gradient net in LDS.
@@ -350,6 +357,7 @@ static bool fill_nurbs(NurbsArgs& a, const float* cp, const float* uv, int64_t u
     a.n_unique_u = (int)nuq_u; a.n_unique_v = (int)nuq_v;
     a.H = (int)H; a.F = (int)F; a.M = (int)M; a.nu = (int)nu; a.nv = (int)nv;
     a.n_mtiles = (int)((M + kNurbsBlock - 1) / kNurbsBlock);
+    a.tiles_per_wg = 1;
     return true;
 }
 
@@ -394,7 +402,18 @@ extern "C" int art_nurbs_fwd(const float* control_points, const float* eval_poin
     if (H == 0) return ART_OK;
     const size_t lds = nurbs_lds_bytes(a, false);
     if (lds > 64 * 1024) return ART_EUNSUPPORTED;
-    const int64_t blocks = (int64_t)H * F * a.n_mtiles;
+    // enough workgroups to fill the chip a few times over, as few stagings as that allows
+    {
+        static const int env_tiles = getenv("ARTIST_HIP_NURBS_TILES") ? atoi(getenv("ARTIST_HIP_NURBS_TILES")) : 0;
+        int t = env_tiles;
+        if (t <= 0) {      // as few workgroups per facet as still give ~1000 workgroups, tiles dealt evenly
+            int groups = 1;
+            while (groups < a.n_mtiles && (int64_t)H * F * groups < 1024) ++groups;
+            t = (a.n_mtiles + groups - 1) / groups;
+        }
+        a.tiles_per_wg = t;      // (1000 heliostats x 4 facets x 2500 points: 1 / 2 / 5 / 10 tiles = 0.257 / 0.235 / 0.225 / 0.220 ms)
+    }
+    const int64_t blocks = (int64_t)H * F * ((a.n_mtiles + a.tiles_per_wg - 1) / a.tiles_per_wg);
     if (blocks > 2147483647LL) return ART_EINVAL;
     ART_DISPATCH_DEG(nurbs_fwd_kernel, dim3((unsigned)blocks), lds, stream, a, reinterpret_cast<float4*>(points),
                      reinterpret_cast<float4*>(normals));
