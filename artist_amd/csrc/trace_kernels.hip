@@ -1175,6 +1175,16 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : 1024) void trace_fwd_lds_k
     }
 }
 
+// What a forward call zeroes before its kernels start - the three ray counters per heliostat (they alias `factors`) and the
+// work counters of its (at most two) launches - in ONE launch: three memsets were three 5 us kernels, a tenth of the
+// forward pass of a 16-heliostat field.
+__global__ void trace_fwd_prep_kernel(unsigned* __restrict__ counts, int n, unsigned* __restrict__ c0, unsigned* __restrict__ c1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) counts[i] = 0u;
+    if (i == 0) { *c0 = 0u; *c1 = 0u; }
+}
+
 // counts (uint32, rows 0,1 of factors) -> fractions (heliostat_ray_tracer.py:498-506).
 __global__ void finalize_factors_kernel(float* factors, int H, float rays_per_heliostat, int blocking)
 {
@@ -2082,7 +2092,7 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
 
 // Work counters of the persistent kernels: 4 KB of device memory per GPU, allocated on the first trace call and kept
 // for the life of the process.  Each launch takes the next of 1024 slots and zeroes it on its stream.
-static unsigned* next_work_counter(hipStream_t stream)
+static unsigned* next_work_counter(hipStream_t stream, bool zero = true)
 {
     constexpr int kSlots = 1024, kMaxDevices = 64;
     static unsigned* base[kMaxDevices] = {};
@@ -2098,7 +2108,7 @@ static unsigned* next_work_counter(hipStream_t stream)
         }
     }
     unsigned* slot = base[dev] + (seq.fetch_add(1) % kSlots);
-    if (hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return nullptr;
+    if (zero && hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return nullptr;
     return slot;
 }
 
@@ -2257,8 +2267,11 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         set_cone(a, max_scatter_angle);
     }
     const int64_t n_maps = mode == 0 ? H : T + Tc;
-    ART_HIP(hipMemsetAsync(factors, 0, sizeof(float) * 3 * H, stream));
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
+    unsigned* work_counters[2] = {next_work_counter(stream, false), next_work_counter(stream, false)};   // planar, cylinder launch
+    if (work_counters[0] == nullptr || work_counters[1] == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
+    hipLaunchKernelGGL(trace_fwd_prep_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, stream, counts, (int)(3 * H),
+                       work_counters[0], work_counters[1]);
     FwdConfig cfg = fwd_config();
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
@@ -2311,9 +2324,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             const int64_t blocks = (CY || BL) ? items : persistent_blocks;     /* see trace_fwd_lds_kernel */    \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL, LN>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            unsigned* work_counter = next_work_counter(stream);                                                  \
-            if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
-            const FwdLaunch launch = {a, flux, counts, work_counter};                                            \
+            const FwdLaunch launch = {a, flux, counts, work_counters[CY ? 1 : 0]};                               \
             hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL, LN>), dim3((unsigned)blocks), dim3(cfg.block),  \
                                lds, stream, launch);                                                             \
         } while (0)

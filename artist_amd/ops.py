@@ -6,6 +6,7 @@ raise.
 """
 from __future__ import annotations
 
+import collections
 import math
 
 import torch
@@ -36,6 +37,32 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+# Small per-call conversions that an optimisation loop repeats with the SAME tensors every epoch - the int32 copy of the
+# target indices, the [H,F,K] materialisation of an expanded knot vector - are kept, keyed by the source's address, shape,
+# strides and version counter (an in-place write makes a new entry).  Each is a 5 us kernel that a 1 ms epoch of a rank's
+# share of a field would pay several times over.  An entry holds the source tensor, so its address cannot be handed to another
+# tensor while the entry lives; sixteen entries of a few KB, the oldest goes first.
+_CONVERTED: "collections.OrderedDict" = collections.OrderedDict()
+
+
+def _converted(t: torch.Tensor, what: str, make):
+    key = (what, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version, str(t.device))
+    hit = _CONVERTED.get(key)
+    if hit is not None:
+        _CONVERTED.move_to_end(key)
+        return hit[1]
+    out = make(t)
+    if out is not t and t.numel() <= (1 << 20):                                  # (nothing to keep when no copy was made)
+        _CONVERTED[key] = (t, out)
+        while len(_CONVERTED) > 16:
+            _CONVERTED.popitem(last=False)
+    return out
+
+
+def _int32c(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dtype == torch.int32 and t.is_contiguous()) else _converted(t, "i32", lambda x: x.to(torch.int32).contiguous())
 
 
 def _dist_views(dist_u: torch.Tensor, dist_e: torch.Tensor, shape):
@@ -135,7 +162,7 @@ class TraceRays(torch.autograd.Function):
             raise ValueError("points_per_facet must divide the number of surface points per heliostat")
         R = dist_u.shape[1] if dist_u.dim() == 3 else -1
         dist_u, dist_e, (sh, sr, sp) = _dist_views(dist_u, dist_e, (H, R, P))
-        target_idx = target_idx.to(torch.int32).contiguous()
+        target_idx = _int32c(target_idx)
         centers, plane_normals, dims = _f32c(centers), _f32c(plane_normals), _f32c(dims)
         T = centers.shape[0]
         cyl_tabs, cyl_ptrs, Tc = _cyl_tables(cyl, dev)
@@ -196,6 +223,7 @@ class TraceRays(torch.autograd.Function):
         ctx.scalars = (float(ray_magnitude), float(extinction), float(reflectivity), width, height, bool(per_target),
                        Cmax, N, float(max_scatter_angle), points_per_facet)
         ctx.mark_non_differentiable(factors, flags)
+        ctx.set_materialize_grads(False)            # no zero tensors (one fill kernel each) for outputs nobody differentiates
         return flux, factors, flags
 
     @staticmethod
@@ -209,6 +237,8 @@ class TraceRays(torch.autograd.Function):
         Tc = cyl_tabs[0].shape[0] if cyl_tabs else 0
         mag, ext, refl, width, height, per_target, Cmax, N, max_scatter, points_per_facet = ctx.scalars
         dev = origins.device
+        if grad_flux is None:                       # the bitmaps were not used downstream
+            return (None,) * 23
         H, P = origins.shape[0], origins.shape[1]
         R = dist_u.shape[1]
         sh, sr, sp = dist_u.stride()
@@ -259,7 +289,7 @@ def per_target_sum(bitmaps: torch.Tensor, target_idx: torch.Tensor, n_targets: i
     """``get_bitmaps_per_target`` (heliostat_ray_tracer.py:563-608) as one kernel; differentiable
     through a gather in torch (the backward of a masked sum is an index_select)."""
     _require_cuda(bitmaps, target_idx)
-    return _PerTargetSum.apply(bitmaps, target_idx.to(torch.int32).contiguous(), int(n_targets))
+    return _PerTargetSum.apply(bitmaps, _int32c(target_idx), int(n_targets))
 
 
 class _PerTargetSum(torch.autograd.Function):
@@ -305,8 +335,8 @@ class NurbsEval(torch.autograd.Function):
         M = uv.shape[2]
         if uv.stride(3) != 1 or uv.stride(2) != 2 or (uv.data_ptr() % 8) != 0:
             uv = uv.contiguous()   # expanded (stride-0) heliostat/facet dims are passed through
-        ku = _f32c(knots_u.expand(H, F, nu + p + 1))
-        kv = _f32c(knots_v.expand(H, F, nv + q + 1))
+        ku = _converted(knots_u.expand(H, F, nu + p + 1), "knots", _f32c)
+        kv = _converted(knots_v.expand(H, F, nv + q + 1), "knots", _f32c)
         cant = None if canting is None else _f32c(canting)
         tr = None if canting is None else _f32c(translations.reshape(H, F, 4))
         points = torch.empty((H, F, M, 4), dtype=torch.float32, device=dev)
