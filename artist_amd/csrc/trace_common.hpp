@@ -51,6 +51,7 @@ struct TraceArgs {
     int facet_points;         // blocks subdivide runs of this many consecutive points (a facet, several facets, or P)
     int blocks_per_facet;     // ceil(facet_points / p_block)
     int tile_cap;             // LDS bitmap-window capacity in pixels
+    int split;                // 0, or which heliostats this launch owns when blocking is on: 1 unblocked (lean kernels), 2 blocked
     int pack_edge;            // lean backward kernel: 0, or the edge margin in 1/64 of the scatter pad (edge points are packed)
     int multipass_ratio;      // footprints above ratio x capacity are swept in several passes
     // Forward accumulation (windowed kernels): every bitmap pixel has a 64-bit FIXED-POINT accumulator in `accum`
@@ -163,7 +164,7 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
     a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
     a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;
     a.n_ptiles = (int)((P + kBlock - 1) / kBlock);
-    a.facet_points = (int)P; a.blocks_per_facet = 1; a.pack_edge = 0;
+    a.facet_points = (int)P; a.blocks_per_facet = 1; a.pack_edge = 0; a.split = 0;
     a.accum = nullptr; a.ex_g = 0; a.scale_g = 1.0f; a.status = nullptr;
     return true;
 }

@@ -416,6 +416,15 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
 //     (Dealing the last items as two halves of their sample range, so that the kernel ends within half an item, measured
 //     neutral at 1000 and 125 heliostats in round 1 and needed float atomics in the backward kernel: removed.)
 struct WorkItem { int h, pblock, rchunk, r0, r1; };
+// Blocking on, but a heliostat none of whose rays can meet a rectangle (an empty candidate list - with the reference's tree
+// that is almost every heliostat) is traced by the LEAN kernels: the call then makes two launches that share the field,
+// a.split = 1 (lean: the unblocked heliostats) and 2 (blocking instantiation: the others).  Workgroup-uniform.
+__device__ __forceinline__ bool other_launch_owns(const TraceArgs& a, int h)
+{
+    if (a.split == 0) return false;
+    const bool blocked = a.cand_count[h] > 0;
+    return a.split == 1 ? blocked : !blocked;
+}
 // Points [p0, p1) of point block `pblock`: blocks never straddle two facets (a.facet_points consecutive points - the
 // caller's facet size, a whole multiple of it when blocks are larger than a facet, or P when no facet structure is
 // known) - two facets' images are two blobs and one window serves them badly.
@@ -475,7 +484,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: a bad index, or the other instantiation's launch owns this heliostat
+    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // workgroup-uniform: a bad index, or another launch owns this heliostat
         if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
         return;
     }
@@ -867,7 +876,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0) {   // a bad index, a cylinder's heliostat (the other launch owns it) or an empty item
+    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // a bad index, another launch's heliostat (cylinder, blocked) or an empty item
         if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
         return;
     }
@@ -1178,15 +1187,16 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : 1024) void trace_fwd_lds_k
 // What a forward call zeroes before its kernels start - the three ray counters per heliostat (they alias `factors`) and the
 // work counters of its (at most two) launches - in ONE launch: three memsets were three 5 us kernels, a tenth of the
 // forward pass of a 16-heliostat field.
-__global__ void trace_fwd_prep_kernel(unsigned* __restrict__ counts, int n, unsigned* __restrict__ c0, unsigned* __restrict__ c1)
+__global__ void trace_fwd_prep_kernel(unsigned* __restrict__ counts, int n, unsigned* __restrict__ c0, unsigned* __restrict__ c1,
+                                      unsigned* __restrict__ c2)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) counts[i] = 0u;
-    if (i == 0) { *c0 = 0u; *c1 = 0u; }
+    if (i == 0) { *c0 = 0u; *c1 = 0u; *c2 = 0u; }
 }
 
 // counts (uint32, rows 0,1 of factors) -> fractions (heliostat_ray_tracer.py:498-506).
-__global__ void finalize_factors_kernel(float* factors, int H, float rays_per_heliostat, int blocking)
+__global__ void finalize_factors_kernel(float* factors, int H, float rays_per_heliostat, int blocking, const int32_t* unblocked_if_empty)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
@@ -1198,6 +1208,8 @@ __global__ void finalize_factors_kernel(float* factors, int H, float rays_per_he
 #ifdef ART_DEBUG_COUNT_STRAYS
     blocking = 1;
 #endif
+    // (split launches: a heliostat with an empty candidate list went through the lean kernel, which does not count free rays)
+    if (unblocked_if_empty != nullptr && unblocked_if_empty[h] == 0) blocking = 0;
     factors[2 * H + h] = (blocking ? (float)n_free : rays_per_heliostat) / rays_per_heliostat;
 }
 
@@ -1347,7 +1359,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     }
 
     const int t = a.target_idx[h];
-    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0) {   // workgroup-uniform: a bad index, or the other instantiation's launch owns this heliostat
+    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // workgroup-uniform: a bad index, or another launch owns this heliostat
         if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
         return;
     }
@@ -1673,7 +1685,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         grad_normals += (int64_t)item.rchunk * a.H * a.P;
     }
     const int t = a.target_idx[h];
-    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0) {
+    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {
         if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
         return;
     }
@@ -2268,10 +2280,14 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     }
     const int64_t n_maps = mode == 0 ? H : T + Tc;
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
-    unsigned* work_counters[2] = {next_work_counter(stream, false), next_work_counter(stream, false)};   // planar, cylinder launch
-    if (work_counters[0] == nullptr || work_counters[1] == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
+    // planar launch, cylinder launch, lean launch of a split call
+    unsigned* work_counters[3] = {next_work_counter(stream, false), next_work_counter(stream, false), next_work_counter(stream, false)};
+    if (work_counters[0] == nullptr || work_counters[1] == nullptr || work_counters[2] == nullptr) {
+        g_last_hip_error = (int)hipErrorOutOfMemory;
+        return ART_ELAUNCH;
+    }
     hipLaunchKernelGGL(trace_fwd_prep_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, stream, counts, (int)(3 * H),
-                       work_counters[0], work_counters[1]);
+                       work_counters[0], work_counters[1], work_counters[2]);
     FwdConfig cfg = fwd_config();
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
@@ -2288,8 +2304,38 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     if (cfg.variant == 0) {
         // the lean ray body (trace_fwd_item_lean): planar receivers, no blocking, positive and sanely scaled intensity
         // factors - then a valid ray is known to carry intensity and one counter serves both factors
-        const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
-                          a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
+        const bool lean_ok = env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
+                             a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
+        const bool lean = !blocking && lean_ok;
+        // Blocking on: the heliostats with an empty candidate list (with the reference's tree, almost all of them) go through
+        // the lean kernel in a launch of their own; the blocking instantiation below skips them.
+        if (blocking && lean_ok && T > 0 && Tc == 0 && env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
+            TraceArgs al = a;
+            al.split = 1;
+            FwdConfig cl = fwd_config();
+            cl.facet_points = (int)facet_points;
+            cl.block = kLeanFwdThreads;
+            cl.exact_pblock = true;
+            if (!cl.p_block_fixed) cl.p_block = cl.facet_points > 0 ? kLeanFwdPoints : kLeanFwdThreads;
+            window_geometry(al, cl, cl.p_block, cl.p_block_fixed);
+            const int64_t items_l = (int64_t)al.H * al.n_pblocks * al.n_rchunks;
+            if (items_l > 2147483647LL - 65536) return ART_EINVAL;
+            const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
+            const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(unsigned);
+            const FwdLaunch launch = {al, flux, counts, work_counters[2]};
+            if (interleaved_layout(al)) {
+                ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true, false, false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                hipLaunchKernelGGL((trace_fwd_lds_kernel<true, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block), lds_l,
+                                   stream, launch);
+            } else {
+                ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false, false, false, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                hipLaunchKernelGGL((trace_fwd_lds_kernel<false, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block), lds_l,
+                                   stream, launch);
+            }
+            a.split = 2;
+        }
         if (lean && T > 0 && Tc == 0) {
             // (the facet hint serves the lean kernels only: with blocking on, facet-sized items measured SLOWER - 37.8 vs
             //  30.5 ms forward + backward on the blocking bench's field - and the cylinder kernels were not measured)
@@ -2364,7 +2410,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                            sign_unit);
     }
     hipLaunchKernelGGL(finalize_factors_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, factors,
-                       (int)H, (float)(R * P), blocking ? 1 : 0);
+                       (int)H, (float)(R * P), blocking ? 1 : 0, a.split == 2 ? a.cand_count : nullptr);
     ART_HIP(hipGetLastError());
 #ifdef ART_DEBUG_TIMELINE
     if (const char* out = getenv("ART_TIMELINE_OUT")) {     // the last call's records: [blocks][8] u64, raw
@@ -2452,6 +2498,46 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             fprintf(stderr, "art_trace_bwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
                     a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean);
         const bool atomic_out = a.n_rchunks > 1;      // (round 1's name: today the chunks write slabs, nothing is atomic)
+        // Blocking on: the heliostats with an empty candidate list take the lean kernel in a launch of their own (see
+        // art_trace_fwd) - for fields large enough that neither launch cuts a point's samples into chunks (the two would
+        // need slabs of their own).
+        if (blocking && !atomic_out && T > 0 && Tc == 0 && env_int("ARTIST_HIP_LEAN", 1) != 0 &&
+            env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
+            TraceArgs al = a;
+            al.split = 1;
+            FwdConfig cl = fwd_config();
+            cl.block = kLeanBwdThreads;
+            cl.exact_pblock = true;
+            cl.facet_points = (int)facet_points;
+            if (!cl.p_block_bwd_fixed) cl.p_block_bwd = kLeanBwdPoints;
+            size_t perm_l = 0;
+            al.pack_edge = std::min(std::max(env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
+            if (al.pack_edge != 0) {
+                perm_l = 2 * kPackPoints;
+                cl.tile_cap = std::min<int>(cl.tile_cap, (int)((160 * 1024 - 1408 - perm_l - 8) / 4) / 64 * 64);
+            }
+            window_geometry(al, cl, cl.p_block_bwd, cl.p_block_bwd_fixed);
+            if (al.n_rchunks == 1) {
+                const int64_t items_l = (int64_t)al.H * al.n_pblocks;
+                if (items_l > 2147483647LL - 65536) return ART_EINVAL;
+                const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
+                const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(float) + perm_l;
+                unsigned* wc = next_work_counter(stream);
+                if (wc == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
+                if (il) {
+                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<true, false, false, false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                    hipLaunchKernelGGL((trace_bwd_lds_kernel<true, false, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block),
+                                       lds_l, stream, al, grad_flux, go, gn, grad_prim_corners, grad_prim_spans, grad_prim_normals, wc);
+                } else {
+                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<false, false, false, false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                    hipLaunchKernelGGL((trace_bwd_lds_kernel<false, false, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block),
+                                       lds_l, stream, al, grad_flux, go, gn, grad_prim_corners, grad_prim_spans, grad_prim_normals, wc);
+                }
+                a.split = 2;
+            }
+        }
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
