@@ -1033,8 +1033,8 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             }
 #endif
         };
-        // The distortion stream: a ring of kRing samples per thread, each slot re-requested the moment its value has been
-        // read, so that kRing - 1 loads (3.5 KB per wave, 56 KB per CU) are in flight at every instant.  The ablation
+        // The distortion stream: a ring of ART_RING_DEPTH (8) samples per thread, each slot re-requested the moment its value
+        // has been read, so that seven loads (3.5 KB per wave, 56 KB per CU) are in flight at every instant.  The ablation
         // builds (tools/ablate.sh) showed what round 1 missed: with the loads of a group of four issued only one group
         // ahead, the waves waited for this stream 40 % of the forward and 60 % of the backward kernel's time.
         const int lane_off = p * (int)a.sp;
@@ -2475,7 +2475,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
-        // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, two trips of points
+        // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, one block per facet
         const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0;
         size_t perm_bytes = 0;
         if (lean) {
