@@ -271,19 +271,42 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
     __syncthreads();
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int h = hf / a.F, f = hf % a.F;
-    // Neighbouring evaluation points share their 16 control points, so lanes that walk the points in order
-    // would all add to the same LDS cells (up to 64-way serialisation).  Walk them in a strided order instead
-    // (i -> i*K mod M, K prime and coprime to M: a bijection) so that the lanes of a wave sit in different
-    // knot spans; the gradient loads become gathers, but they are 32 B per point and L2-resident.
+    // A thread owns a RUN of consecutive evaluation points and keeps the (p+1)(q+1) x 3 sums of the control points of the
+    // current knot-span cell in registers; they go to the LDS accumulator - one ds_add_f64 each, the pipe that bounds this
+    // kernel - only when the run leaves the cell and at its end.  On a row-major evaluation grid (50 x 50 points over 7 x 7
+    // cells) a run of ten points meets ~2.4 cells: 4 x fewer LDS atomics than one set per point (0.47 -> see DESIGN.md 4.3);
+    // scattered evaluation points flush after every point, as before.  Neighbouring runs share their control points, so lanes
+    // that took neighbouring runs would all add to the same LDS cells (up to 64-way serialisation): lane t takes run
+    // (t K) mod n_runs, K prime and coprime to n_runs (a bijection), which puts the lanes of a wave in different cells; the
+    // gradient loads become gathers of 32 B per point and are L2-resident.
+    const int run_len = (a.M + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int n_runs = (a.M + run_len - 1) / run_len;
     int K = 1;
     {
         const int primes[8] = {61, 59, 53, 47, 43, 41, 37, 31};
 #pragma unroll
         for (int i = 7; i >= 0; --i)
-            if (a.M % primes[i] != 0) K = primes[i];
+            if (n_runs % primes[i] != 0) K = primes[i];
     }
-    for (int i = threadIdx.x; i < a.M; i += blockDim.x) {
-        const int m = (int)(((int64_t)i * K) % a.M);
+    float acc[S][S][3];
+    int cur_u = -1, cur_v = -1;
+    auto flush = [&]() {
+        if (cur_u < 0) return;
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            if (r > p) break;
+#pragma unroll
+            for (int s_ = 0; s_ < S; ++s_) {
+                if (s_ > q) break;
+                double* g3 = s_g + ((cur_u - p + r) * a.nv + (cur_v - q + s_)) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) atomicAdd(g3 + k, (double)acc[r][s_][k]);
+            }
+        }
+    };
+    if ((int)threadIdx.x < n_runs) {
+      const int run = (int)(((int64_t)threadIdx.x * K) % n_runs);
+      for (int m = run * run_len; m < min(a.M, (run + 1) * run_len); ++m) {
         const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * m);
         Eval<DEG> E;
         evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
@@ -324,18 +347,24 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
                               gc[0] * E.Su[1] - gc[1] * E.Su[0]};
         const float iw = 1.0f / E.S0[3];
         const float gS[3] = {gpt[0] * iw, gpt[1] * iw, gpt[2] * iw};
+        const bool same = E.su == cur_u && E.sv == cur_v;
+        if (!same) { flush(); cur_u = E.su; cur_v = E.sv; }
 #pragma unroll
         for (int r = 0; r < S; ++r) {
             if (r > p) break;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (s > q) break;
-                const float w00 = E.Nu[r] * E.Nv[s], w10 = E.Du[r] * E.Nv[s], w01 = E.Nu[r] * E.Dv[s];
-                double* g3 = s_g + ((E.su - p + r) * a.nv + (E.sv - q + s)) * 3;
+            for (int s_ = 0; s_ < S; ++s_) {
+                if (s_ > q) break;
+                const float w00 = E.Nu[r] * E.Nv[s_], w10 = E.Du[r] * E.Nv[s_], w01 = E.Nu[r] * E.Dv[s_];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) atomicAdd(g3 + k, (double)(w00 * gS[k] + w10 * gSu[k] + w01 * gSv[k]));
+                for (int k = 0; k < 3; ++k) {
+                    const float c = w00 * gS[k] + w10 * gSu[k] + w01 * gSv[k];
+                    acc[r][s_][k] = same ? acc[r][s_][k] + c : c;
+                }
             }
         }
+      }
+      flush();
     }
     __syncthreads();
     float* out = g_cp + (int64_t)hf * ncp;
