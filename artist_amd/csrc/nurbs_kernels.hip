@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "launch_common.hpp"
+#include "ray_math.hpp"      // div_noscale: n / a bit for bit, without the range scaling of the IEEE sequence
 
 namespace art {
 
@@ -79,7 +80,8 @@ __device__ __forceinline__ void basis(float x, const float* knots, int span, int
         for (int r = 0; r < S - 1; ++r) {
             if (r >= j) break;
             ndu[j][r] = right[r + 1] + left[j - r];
-            const float tmp = ndu[r][j - 1] / ndu[j][r];
+            // (knot differences and basis values are far inside the normal range: div_noscale == '/')
+            const float tmp = div_noscale(ndu[r][j - 1], ndu[j][r]);
             ndu[r][j] = saved + right[r + 1] * tmp;
             saved = left[j - r] * tmp;
         }
@@ -96,11 +98,11 @@ __device__ __forceinline__ void basis(float x, const float* knots, int span, int
         if (r > pdeg) break;
         float d = 0.0f;
         if (r >= 1) {
-            const float a0 = 1.0f / ndu[pk + 1][r - 1];
+            const float a0 = div_noscale(1.0f, ndu[pk + 1][r - 1]);
             d = a0 * ndu[r - 1][pk];
         }
         if (r <= pk) {
-            const float a1 = -1.0f / ndu[pk + 1][r];
+            const float a1 = div_noscale(-1.0f, ndu[pk + 1][r]);
             d += a1 * ndu[r][pk];
         }
         D[r] = d * (float)pdeg;
