@@ -11,8 +11,9 @@ import subprocess
 import sys
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
-if len(sys.argv) > 1:
-    asm = pathlib.Path(sys.argv[1])
+args = [x for x in sys.argv[1:] if not x.startswith("--")]
+if args:
+    asm = pathlib.Path(args[0])
 else:
     asm = pathlib.Path("/tmp/trace_kernels_stats.s")
     flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize".split()
@@ -64,6 +65,11 @@ def stats(name, pat, depth):
                 if m:
                     meta[m.group(1)] = int(m.group(2))
             break
+    if "--histogram" in sys.argv:
+        hist = collections.Counter(ins)
+        print(f"  opcodes per ray, {name}:")
+        for k, v in hist.most_common():
+            print(f"    {k:28s} {v / depth:6.2f}")
     print(f"{name} (ring of {depth}): per ray " + ", ".join(f"{k} {v / depth:.1f}" for k, v in sorted(c.items())) +
           f"; v_mov {sum(k.startswith('v_mov') for k in ins) / depth:.1f}, scratch in loop {sum(k.startswith('scratch') for k in ins)}; {meta}")
 
