@@ -1936,8 +1936,11 @@ constexpr int kLeanBwdThreads = 768;
 // 2 x 5000 4.08.  The trips of a block need not be full: 2500 points = 768 + 768 + 768 + 196 threads beat four equal trips of
 // 640 threads (4.28 ms) - a trip costs what its active waves issue, not a fixed time.
 constexpr int kLeanBwdPoints = 2560;
+// (cylinder adjoint: 512-thread workgroups, it keeps ~60 more values alive; planar blocking: 768 - 160 B of spills but three
+//  waves per SIMD, forward + backward of the blocking bench's exact mode 30.5 -> 29.0 ms)
+constexpr int kCylBwdThreads = 512, kBlockingBwdThreads = 768;
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
-__global__ __launch_bounds__((CYL || BLOCKING) ? 512 : (LEAN ? kLeanBwdThreads : 1024)) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
+__global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThreads : (LEAN ? kLeanBwdThreads : 1024))) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
                                                              float4* __restrict__ grad_normals,
                                                              float* __restrict__ g_corners, float* __restrict__ g_spans,
@@ -2559,7 +2562,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             unsigned* work_counter = next_work_counter(stream);                                                  \
             if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
             hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL, LN>), dim3((unsigned)blocks),               \
-                               dim3((CY || BL) && cfg.block > 512 ? 512 : cfg.block), lds, stream, a, grad_flux, \
+                               dim3(std::min(cfg.block, CY ? kCylBwdThreads : (BL ? kBlockingBwdThreads : 1024))), lds, stream, a, grad_flux, \
                                go, gn,                                                                           \
                                grad_prim_corners, grad_prim_spans, grad_prim_normals, work_counter);             \
         } while (0)
