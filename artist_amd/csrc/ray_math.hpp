@@ -431,7 +431,7 @@ constexpr float kBlockOffset = 0.05f;         // :220
 constexpr float kBlockEps = 1e-12f;           // :217
 constexpr float kBlockMargin = 0.026f;        // sigmoid(-1000 * 0.026) = 5e-12
 
-struct Prim {            // one blocking rectangle, 20 floats in LDS
+struct alignas(16) Prim {   // one blocking rectangle, 20 floats in LDS (five 128-bit reads)
     float c0x, c0y, c0z;     // corner 0
     float sux, suy, suz;     // span u = corner 1 - corner 0
     float svx, svy, svz;     // span v = corner 3 - corner 0
@@ -526,7 +526,7 @@ __device__ __forceinline__ unsigned cone_mask(const Prim* __restrict__ prims, in
 }
 
 // exp(-alpha sum sigma) over the rectangles in `wave_mask` (wave-uniform union of the lanes' `mask`); `near` gets
-// the rectangles whose mask this ray actually entered.
+// the rectangles whose mask this ray actually entered with a gradient (not the rays deep inside one: sigma == 1).
 __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, unsigned wave_mask, unsigned mask,
                                                     float ox, float oy, float oz, float rx, float ry, float rz,
                                                     unsigned& near)
@@ -544,7 +544,9 @@ __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ pri
         SoftSig g;
         const float sg = soft_sigma(s, g);
         sum += s.near ? sg : 0.0f;
-        near |= s.near ? 1u << k : 0u;
+        // all five sigmoids saturated at exactly 1 (x >= 17): sigma = 1 with a gradient of exactly zero - not "near"
+        const bool flat = g.sigma_raw == 1.0f;
+        near |= s.near && !flat ? 1u << k : 0u;
     }
     return __expf(-(kBlockAlpha * sum));
 }

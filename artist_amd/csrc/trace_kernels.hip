@@ -1302,16 +1302,27 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
 // (0 for lanes without a gradient), g_sigma = dL/dsigma.  Ray-side gradients come back per lane; the rectangles'
 // gradients are accumulated in LDS (12 floats per candidate: corner 0, span u, span v, normal) and flushed once
 // per workgroup - few rays sit in the soft edge of a rectangle, so the LDS float atomics are off the common path.
-__device__ __attribute__((noinline)) void block_adjoint(const Prim* __restrict__ prims, unsigned wave_mask, unsigned near,
-                                              float ox, float oy, float oz, float rx, float ry, float rz,
-                                              float g_sigma, float& g_ox, float& g_oy, float& g_oz, float& g_rx,
-                                              float& g_ry, float& g_rz, float* __restrict__ s_gprim)
+// The function is a real call (eight inlined copies would not fit the instruction cache), so its interface is kept in
+// registers: the tables come as LDS pointers (a generic pointer costs a null check per access), the wave-uniform mask
+// goes back to an SGPR, the ray-side gradients return by value (references would go through scratch memory).
+struct RayGrad { float ox, oy, oz, rx, ry, rz; };
+typedef const __attribute__((address_space(3))) Prim* LdsPrims;
+typedef __attribute__((address_space(3))) float* LdsFloats;
+__device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsFloats s_gprim, unsigned wave_mask, unsigned near,
+                                                           float ox, float oy, float oz, float rx, float ry, float rz,
+                                                           float g_sigma)
 {
-    for (unsigned m = wave_mask; m != 0u; m &= m - 1u) {
+    RayGrad out = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (unsigned m = __builtin_amdgcn_readfirstlane(wave_mask); m != 0u; m &= m - 1u) {
         const int k = __builtin_ctz(m);
         const bool on = (near >> k) & 1u;
         if (!wave_any(on)) continue;
-        const Prim q = prims[k];
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        static_assert(sizeof(Prim) == 5 * sizeof(v4f), "Prim is five 128-bit LDS reads");
+        const __attribute__((address_space(3))) v4f* src = (const __attribute__((address_space(3))) v4f*)(prims + k);
+        const v4f words[5] = {src[0], src[1], src[2], src[3], src[4]};
+        Prim q;
+        __builtin_memcpy(&q, words, sizeof(Prim));
         SoftHit sh;
         const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, sh);
         soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, sh);
@@ -1320,16 +1331,23 @@ __device__ __attribute__((noinline)) void block_adjoint(const Prim* __restrict__
         SoftGrad g;
         soft_sigma_bwd(q, ox, oy, oz, rx, ry, rz, sh, sg, on ? g_sigma : 0.0f, g);
         if (on) {     // other lanes may hold non-finite intermediates: branch, do not multiply
-            g_ox += g.ox; g_oy += g.oy; g_oz += g.oz;
-            g_rx += g.rx; g_ry += g.ry; g_rz += g.rz;
-            float* acc = s_gprim + 12 * k;
+            out.ox += g.ox; out.oy += g.oy; out.oz += g.oz;
+            out.rx += g.rx; out.ry += g.ry; out.rz += g.rz;
+            LdsFloats acc = s_gprim + 12 * k;
+#ifndef ART_ABLATE_NO_BLOCK_ATOMICS
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                atomicAdd(acc + c, g.c0[c]); atomicAdd(acc + 3 + c, g.su[c]);
-                atomicAdd(acc + 6 + c, g.sv[c]); atomicAdd(acc + 9 + c, g.n[c]);
+                __hip_atomic_fetch_add(acc + c, g.c0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + 3 + c, g.su[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + 6 + c, g.sv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + 9 + c, g.n[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+#else
+            acc[0] = g.c0[0] + g.su[1] + g.sv[2] + g.n[0];
+#endif
         }
     }
+    return out;
 }
 
 // (The cylinder and blocking instantiations keep ~60 more live values per ray; they run 512-thread workgroups =
@@ -1478,15 +1496,18 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
             auto mask_adjoint = [&]() {
                 if constexpr (BLOCKING) {
                     // only rays inside some rectangle's mask that still carry light have a gradient through it
-                    const bool adj = near != 0u && g_keep != 0.0f && trans > 0.0f;
+#ifdef ART_ABLATE_NO_BLOCK_ADJ
+                    const bool adj = false;
+#else
+                    const bool adj = near != 0u && g_keep != 0.0f && trans > 1e-30f;
+#endif
                     if (wave_any(adj)) {
-                        float ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
-                        block_adjoint(s_tab.prim, wmask, adj ? near : 0u, o.x, o.y, o.z, rx, ry, rz,
-                                      adj ? -kBlockAlpha * trans * g_keep : 0.0f, ax, ay, az, bx, by, bz, s_tab.grad);
-                        bgx += ax; bgy += ay; bgz += az;
-                        gdx += m.cu * bx + m.m10 * by + m.m20 * bz;
-                        gdy += m.m11 * by + m.m21 * bz - m.su * bx;
-                        gdz += m.ce * bz - m.se * by;
+                        const RayGrad b = block_adjoint((LdsPrims)s_tab.prim, (LdsFloats)s_tab.grad, wmask, adj ? near : 0u, o.x, o.y,
+                                                        o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+                        bgx += b.ox; bgy += b.oy; bgz += b.oz;
+                        gdx += m.cu * b.rx + m.m10 * b.ry + m.m20 * b.rz;
+                        gdy += m.m11 * b.ry + m.m21 * b.rz - m.su * b.rx;
+                        gdz += m.ce * b.rz - m.se * b.ry;
                     }
                 }
             };
