@@ -533,13 +533,22 @@ __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ pri
 {
     float sum = 0.0f;
     near = 0u;
+#ifdef ART_ABLATE_BLOCK_STAGE0
+    wave_mask = 0u;
+#endif
     for (unsigned m = wave_mask; m != 0u; m &= m - 1u) {
         const int k = __builtin_ctz(m);
         const Prim q = prims[k];                       // wave-uniform LDS address: broadcast reads
         SoftHit s;
         const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s) && ((mask >> k) & 1u);
+#ifdef ART_ABLATE_BLOCK_STAGE1
+        sum += in_front ? 1e-30f : 0.0f; continue;
+#endif
         if (!wave_any(in_front)) continue;
         soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, s);
+#ifdef ART_ABLATE_BLOCK_STAGE2
+        sum += s.near ? 1e-30f : 0.0f; continue;
+#endif
         if (!wave_any(s.near)) continue;
         SoftSig g;
         const float sg = soft_sigma(s, g);
@@ -572,7 +581,7 @@ __device__ __forceinline__ void soft_sigma_bwd(const Prim& q, float ox, float oy
     const float g_u = g_sigma * iv * g.f * (k * iu * (g.Bu - g.Au));
     const float g_v = g_sigma * iu * g.f * (k * iv * (g.Bv - g.Av));
     float g_d = g_sigma * iu * iv * (g.f * (1.0f - g.f) * k);
-    const float idet = 1.0f / q.det_safe;
+    const float idet = __builtin_amdgcn_rcpf(q.det_safe);       // (adjoint only: 1 ulp reciprocals, no division sequences)
     const float g_pu = (g_u * q.svv - g_v * q.suv) * idet;
     const float g_pv = (g_v * q.suu - g_u * q.suv) * idet;
     float g_svv = g_u * s.pu * idet, g_suu = g_v * s.pv * idet, g_suv = -(g_u * s.pv + g_v * s.pu) * idet;
@@ -591,8 +600,8 @@ __device__ __forceinline__ void soft_sigma_bwd(const Prim& q, float ox, float oy
         out.sv[c] = g_pv * off[c] + 2.0f * g_svv * sv[c] + g_suv * su[c];
         g_d += g_off[c] * dir[c];
     }
-    const float g_num = g_d / s.den_safe;
-    const float g_den = fabsf(s.den) < kBlockEps ? 0.0f : -g_d * s.d / s.den_safe;
+    const float g_num = g_d * __builtin_amdgcn_rcpf(s.den_safe);
+    const float g_den = fabsf(s.den) < kBlockEps ? 0.0f : -g_num * s.d;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         go[c] = g_off[c] - g_num * nn[c];
