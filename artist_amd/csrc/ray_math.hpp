@@ -506,11 +506,35 @@ __device__ __forceinline__ float soft_sigma(const SoftHit& s, SoftSig& g)     //
     return __builtin_amdgcn_fmed3f(g.sigma_raw, 0.0f, 1.0f);
 }
 
+// The local coordinates of soft_uv are two linear functionals of the hit point: u(X) = (X - c0).a, v(X) = (X - c0).b.
+struct alignas(16) PrimAux { float ax, ay, az, an, bx, by, bz, bn; };     // a, |a|, b, |b|
+
+__device__ __forceinline__ PrimAux make_prim_aux(const Prim& q)
+{
+    PrimAux x;
+    const float idet = 1.0f / q.det_safe;
+    x.ax = (q.sux * q.svv - q.svx * q.suv) * idet; x.ay = (q.suy * q.svv - q.svy * q.suv) * idet;
+    x.az = (q.suz * q.svv - q.svz * q.suv) * idet;
+    x.bx = (q.svx * q.suu - q.sux * q.suv) * idet; x.by = (q.svy * q.suu - q.suy * q.suv) * idet;
+    x.bz = (q.svz * q.suu - q.suz * q.suv) * idet;
+    x.an = sqrtf(x.ax * x.ax + x.ay * x.ay + x.az * x.az);
+    x.bn = sqrtf(x.bx * x.bx + x.by * x.by + x.bz * x.bz);
+    return x;
+}
+
 // Which of the n rectangles can a ray leaving o within `theta` of the unit direction (dx,dy,dz) touch at all?
-// Sphere against cone: the centre's distance to the cone surface is perp cos(theta) - t sin(theta).  (cos_t, sin_t) =
-// (0, 0) accepts everything (no bound on the scatter angle known).
-__device__ __forceinline__ unsigned cone_mask(const Prim* __restrict__ prims, int n, float ox, float oy, float oz,
-                                              float dx, float dy, float dz, float cos_t, float sin_t)
+//  1. Sphere against cone: the centre's distance to the cone surface is perp cos(theta) - t sin(theta).  (cos_t, sin_t) =
+//     (0, 0) accepts everything (no bound on the scatter angle known).
+//  2. The sphere is a loose hull of a rectangle, and the 64 points of a wave spread over a facet's width, so a wave would
+//     evaluate many rectangles its rays pass beside.  A ray of the cone that enters the mask does so at a point X of the
+//     rectangle's plane with |X - o| <= |w| + rho, u(X), v(X) in (-margin, 1 + margin); X is within
+//     delta = (|w| + rho) sin(theta) of some point Y = o + tau d (tau >= 0) of the chief ray, hence
+//     |(Y - c0).n| <= |n| delta, u(Y) within |a| delta of that interval, v(Y) within |b| delta: three slabs in tau.
+//     Conservative (delta carries 1 % + 1 mm of slack for the fp32 evaluation); a lane without the bit contributes
+//     nothing for that rectangle, exactly like a ray that fails soft_uv's own test.
+__device__ __forceinline__ unsigned cone_mask(const Prim* __restrict__ prims, const PrimAux* __restrict__ aux, int n, float ox,
+                                              float oy, float oz, float dx, float dy, float dz, float cos_t, float sin_t,
+                                              bool slabs = true)
 {
 #pragma clang fp contract(fast)
     unsigned mask = 0u;
@@ -520,7 +544,30 @@ __device__ __forceinline__ unsigned cone_mask(const Prim* __restrict__ prims, in
         const float t = wx * dx + wy * dy + wz * dz;
         const float perp = sqrtf(fmaxf(l2 - t * t, 0.0f));
         const float rho = prims[k].rho;
-        if (perp * cos_t - t * sin_t <= rho || l2 <= rho * rho) mask |= 1u << k;
+        if (!(perp * cos_t - t * sin_t <= rho || l2 <= rho * rho)) continue;
+        if (slabs && cos_t > 0.0f) {
+            const Prim q = prims[k];
+            const PrimAux x = aux[k];
+            const float delta = (sqrtf(l2) + rho) * sin_t * 1.01f + 1e-3f;
+            const float rx = ox - q.c0x, ry = oy - q.c0y, rz = oz - q.c0z;
+            const float f[3] = {rx * q.nx + ry * q.ny + rz * q.nz, rx * x.ax + ry * x.ay + rz * x.az,
+                                rx * x.bx + ry * x.by + rz * x.bz};
+            const float g[3] = {dx * q.nx + dy * q.ny + dz * q.nz, dx * x.ax + dy * x.ay + dz * x.az,
+                                dx * x.bx + dy * x.by + dz * x.bz};
+            const float nn = sqrtf(q.nx * q.nx + q.ny * q.ny + q.nz * q.nz);
+            const float lo[3] = {-nn * delta, -kBlockMargin - x.an * delta, -kBlockMargin - x.bn * delta};
+            const float hi[3] = {nn * delta, 1.0f + kBlockMargin + x.an * delta, 1.0f + kBlockMargin + x.bn * delta};
+            float entry = 0.0f, exit_ = 3.0e38f;         // tau >= 0
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float inv = 1.0f / (fabsf(g[c]) > 1e-12f ? g[c] : 1e-12f);
+                const float t0 = (lo[c] - f[c]) * inv, t1 = (hi[c] - f[c]) * inv;
+                entry = fmaxf(entry, fminf(t0, t1));
+                exit_ = fminf(exit_, fmaxf(t0, t1));
+            }
+            if (!(exit_ >= entry)) continue;
+        }
+        mask |= 1u << k;
     }
     return mask;
 }

@@ -37,6 +37,7 @@ struct TraceArgs {
     const int32_t* cand_count;  // [H]
     int Cmax;
     float cone_cos, cone_sin;   // of the largest angle between a ray and its point's chief ray (0, 0: unknown)
+    int slab_cull;              // per-point rectangle culling also by the three slabs of cone_mask (ray_math.hpp)
     float mag, k_ext, k_refl;
     int H, R, P, T, Tc, W, Hh;  // target index t < T: planar area t; T <= t < T + Tc: cylinder t - T
     int mode;                 // 0: bitmap per heliostat, 1: bitmap per target
@@ -160,7 +161,7 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
     a.cyl_centers = cyl_centers; a.cyl_normals = cyl_normals; a.cyl_axes = cyl_axes; a.cyl_radii = cyl_radii;
     a.cyl_heights = cyl_heights; a.cyl_opening = cyl_opening; a.Tc = (int)Tc;
     a.prim_corners = a.prim_spans = a.prim_normals = nullptr; a.cand = a.cand_count = nullptr; a.Cmax = 0;
-    a.cone_cos = a.cone_sin = 0.0f;
+    a.cone_cos = a.cone_sin = 0.0f; a.slab_cull = 1;
     a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
     a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;
     a.n_ptiles = (int)((P + kBlock - 1) / kBlock);
@@ -172,8 +173,10 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
 
 // Largest angle between a scattered ray and its point's chief ray: the two rotations of rotate_distortions compose
 // to at most sqrt(2) x the larger angle (+ slack).  A negative bound = unknown: the per-point cone test accepts all.
+static inline int env_int(const char* name, int dflt);
 static inline void set_cone(TraceArgs& a, double max_scatter_angle)
 {
+    a.slab_cull = env_int("ARTIST_HIP_BLOCK_SLABS", 1) != 0;     // 0: sphere test only (diagnostic; same results)
     if (max_scatter_angle < 0.0) { a.cone_cos = a.cone_sin = 0.0f; return; }
     double theta = 1.4143 * max_scatter_angle * 1.001 + 1e-4;
     if (theta > 1.5) { a.cone_cos = a.cone_sin = 0.0f; return; }

@@ -390,8 +390,8 @@ __device__ __forceinline__ void timeline_mark(int slot, int k)
 #define ART_TIMELINE(k)
 #endif
 
-template <bool BLOCKING> struct PrimTable { Prim prim[kMaxCand]; int id[kMaxCand]; float grad[kMaxCand * 12]; };
-template <> struct PrimTable<false> { Prim prim[1]; int id[1]; float grad[1]; };
+template <bool BLOCKING> struct PrimTable { Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; float grad[kMaxCand * 12]; };
+template <> struct PrimTable<false> { Prim prim[1]; PrimAux aux[1]; int id[1]; float grad[1]; };
 
 // candidates of heliostat h -> LDS; returns their number (workgroup-uniform).  Ends with a barrier.
 template <bool BLOCKING>
@@ -403,6 +403,7 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
         const int k = a.cand[(int64_t)h * a.Cmax + c];
         tab.id[c] = k;
         tab.prim[c] = make_prim(a.prim_corners, a.prim_spans, a.prim_normals, k);
+        tab.aux[c] = make_prim_aux(tab.prim[c]);
     }
     for (int c = threadIdx.x; c < n * 12; c += blockDim.x) tab.grad[c] = 0.0f;
     __syncthreads();
@@ -572,7 +573,8 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
         if constexpr (BLOCKING) {
             if (n_prims > 0) {
                 const float il = rsqrtf(fmaxf(d.x * d.x + d.y * d.y + d.z * d.z, 1e-30f));
-                pmask = cone_mask(s_tab.prim, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin);
+                pmask = cone_mask(s_tab.prim, s_tab.aux, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin,
+                                  a.slab_cull != 0);
                 wmask = wave_or_mask(pmask, n_prims);
             }
         }
@@ -1473,7 +1475,8 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
         if constexpr (BLOCKING) {
             if (n_prims > 0) {
                 const float il = rsqrtf(fmaxf(d.x * d.x + d.y * d.y + d.z * d.z, 1e-30f));
-                pmask = cone_mask(s_tab.prim, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin);
+                pmask = cone_mask(s_tab.prim, s_tab.aux, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin,
+                                  a.slab_cull != 0);
                 wmask = wave_or_mask(pmask, n_prims);
             }
         }

@@ -929,6 +929,39 @@ def test_blocking_through_ray_tracer_mirror():
     assert rel_l2(n(points.grad), go + g_sfc) < 5e-3, rel_l2(n(points.grad), go + g_sfc)
 
 
+def test_per_point_rectangle_culling_changes_speed_only(monkeypatch):
+    """The trace kernels drop, per surface point, the rectangles none of the point's rays can enter (cone against bounding
+    sphere, then the three slabs of ``cone_mask``, ray_math.hpp) and the filter does the same with the grown boxes: both
+    tests are conservative, so a dense field that shades itself heavily gives the same bits with the slab test off, and
+    the same filtered set."""
+    from artist_amd import HeliostatRayTracer
+    from artist_amd.scene import build_synthetic_scenario
+    H, R = 48, 6
+    scenario, _ = build_synthetic_scenario(H, R, n_eval=24, device=DEV)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    i = torch.arange(H, device=DEV)
+    group.positions = torch.stack([((i % 8) - 3.5) * 4.2, 160.0 + (i // 8) * 5.0, torch.zeros(H, device=DEV),
+                                   torch.ones(H, device=DEV)], dim=1)
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    tix = torch.zeros(H, dtype=torch.long, device=DEV)
+    inc = torch.nn.functional.normalize(torch.tensor([0.0, 0.94, -0.34, 0.0], device=DEV), dim=0).expand(H, 4).contiguous()
+    group.activate_heliostats(mask, DEV)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask, DEV)
+
+    def run():
+        rt = HeliostatRayTracer(scenario, group, bitmap_resolution=torch.tensor([64, 64]))
+        rt.lbvh_compat = False
+        flux, intercept, on_target, unblocked = rt.trace_rays(inc, mask, tix)
+        return flux, unblocked, sorted(rt.filtered_blocking_primitive_indices.tolist())
+
+    flux, unblocked, kept = run()
+    assert float(unblocked.mean()) < 0.95 and len(kept) > H // 2              # the field does shade itself
+    monkeypatch.setenv("ARTIST_HIP_BLOCK_SLABS", "0")
+    flux0, unblocked0, kept0 = run()
+    assert kept == kept0
+    assert torch.equal(flux, flux0) and torch.equal(unblocked, unblocked0)
+
+
 @pytest.mark.parametrize("lbvh_compat", [True, False])
 def test_sharded_blocking_equals_single_rank(lbvh_compat):
     """Heliostat sharding with blocking on (each rank needs the rectangles of ALL heliostats, which the
