@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cstdio>
 #include <mutex>
 #include <vector>
@@ -1135,6 +1136,11 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
 // Everything the forward kernel is launched with, as ONE argument: the persistent loop below re-reads what an item
 // needs from the kernarg segment instead of carrying it in registers.
 struct FwdLaunch { TraceArgs a; float* flux; unsigned int* counts; unsigned int* work_counter; };
+// The blocking instantiations: one item per workgroup in the forward kernel (inside the persistent loop it spills enough
+// to lose 8 % in exact mode), the persistent loop in the backward kernel (same-box, tools/blocking_bench.py: backward of
+// exact mode 12.6 -> 11.8 ms, of reference-tree mode 5.3 -> 5.0 ms - its few dozen items no longer wait behind 5000
+// workgroups that exit at once but need a CU's LDS to do so).
+constexpr bool kBlockingPersistentFwd = false, kBlockingPersistentBwd = true;
 
 #ifndef ART_LEAN_FWD_THREADS
 #define ART_LEAN_FWD_THREADS 1024
@@ -1150,7 +1156,7 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : 1024) void trace_fwd_lds_k
 #else
     // The cylinder and blocking instantiations keep more values alive per ray; inside the persistent loop they spill
     // enough to lose 5-9 % (tools/blocking_bench.py, same-box A/B), so they take one item per workgroup.
-    constexpr bool single_item = CYL || BLOCKING;
+    constexpr bool single_item = CYL || (BLOCKING && !kBlockingPersistentFwd);
 #endif
     if constexpr (single_item) {
         if ((int)blockIdx.x < work_item_count(launch.a))
@@ -1974,7 +1980,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
     __shared__ int s_next;
     const int n_items = work_item_count(a);
     int item = blockIdx.x;
-    if constexpr (CYL || BLOCKING) {             // one item per workgroup, as in the forward kernel
+    if constexpr (CYL || (BLOCKING && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
         if (item < n_items)
             trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
                                                                    g_pnormals, decode_work_item(a, item), work_counter, &s_next);
@@ -2157,6 +2163,54 @@ static unsigned* next_work_counter(hipStream_t stream, bool zero = true)
 }
 
 
+// A split call (blocking on: lean launch for the heliostats with no candidate rectangle, blocking instantiation for the
+// others) runs its two launches side by side: with the reference's tree the blocking launch has a few dozen items for 256
+// CUs and would otherwise hold the stream for the length of one item (0.5 ms forward, 1 ms backward at the metric size);
+// in exact mode the second launch fills the first one's tail.  One side stream + two events per host thread and device,
+// created on first use and kept; fork/join by events, so it also works under stream capture.
+struct SideStream {
+    hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; int dev = -1; bool pending = false;
+    hipStream_t main = nullptr;
+    // the side launch depends on everything enqueued on `stream` SO FAR ...
+    bool begin(hipStream_t stream)
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return false;
+        if (dev != d) {
+            if (dev >= 0) return false;                 // (one device per process in this framework: no second set)
+            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { dev = -2; return false; }
+            dev = d;
+        }
+        if (hipEventRecord(fork, stream) != hipSuccess) return false;
+        main = stream;
+        return true;
+    }
+    // ... and is submitted later (after the main stream's launch): the side stream's work starts here
+    bool start()
+    {
+        if (hipStreamWaitEvent(side, fork, 0) != hipSuccess) return false;
+        pending = true;
+        return true;
+    }
+    // `stream` continues after the side launch
+    void end()
+    {
+        if (!pending) return;
+        pending = false;
+        if (hipEventRecord(join, side) == hipSuccess) (void)hipStreamWaitEvent(main, join, 0);
+        else (void)hipStreamSynchronize(side);
+    }
+};
+struct SideJoin { SideStream* s; ~SideJoin() { if (s) s->end(); } };      // error returns join too
+static SideStream* side_stream()
+{
+    thread_local SideStream s;
+    return env_int("ARTIST_HIP_BLOCKING_CONCURRENT", 1) != 0 ? &s : nullptr;
+}
+
+
 // Device status word: 4 bytes of mapped host memory per GPU, allocated on the first trace call and kept.  Kernels set
 // bit 0 when they meet a target index outside the tables (the heliostat is skipped); the host reads it without a
 // synchronisation at the start of every trace call (a failure of an EARLIER launch then surfaces as ART_ETARGET) and,
@@ -2333,6 +2387,8 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         a.scale_g = ldexpf(1.0f, 28 - a.ex_g);
         a.accum = reinterpret_cast<unsigned long long*>(accum);
     }
+    SideJoin side = {nullptr};
+    std::function<int()> launch_lean;
     if (cfg.variant == 0) {
         // the lean ray body (trace_fwd_item_lean): planar receivers, no blocking, positive and sanely scaled intensity
         // factors - then a valid ray is known to carry intensity and one counter serves both factors
@@ -2355,17 +2411,27 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
             const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(unsigned);
             const FwdLaunch launch = {al, flux, counts, work_counters[2]};
-            if (interleaved_layout(al)) {
-                ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true, false, false, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                hipLaunchKernelGGL((trace_fwd_lds_kernel<true, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block), lds_l,
-                                   stream, launch);
-            } else {
-                ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false, false, false, true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                hipLaunchKernelGGL((trace_fwd_lds_kernel<false, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block), lds_l,
-                                   stream, launch);
-            }
+            const bool il_l = interleaved_layout(al);
+            const int threads_l = cl.block;
+            // submitted AFTER the blocking launch (whose few long workgroups then start at once, on CUs of their own)
+            SideStream* ss = side_stream();
+            if (ss != nullptr && !ss->begin(stream)) ss = nullptr;
+            launch_lean = [=, &side]() -> int {
+                hipStream_t lean_stream = stream;
+                if (ss != nullptr && ss->start()) { side.s = ss; lean_stream = ss->side; }
+                if (il_l) {
+                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true, false, false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                    hipLaunchKernelGGL((trace_fwd_lds_kernel<true, false, false, true>), dim3((unsigned)blocks_l), dim3(threads_l),
+                                       lds_l, lean_stream, launch);
+                } else {
+                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false, false, false, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                    hipLaunchKernelGGL((trace_fwd_lds_kernel<false, false, false, true>), dim3((unsigned)blocks_l), dim3(threads_l),
+                                       lds_l, lean_stream, launch);
+                }
+                return ART_OK;
+            };
             a.split = 2;
         }
         if (lean && T > 0 && Tc == 0) {
@@ -2399,7 +2465,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // exits at once (the type is only known on the device)
 #define ART_LAUNCH_FWD(IL, CY, BL, LN)                                                                           \
         do {                                                                                                     \
-            const int64_t blocks = (CY || BL) ? items : persistent_blocks;     /* see trace_fwd_lds_kernel */    \
+            const int64_t blocks = (CY || (BL && !kBlockingPersistentFwd)) ? items : persistent_blocks;                \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL, LN>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             const FwdLaunch launch = {a, flux, counts, work_counters[CY ? 1 : 0]};                               \
@@ -2423,6 +2489,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
 #undef ART_LAUNCH_FWD_TYPE
 #undef ART_LAUNCH_FWD
         ART_HIP(hipGetLastError());
+        if (launch_lean) { const int rc = launch_lean(); if (rc != ART_OK) return rc; }
     } else {
         if (Tc > 0 || blocking) return ART_EUNSUPPORTED;   // the global-atomic A/B variant: planar, no blocking
         choose_chunks(a, 4096, 8);
@@ -2434,6 +2501,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             hipLaunchKernelGGL(trace_fwd_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a, flux, counts);
     }
     ART_HIP(hipGetLastError());
+    if (side.s) { side.s->end(); side.s = nullptr; }
     {   // accumulators -> fp32 bitmaps (every pixel is written: no memset of `flux`); accumulators back to zero
         const int64_t npix = n_maps * Hh * W;
         const float kI = (a.mag * a.k_ext) * a.k_refl;
@@ -2530,6 +2598,8 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             fprintf(stderr, "art_trace_bwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
                     a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean);
         const bool atomic_out = a.n_rchunks > 1;      // (round 1's name: today the chunks write slabs, nothing is atomic)
+        SideJoin side = {nullptr};                    // (joins `stream` when this scope is left, errors included)
+        std::function<int()> launch_lean;
         // Blocking on: the heliostats with an empty candidate list take the lean kernel in a launch of their own (see
         // art_trace_fwd) - for fields large enough that neither launch cuts a point's samples into chunks (the two would
         // need slabs of their own).
@@ -2556,17 +2626,28 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                 const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(float) + perm_l;
                 unsigned* wc = next_work_counter(stream);
                 if (wc == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
-                if (il) {
-                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<true, false, false, false, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                    hipLaunchKernelGGL((trace_bwd_lds_kernel<true, false, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block),
-                                       lds_l, stream, al, grad_flux, go, gn, grad_prim_corners, grad_prim_spans, grad_prim_normals, wc);
-                } else {
-                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<false, false, false, false, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                    hipLaunchKernelGGL((trace_bwd_lds_kernel<false, false, false, false, true>), dim3((unsigned)blocks_l), dim3(cl.block),
-                                       lds_l, stream, al, grad_flux, go, gn, grad_prim_corners, grad_prim_spans, grad_prim_normals, wc);
-                }
+                const int threads_l = cl.block;
+                // submitted AFTER the blocking launch (see art_trace_fwd)
+                SideStream* ss = side_stream();
+                if (ss != nullptr && !ss->begin(stream)) ss = nullptr;
+                launch_lean = [=, &side]() -> int {
+                    hipStream_t lean_stream = stream;
+                    if (ss != nullptr && ss->start()) { side.s = ss; lean_stream = ss->side; }
+                    if (il) {
+                        ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<true, false, false, false, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                        hipLaunchKernelGGL((trace_bwd_lds_kernel<true, false, false, false, true>), dim3((unsigned)blocks_l),
+                                           dim3(threads_l), lds_l, lean_stream, al, grad_flux, go, gn, grad_prim_corners,
+                                           grad_prim_spans, grad_prim_normals, wc);
+                    } else {
+                        ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<false, false, false, false, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
+                        hipLaunchKernelGGL((trace_bwd_lds_kernel<false, false, false, false, true>), dim3((unsigned)blocks_l),
+                                           dim3(threads_l), lds_l, lean_stream, al, grad_flux, go, gn, grad_prim_corners,
+                                           grad_prim_spans, grad_prim_normals, wc);
+                    }
+                    return ART_OK;
+                };
                 a.split = 2;
             }
         }
@@ -2580,7 +2661,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         }
 #define ART_LAUNCH_BWD(IL, AT, CY, BL, LN)                                                                       \
         do {                                                                                                     \
-            const int64_t blocks = (CY || BL) ? items : persistent_blocks;                                       \
+            const int64_t blocks = (CY || (BL && !kBlockingPersistentBwd)) ? items : persistent_blocks;             \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL, LN>),\
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = next_work_counter(stream);                                                  \
@@ -2618,6 +2699,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
 #undef ART_LAUNCH_BWD_BL
 #undef ART_LAUNCH_BWD
         ART_HIP(hipGetLastError());
+        if (launch_lean) { const int rc = launch_lean(); if (rc != ART_OK) return rc; }
         if (atomic_out) {
             const int64_t n = H * P;
             hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, go, gn, a.n_rchunks, n,
