@@ -1141,13 +1141,15 @@ struct FwdLaunch { TraceArgs a; float* flux; unsigned int* counts; unsigned int*
 // exact mode 12.6 -> 11.8 ms, of reference-tree mode 5.3 -> 5.0 ms - its few dozen items no longer wait behind 5000
 // workgroups that exit at once but need a CU's LDS to do so).
 constexpr bool kBlockingPersistentFwd = false, kBlockingPersistentBwd = true;
+constexpr bool kCylPersistentBwd = false;       // (measured neutral: 18.57 vs 18.43 ms)
 
 #ifndef ART_LEAN_FWD_THREADS
 #define ART_LEAN_FWD_THREADS 1024
 #endif
 constexpr int kLeanFwdThreads = ART_LEAN_FWD_THREADS;
+constexpr int kCylFwdThreads = 1024;             // (768: within the noise of the box, 512: 17 % slower)
 template <bool INTERLEAVED, bool CYL, bool BLOCKING, bool LEAN = false>
-__global__ __launch_bounds__(LEAN ? kLeanFwdThreads : 1024) void trace_fwd_lds_kernel(FwdLaunch launch)
+__global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
     static_assert(!LEAN || (!CYL && !BLOCKING), "the lean ray body is the planar, non-blocking one");
     __shared__ int s_next, s_reverse;
@@ -1358,8 +1360,8 @@ __device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsFl
     return out;
 }
 
-// (The cylinder and blocking instantiations keep ~60 more live values per ray; they run 512-thread workgroups =
-// 256 VGPRs.)
+// (The cylinder and blocking instantiations keep ~60 more live values per ray; they run 768-thread workgroups =
+// 168 VGPRs, see kCylBwdThreads.)
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
 __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* __restrict__ grad_flux,
                                                float4* __restrict__ grad_origins, float4* __restrict__ grad_normals,
@@ -1966,9 +1968,10 @@ constexpr int kLeanBwdThreads = 768;
 // 2 x 5000 4.08.  The trips of a block need not be full: 2500 points = 768 + 768 + 768 + 196 threads beat four equal trips of
 // 640 threads (4.28 ms) - a trip costs what its active waves issue, not a fixed time.
 constexpr int kLeanBwdPoints = 2560;
-// (cylinder adjoint: 512-thread workgroups, it keeps ~60 more values alive; planar blocking: 768 - 160 B of spills but three
-//  waves per SIMD, forward + backward of the blocking bench's exact mode 30.5 -> 29.0 ms)
-constexpr int kCylBwdThreads = 512, kBlockingBwdThreads = 768;
+// (768-thread workgroups for the cylinder adjoint and the planar blocking instantiation: they keep ~60 more values alive per
+//  ray than the plain body, and three waves per SIMD with a few spills beat two without - same-box, tools/cylinder_bench.py:
+//  512 -> 768 threads 18.6 -> 17.0 ms forward + backward, 1024 threads 17.9; tools/blocking_bench.py exact mode 30.5 -> 29.0)
+constexpr int kCylBwdThreads = 768, kBlockingBwdThreads = 768;
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
 __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThreads : (LEAN ? kLeanBwdThreads : 1024))) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
@@ -1980,7 +1983,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
     __shared__ int s_next;
     const int n_items = work_item_count(a);
     int item = blockIdx.x;
-    if constexpr (CYL || (BLOCKING && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
+    if constexpr ((CYL && !kCylPersistentBwd) || (!CYL && BLOCKING && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
         if (item < n_items)
             trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
                                                                    g_pnormals, decode_work_item(a, item), work_counter, &s_next);
@@ -2469,7 +2472,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL, LN>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             const FwdLaunch launch = {a, flux, counts, work_counters[CY ? 1 : 0]};                               \
-            hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL, LN>), dim3((unsigned)blocks), dim3(cfg.block),  \
+            hipLaunchKernelGGL((trace_fwd_lds_kernel<IL, CY, BL, LN>), dim3((unsigned)blocks), dim3(CY ? std::min(cfg.block, kCylFwdThreads) : cfg.block),  \
                                lds, stream, launch);                                                             \
         } while (0)
 #define ART_LAUNCH_FWD_TYPE(CY)                                                                                  \
@@ -2661,7 +2664,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         }
 #define ART_LAUNCH_BWD(IL, AT, CY, BL, LN)                                                                       \
         do {                                                                                                     \
-            const int64_t blocks = (CY || (BL && !kBlockingPersistentBwd)) ? items : persistent_blocks;             \
+            const int64_t blocks = ((CY && !kCylPersistentBwd) || (!CY && BL && !kBlockingPersistentBwd)) ? items : persistent_blocks; \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL, LN>),\
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = next_work_counter(stream);                                                  \
