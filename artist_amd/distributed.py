@@ -10,6 +10,8 @@ artist/optim/surface_reconstructor.py:767-777).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,10 +24,18 @@ def owned_heliostats(n_heliostats: int, world_size: int, rank: int) -> list[int]
     return list(RestrictedDistributedSampler(n_heliostats, n_heliostats, world_size, rank))
 
 
+def _exchanging(group=None) -> bool:
+    """Is there anybody to exchange with?  ``ARTIST_AMD_COLLECTIVES_AT_WORLD_1=1`` makes a one-rank process group issue its
+    collectives too - a rehearsal of the RCCL calls (streams, async handles, dtypes) on a box with a single GPU."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("ARTIST_AMD_COLLECTIVES_AT_WORLD_1", "0") == "1"
+
+
 def all_reduce_sum(tensor: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM all-reduce; a no-op in a single-process run (same silent fallback as
     artist/util/env.py:70-84)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _exchanging(group):
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
     return tensor
 
@@ -33,7 +43,7 @@ def all_reduce_sum(tensor: torch.Tensor, group=None) -> torch.Tensor:
 def all_reduce_sum_async(tensor: torch.Tensor, group=None):
     """Start an in-place SUM all-reduce and return a ``wait()``-able handle (None in a single-process run), so that
     the 256 KB flux reduce travels over xGMI while the backward kernels run."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _exchanging(group):
         return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 
@@ -59,7 +69,7 @@ def gather_owned_rows(local_rows: torch.Tensor, n_total: int, group=None, async_
     Ragged shards (``n_total`` not a multiple of the world size) fall back to that all-reduce.
     ``async_op=True`` returns a handle whose ``wait()`` gives the tensor: the exchange then travels while the caller's
     optimiser step (which needs the own rows only) runs."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchanging(group):
         return _PendingRows(None, lambda: local_rows) if async_op else local_rows
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if n_total % world != 0:

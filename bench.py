@@ -183,7 +183,9 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # (ARTIST_AMD_COLLECTIVES_AT_WORLD_1=1 under a one-rank torch.distributed.run: the RCCL calls of the N>1 path on one GPU)
+    rehearse = world == 1 and "RANK" in os.environ and os.environ.get("ARTIST_AMD_COLLECTIVES_AT_WORLD_1", "0") == "1"
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm (xGMI inside a node).  ARTIST_BENCH_BACKEND=gloo exists only to rehearse the
         # N>1 code path with several ranks sharing one GPU (RCCL refuses duplicate devices).
@@ -275,7 +277,7 @@ def main():
         del f0
 
     def sync():
-        if world > 1:
+        if world > 1 or rehearse:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -286,7 +288,7 @@ def main():
             fn()
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if world > 1 or rehearse:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -405,7 +407,7 @@ def main():
             out["cpu_baseline"]["reference_shape_torch"] = torch_eager_baseline(
                 args, ap[:min(H, 64)].cpu(), an[:min(H, 64)].cpu(), inc[:min(H, 64)].cpu(), planar, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 
