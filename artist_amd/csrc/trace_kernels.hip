@@ -391,8 +391,9 @@ __device__ __forceinline__ void timeline_mark(int slot, int k)
 #define ART_TIMELINE(k)
 #endif
 
-template <bool BLOCKING> struct PrimTable { Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; float grad[kMaxCand * 12]; };
-template <> struct PrimTable<false> { Prim prim[1]; PrimAux aux[1]; int id[1]; float grad[1]; };
+// (grad is DOUBLE: on gfx950 ds_add_f64 retires a wave instruction in ~25 cycles, ds_add_f32 in ~193 - tools/lds_atomic_bench.hip)
+template <bool BLOCKING> struct PrimTable { Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; double grad[kMaxCand * 12]; };
+template <> struct PrimTable<false> { Prim prim[1]; PrimAux aux[1]; int id[1]; double grad[1]; };
 
 // candidates of heliostat h -> LDS; returns their number (workgroup-uniform).  Ends with a barrier.
 template <bool BLOCKING>
@@ -406,7 +407,7 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
         tab.prim[c] = make_prim(a.prim_corners, a.prim_spans, a.prim_normals, k);
         tab.aux[c] = make_prim_aux(tab.prim[c]);
     }
-    for (int c = threadIdx.x; c < n * 12; c += blockDim.x) tab.grad[c] = 0.0f;
+    for (int c = threadIdx.x; c < n * 12; c += blockDim.x) tab.grad[c] = 0.0;
     __syncthreads();
     return n;
 }
@@ -1317,8 +1318,8 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
 // goes back to an SGPR, the ray-side gradients return by value (references would go through scratch memory).
 struct RayGrad { float ox, oy, oz, rx, ry, rz; };
 typedef const __attribute__((address_space(3))) Prim* LdsPrims;
-typedef __attribute__((address_space(3))) float* LdsFloats;
-__device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsFloats s_gprim, unsigned wave_mask, unsigned near,
+typedef __attribute__((address_space(3))) double* LdsDoubles;
+__device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsDoubles s_gprim, unsigned wave_mask, unsigned near,
                                                            float ox, float oy, float oz, float rx, float ry, float rz,
                                                            float g_sigma)
 {
@@ -1343,14 +1344,14 @@ __device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsFl
         if (on) {     // other lanes may hold non-finite intermediates: branch, do not multiply
             out.ox += g.ox; out.oy += g.oy; out.oz += g.oz;
             out.rx += g.rx; out.ry += g.ry; out.rz += g.rz;
-            LdsFloats acc = s_gprim + 12 * k;
+            LdsDoubles acc = s_gprim + 12 * k;
 #ifndef ART_ABLATE_NO_BLOCK_ATOMICS
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                __hip_atomic_fetch_add(acc + c, g.c0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + 3 + c, g.su[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + 6 + c, g.sv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + 9 + c, g.n[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + c, (double)g.c0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + 3 + c, (double)g.su[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + 6 + c, (double)g.sv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(acc + 9 + c, (double)g.n[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
 #else
             acc[0] = g.c0[0] + g.su[1] + g.sv[2] + g.n[0];
@@ -1513,7 +1514,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
                     const bool adj = near != 0u && g_keep != 0.0f && trans > 1e-30f;
 #endif
                     if (wave_any(adj)) {
-                        const RayGrad b = block_adjoint((LdsPrims)s_tab.prim, (LdsFloats)s_tab.grad, wmask, adj ? near : 0u, o.x, o.y,
+                        const RayGrad b = block_adjoint((LdsPrims)s_tab.prim, (LdsDoubles)s_tab.grad, wmask, adj ? near : 0u, o.x, o.y,
                                                         o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
                         bgx += b.ox; bgy += b.oy; bgz += b.oz;
                         gdx += m.cu * b.rx + m.m10 * b.ry + m.m20 * b.rz;
@@ -1675,7 +1676,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     if (win.npass < 1 && tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));   // (never: npass >= 1)
     if constexpr (BLOCKING) {      // rectangle gradients of this workgroup -> the primitive tables
         for (int c = tid; c < n_prims * 12; c += blockDim.x) {
-            const float v = s_tab.grad[c];
+            const float v = (float)s_tab.grad[c];
             if (v == 0.0f) continue;
             const int64_t id = s_tab.id[c / 12];
             const int part = (c % 12) / 3, comp = c % 3;
