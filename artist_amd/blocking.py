@@ -27,6 +27,9 @@ def _spans_and_normals(corners: torch.Tensor) -> tuple[torch.Tensor, torch.Tenso
     return spans, normals
 
 
+_CORNER_INDEX: dict = {}
+
+
 def create_blocking_primitives_rectangles_by_index(blocking_heliostats_active_surface_points: torch.Tensor,
                                                    device: torch.device | None = None
                                                    ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -39,7 +42,10 @@ def create_blocking_primitives_rectangles_by_index(blocking_heliostats_active_su
     pts = blocking_heliostats_active_surface_points
     P = pts.shape[1]
     side = math.sqrt(P / 4)
-    index = torch.tensor([int(P / 2), int(side - 1), int((P / 2) - 1), int(P - side)], device=pts.device)
+    key = (P, pts.device)
+    index = _CORNER_INDEX.get(key)
+    if index is None:      # (a host list -> device tensor copy waits for the stream: once per shape, not once per trace call)
+        index = _CORNER_INDEX[key] = torch.tensor([int(P / 2), int(side - 1), int((P / 2) - 1), int(P - side)], device=pts.device)
     corners = pts.index_select(1, index)
     spans, normals = _spans_and_normals(corners)
     return corners, spans, normals

@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
 // cand[h] <- its flagged entries (the heliostat's own rectangle included when foreign rays flagged it: the
 // reference's mask is evaluated against every filtered primitive for every ray).
 __global__ void compact_kernel(int* __restrict__ cand, int* __restrict__ cand_count, int H, int Cmax,
-                               const int* __restrict__ flags)
+                               const int* __restrict__ flags, unsigned* __restrict__ status)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
@@ -443,8 +443,10 @@ __global__ void compact_kernel(int* __restrict__ cand, int* __restrict__ cand_co
         const int k = cand[(int64_t)h * Cmax + c];
         if (flags[k]) cand[(int64_t)h * Cmax + m++] = k;
     }
-    // a count above Cmax (overflow of the cull) is kept so that the host can see it
+    // a count above Cmax (overflow of the cull) is kept so that the host can see it, and reported through the device
+    // status word (art_async_status / the next trace call: ART_ECANDIDATES) - no host read of the counts per call
     if (cand_count[h] <= Cmax) cand_count[h] = m;
+    else if (status != nullptr) atomicOr(status, 2u);
 }
 
 static int next_pow2(int64_t n)
@@ -537,7 +539,7 @@ extern "C" int art_blocking_filter(const float* origins, const float* normals, c
         hipLaunchKernelGGL(blocking_filter_kernel<false>, dim3((unsigned)blocks), dim3(kFilterBlock), 0, stream, a,
                            prim_corners, owner, cand, cand_count, (int)Cmax, live, flags);
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, cand, cand_count, (int)H,
-                       (int)Cmax, flags);
+                       (int)Cmax, flags, status_word().dev);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

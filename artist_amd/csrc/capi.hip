@@ -17,6 +17,7 @@ extern "C" const char* art_strerror(int code)
         case ART_ETARGET: return "target index out of range";
         case ART_ELAUNCH: return "HIP runtime/launch error (see art_last_hip_error)";
         case ART_EUNSUPPORTED: return "unsupported configuration";
+        case ART_ECANDIDATES: return "a heliostat has more blocking rectangles inside its ray cone than the kernels hold";
         default: return "unknown error";
     }
 }

@@ -1,6 +1,7 @@
 // trace_common.hpp - argument block and distortion fetch shared by the trace and blocking kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <math.h>
 #include <stdlib.h>
@@ -194,6 +195,31 @@ static inline int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+}
+
+
+// Device status word: 4 bytes of mapped host memory per GPU, allocated on the first trace call and kept.  Kernels set
+// bit 0 when they meet a target index outside the tables (the heliostat is skipped), bit 1 when a heliostat has more
+// candidate rectangles inside its ray cone than the tables hold (art_blocking_filter; the surplus is not evaluated); the host reads it without a
+// synchronisation at the start of every trace call (a failure of an EARLIER launch then surfaces as ART_ETARGET / ART_ECANDIDATES) and,
+// synchronised, in art_async_status.
+struct StatusWord { unsigned* host; unsigned* dev; };
+inline StatusWord status_word()
+{
+    constexpr int kMaxDevices = 64;
+    static StatusWord words[kMaxDevices] = {};
+    static std::mutex lock;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return {nullptr, nullptr};
+    std::lock_guard<std::mutex> guard(lock);
+    if (words[dev].host == nullptr) {
+        unsigned* h = nullptr; unsigned* d = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) return {nullptr, nullptr};
+        *h = 0u;
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipHostFree(h); return {nullptr, nullptr}; }
+        words[dev] = {h, d};
+    }
+    return words[dev];
 }
 
 

@@ -2215,29 +2215,6 @@ static SideStream* side_stream()
 }
 
 
-// Device status word: 4 bytes of mapped host memory per GPU, allocated on the first trace call and kept.  Kernels set
-// bit 0 when they meet a target index outside the tables (the heliostat is skipped); the host reads it without a
-// synchronisation at the start of every trace call (a failure of an EARLIER launch then surfaces as ART_ETARGET) and,
-// synchronised, in art_async_status.
-struct StatusWord { unsigned* host; unsigned* dev; };
-static StatusWord status_word()
-{
-    constexpr int kMaxDevices = 64;
-    static StatusWord words[kMaxDevices] = {};
-    static std::mutex lock;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return {nullptr, nullptr};
-    std::lock_guard<std::mutex> guard(lock);
-    if (words[dev].host == nullptr) {
-        unsigned* h = nullptr; unsigned* d = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void**>(&h), 64, hipHostMallocMapped) != hipSuccess) return {nullptr, nullptr};
-        *h = 0u;
-        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0) != hipSuccess) { (void)hipHostFree(h); return {nullptr, nullptr}; }
-        words[dev] = {h, d};
-    }
-    return words[dev];
-}
-
 // Workgroups that run at once: one per CU (a window fills the CU's LDS).
 static int resident_workgroups()
 {
@@ -2360,6 +2337,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         return ART_EINVAL;
     const StatusWord status = status_word();
     if (status.host != nullptr && (*status.host & 1u)) return ART_ETARGET;     // an earlier launch met a bad target index
+    if (status.host != nullptr && (*status.host & 2u)) return ART_ECANDIDATES; // ... or more candidate rectangles than the tables hold
     a.status = status.dev;
     const bool blocking = prim_corners != nullptr;
     if (blocking) {
@@ -2553,6 +2531,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     {
         const StatusWord status = status_word();
         if (status.host != nullptr && (*status.host & 1u)) return ART_ETARGET;
+        if (status.host != nullptr && (*status.host & 2u)) return ART_ECANDIDATES;
         a.status = status.dev;
     }
     const bool blocking = prim_corners != nullptr;
@@ -2767,5 +2746,5 @@ extern "C" int art_async_status(void* stream_, int clear)
     ART_HIP(hipStreamSynchronize(stream));
     const unsigned word = *status.host;
     if (clear) *status.host = 0u;
-    return (word & 1u) ? ART_ETARGET : ART_OK;
+    return (word & 1u) ? ART_ETARGET : ((word & 2u) ? ART_ECANDIDATES : ART_OK);
 }

@@ -21,10 +21,11 @@ def target_dimensions(solar_tower, target_area_indices: torch.Tensor) -> torch.T
     """``[B,2]`` (width, height) in metres of each bitmap's target area by GLOBAL index, planar first, cylindrical
     second: planar ``dimensions``, or ``radius * opening_angle`` and ``height`` (bitmap.py:183-216)."""
     tables = []
-    n_per_type = solar_tower.number_of_target_areas_per_type
-    if int(n_per_type[0]) > 0:
+    from .raytracing import target_area_counts
+    n_per_type = target_area_counts(solar_tower)          # (host side: no read of the tower's device tensor)
+    if n_per_type[0] > 0:
         tables.append(solar_tower.target_areas[0].dimensions.to(torch.float32))
-    if len(solar_tower.target_areas) > 1 and int(n_per_type[1]) > 0:
+    if n_per_type[1] > 0:
         cyl = solar_tower.target_areas[1]
         tables.append(torch.stack((cyl.radii.reshape(-1) * cyl.opening_angles.reshape(-1), cyl.heights.reshape(-1)), dim=1)
                       .to(torch.float32))

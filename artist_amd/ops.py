@@ -122,14 +122,18 @@ def _accumulators(dev: torch.device, n: int) -> torch.Tensor:
 
 def check_async_errors(device=None, clear: bool = True) -> None:
     """Synchronise the current stream of ``device`` and raise if a kernel met a target index outside the target
-    tables (``art_async_status``): the entry points are asynchronous, so the device-side range check reports here -
-    or at the next trace call, which refuses to start while the status is set."""
+    tables or the blocking filter found more candidate rectangles for a heliostat than the kernels hold
+    (``art_async_status``): the entry points are asynchronous, so the device-side checks report here - or at the
+    next trace call, which refuses to start while the status is set."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     with torch.cuda.device(dev):
         rc = _lib.lib().art_async_status(_stream(dev), 1 if clear else 0)
     if rc == -2:
         _ACCUM.clear()              # a skipped heliostat leaves nothing behind, but take no chances with the invariant
         raise IndexError("target_area_indices out of range (found by the kernels: art_async_status)")
+    if rc == -5:
+        raise _lib.ArtistHipError(f"a heliostat has more than {BLOCKING_CANDIDATES} blocking rectangles inside its ray cone "
+                                  "(found by art_blocking_filter: art_async_status); its blocking would be incomplete")
     _lib.check(rc, "art_async_status")
 
 
@@ -195,10 +199,8 @@ class TraceRays(torch.autograd.Function):
                     owner.data_ptr(), N, float(max_scatter_angle), 1 if lbvh_compat else 0, Cmax, flags.data_ptr(),
                     cand.data_ptr(), cand_count.data_ptr(), workspace.data_ptr(), _stream(dev))
             _lib.check(rc, "art_blocking_filter")
-            most = int(cand_count.max())
-            if most > Cmax:
-                raise _lib.ArtistHipError(
-                    f"a heliostat has {most} blocking rectangles inside its ray cone; the kernels hold {Cmax}")
+            # (more than Cmax rectangles inside a heliostat's ray cone: the device reports it - ART_ECANDIDATES from
+            #  check_async_errors() or from the next trace call - instead of a host read of the counts in every call)
             block_tabs = (prim_corners, prim_spans, prim_normals, cand, cand_count)
             block_ptrs = tuple(t.data_ptr() for t in block_tabs)
 

@@ -39,11 +39,29 @@ def reflect(incident_ray_directions: torch.Tensor, reflection_surface_normals: t
             * reflection_surface_normals)
 
 
+def target_area_counts(tower) -> tuple[int, int]:
+    """(planar, cylindrical) target areas of a tower, from the HOST side of its tables (``number_of_target_areas`` is
+    ``len(names)``, artist/field/tower_target_areas.py:62): ``solar_tower.number_of_target_areas_per_type``
+    is a device tensor, and reading it costs a host-device synchronisation in every call."""
+    counts = []
+    for k in range(2):
+        if k >= len(tower.target_areas):
+            counts.append(0)
+            continue
+        area = tower.target_areas[k]
+        n = getattr(area, "number_of_target_areas", None)
+        if not isinstance(n, int):
+            table = getattr(area, "centers", None)
+            n = int(table.shape[0]) if table is not None else 0
+        counts.append(n)
+    return counts[0], counts[1]
+
+
 def _planar_tables(tower, device):
     """(centers [T,4], normals [T,4], dimensions [T,2]) of ``solar_tower.target_areas[planar]``; empty tables when
     the tower has cylindrical receivers only."""
     planar = tower.target_areas[0]
-    if int(tower.number_of_target_areas_per_type[0]) == 0 or not hasattr(planar, "centers"):
+    if target_area_counts(tower)[0] == 0 or not hasattr(planar, "centers"):
         z = torch.zeros((0, 4), device=device)
         return z, z, torch.zeros((0, 2), device=device)
     return planar.centers, planar.normals, planar.dimensions
@@ -52,7 +70,7 @@ def _planar_tables(tower, device):
 def _cylinder_tables(tower):
     """The six ``TowerTargetAreasCylindrical`` tensors (artist/field/tower_target_areas_cylindrical.py:52-102) or
     None when the tower has none."""
-    if len(tower.target_areas) < 2 or int(tower.number_of_target_areas_per_type[1]) == 0:
+    if target_area_counts(tower)[1] == 0:
         return None
     c = tower.target_areas[1]
     return (c.centers, c.normals, c.axes, c.radii, c.heights, c.opening_angles)
@@ -116,7 +134,8 @@ class HeliostatRayTracer:
         self._checked_targets = None
         self.lbvh_compat = True
         #: indices of the rectangles the last ``trace_rays`` call filtered (blocking only)
-        self.filtered_blocking_primitive_indices = None
+        self._filter_flags = self._filtered = None
+        self._owner_cache = None
 
         if dni is not None:
             # heliostat_ray_tracer.py:185-201
@@ -189,8 +208,21 @@ class HeliostatRayTracer:
             _cylinder_tables(tower), *(self._blocking_arguments(idx, active_heliostats_mask) or (None, None, None, None, -1.0, True)),
             self._points_per_facet(points))
         if self.blocking_active:
-            self.filtered_blocking_primitive_indices = torch.nonzero(flags, as_tuple=True)[0]
+            self._filter_flags, self._filtered = flags, None       # (indices on demand: nonzero() waits for the device)
         return flux, factors[0], factors[1], factors[2]
+
+    @property
+    def filtered_blocking_primitive_indices(self):
+        """Indices of the blocking rectangles the last ``trace_rays`` call kept (heliostat_ray_tracer.py:445-461) or None.
+        The call leaves one flag per rectangle on the device; the index list is made when somebody reads it, so an epoch
+        that never looks at it has no host-device synchronisation in its ray tracing."""
+        if self._filtered is None and self._filter_flags is not None:
+            self._filtered = torch.nonzero(self._filter_flags, as_tuple=True)[0]
+        return self._filtered
+
+    @filtered_blocking_primitive_indices.setter
+    def filtered_blocking_primitive_indices(self, value) -> None:
+        self._filter_flags, self._filtered = None, value
 
     def _points_per_facet(self, points) -> int:
         """The group's surface tensors are facet-major ``[H, F * M, 4]`` (heliostat_group.py:26-63): tell the kernels M, so
@@ -209,7 +241,7 @@ class HeliostatRayTracer:
         if target_area_indices.numel() > 0 and not (checked is not None and checked[0]() is target_area_indices and
                                                      checked[1] == target_area_indices._version):
             lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
-            if lo < 0 or hi >= int(tower.number_of_target_areas_per_type.sum()):
+            if lo < 0 or hi >= sum(target_area_counts(tower)):
                 raise IndexError("target_area_indices out of range")
             self._checked_targets = (weakref.ref(target_area_indices), target_area_indices._version)
 
@@ -218,9 +250,14 @@ class HeliostatRayTracer:
         if not self.blocking_active:
             return ()
         corners, spans, normals = create_blocking_primitives_rectangles_by_index(self.blocking_heliostat_surfaces_active)
-        owner = torch.nonzero(active_heliostats_mask, as_tuple=True)[0]
-        if idx is not None:
-            owner = owner.index_select(0, idx.to(owner.device))
+        # rectangle index of each active heliostat: once per mask tensor object and version (nonzero() waits for the device)
+        cached = self._owner_cache
+        if cached is None or cached[0]() is not active_heliostats_mask or cached[1] != active_heliostats_mask._version:
+            owner = torch.nonzero(active_heliostats_mask, as_tuple=True)[0]
+            if idx is not None:
+                owner = owner.index_select(0, idx.to(owner.device))
+            self._owner_cache = cached = (weakref.ref(active_heliostats_mask), active_heliostats_mask._version, owner)
+        owner = cached[2]
         return corners, spans, normals, owner, self._max_scatter_angle(), self.lbvh_compat
 
     def _max_scatter_angle(self) -> float:
@@ -264,11 +301,11 @@ class HeliostatRayTracer:
             _cylinder_tables(tower), *(self._blocking_arguments(idx, active_heliostats_mask) or (None, None, None, None, -1.0, True)),
             self._points_per_facet(points))
         if self.blocking_active:
-            self.filtered_blocking_primitive_indices = torch.nonzero(flags, as_tuple=True)[0]
+            self._filter_flags, self._filtered = flags, None       # (indices on demand: nonzero() waits for the device)
         return flux, factors[0], factors[1], factors[2]
 
     def get_bitmaps_per_target(self, bitmaps_per_heliostat: torch.Tensor, target_area_indices: torch.Tensor,
                                device: torch.device | None = None) -> torch.Tensor:
         """Bitmaps per heliostat -> bitmaps per target area ``[T,res_u,res_e]`` (:563-608)."""
-        n_targets = int(self.scenario.solar_tower.number_of_target_areas_per_type.sum())
+        n_targets = sum(target_area_counts(self.scenario.solar_tower))
         return ops.per_target_sum(bitmaps_per_heliostat, target_area_indices, n_targets)

@@ -30,6 +30,7 @@ extern "C" {
 #define ART_ETARGET -2     /* a target index was outside [0, T + Tc): found on the DEVICE (art_async_status) */
 #define ART_ELAUNCH -3     /* HIP launch or runtime error (see art_last_hip_error) */
 #define ART_EUNSUPPORTED -4
+#define ART_ECANDIDATES -5 /* a heliostat has more blocking rectangles inside its ray cone than Cmax: found on the DEVICE (art_async_status) */
 
 /* Library / ABI version (bumped when a signature changes). */
 int art_abi_version(void);
@@ -106,8 +107,10 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
  * art_async_status - the entry points are asynchronous, so what only the DEVICE can find out is reported here:
  * synchronises `stream` and returns ART_ETARGET if a kernel launched through this library met a target index
  * outside [0, T + Tc) since the status was last cleared (the heliostat was skipped - no table is indexed out of
- * bounds - and its bitmap and factors are zero), ART_OK otherwise.  `clear` != 0 resets the status.  Until it is
- * cleared, every later art_trace_fwd / art_trace_bwd call returns ART_ETARGET at once (checked without a
+ * bounds - and its bitmap and factors are zero), ART_ECANDIDATES if art_blocking_filter found more than Cmax
+ * rectangles inside a heliostat's ray cone (the surplus is not evaluated: that heliostat's blocking is incomplete;
+ * cand_count[h] holds the number found), ART_OK otherwise.  `clear` != 0 resets the status.  Until it is
+ * cleared, every later art_trace_fwd / art_trace_bwd call returns the same code at once (checked without a
  * synchronisation).  The reference fails in the same situation with an IndexError from its target-area gather
  * (artist/raytracing/geometry.py:104-105).
  * ------------------------------------------------------------------------------------------- */

@@ -1036,6 +1036,35 @@ def test_target_index_out_of_range_is_reported_not_dereferenced(golden):
         ops.check_async_errors(DEV)
 
 
+def test_too_many_candidate_rectangles_are_reported_by_the_device(golden):
+    """More rectangles inside one heliostat's ray cone than the kernels' tables hold (32): the filter says so through the
+    device status word - no host read of the candidate counts in every call - ``check_async_errors`` raises, later trace
+    calls refuse to start until the status is cleared, and the library works as before afterwards."""
+    from artist_amd import ArtistHipError, _lib, ops, trace_rays
+    d = golden("small_blocking")
+    inp = trace_inputs(d)
+    blk = blocking_inputs(d)
+    good, _, flags = trace_rays(**inp, blocking=blk)
+    k = int(np.nonzero(n(flags))[0][0])                          # a rectangle that does block somebody
+    shifts = torch.arange(1, 41, device=DEV, dtype=torch.float32)[:, None, None] * 1e-3
+    extra = blk["corners"][k][None] + shifts * blk["normals"][k][None, None, :] * torch.tensor([1.0, 1.0, 1.0, 0.0], device=DEV)
+    crowded = dict(blk, corners=torch.cat([blk["corners"], extra]), spans=torch.cat([blk["spans"], blk["spans"][k][None].expand(40, -1, -1)]),
+                   normals=torch.cat([blk["normals"], blk["normals"][k][None].expand(40, -1)]))
+    try:
+        trace_rays(**inp, blocking=crowded)                       # asynchronous: normally no error yet
+    except ArtistHipError:
+        pass                                                      # (the status word may already be visible to the host)
+    stream = torch.cuda.current_stream(DEV).cuda_stream
+    assert _lib.lib().art_async_status(stream, 0) == -5           # ART_ECANDIDATES, still set
+    with pytest.raises(ArtistHipError, match="blocking rectangles"):
+        trace_rays(**inp, blocking=blk)                           # refused while the status is set
+    with pytest.raises(ArtistHipError, match="blocking rectangles"):
+        ops.check_async_errors(DEV)                               # reports and clears
+    assert _lib.lib().art_async_status(stream, 0) == 0
+    again, _, _ = trace_rays(**inp, blocking=blk)
+    np.testing.assert_array_equal(n(again), n(good))
+
+
 # ---------------------------------------------------------------------------------------------
 # Flux epilogue (artist/flux/bitmap.py:121-246, artist/optim/loss.py:251-410)
 # ---------------------------------------------------------------------------------------------
