@@ -9,6 +9,7 @@ timeout -k 10 300 python bench.py --heliostats 125 --steps 30 --warmup 5 --no-cp
 ARTIST_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final_bench_2rank_gloo.log 2> gpurun_out/final_bench_2rank_gloo.err || echo "2-rank rehearsal failed"
 timeout -k 10 300 python tools/blocking_bench.py 2>/dev/null | tail -1 > gpurun_out/final_blocking_bench.json
 timeout -k 10 300 python tools/flux_bench.py 2>/dev/null | tail -1 > gpurun_out/final_flux_bench.json
+timeout -k 10 300 python tools/cylinder_bench.py 2>/dev/null | tail -1 > gpurun_out/final_cylinder_bench.json
 if ls tools/bin/libabl_base.so > /dev/null 2>&1; then
   timeout -k 10 300 python tools/ab_libs.py --rounds 4 --reps 3 shipped=tools/bin/libabl_base.so no_lds_atomics=tools/bin/libabl_noatomics.so no_strays=tools/bin/libabl_nostrays.so no_loads=tools/bin/libabl_noloads.so no_flush=tools/bin/libabl_noflush.so alu_only=tools/bin/libabl_aluonly.so 2>&1 | tail -6 > gpurun_out/final_ablation.txt || true
 fi

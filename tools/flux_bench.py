@@ -7,7 +7,7 @@ import torch
 from artist_amd import _lib
 
 dev = torch.device("cuda:0")
-B, Hh, W = 1000, 256, 256
+B, Hh, W = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 256, 256
 nbytes = B * Hh * W * 4
 
 
@@ -42,6 +42,12 @@ cases = {
     "kl_loss_fwd": (lambda: lib.art_flux_loss(p(out), p(truth), B, Hh * W, 1, p(loss), None, None, s), 2 * nbytes),
     "kl_loss_bwd": (lambda: lib.art_flux_loss(p(out), p(truth), B, Hh * W, 1, None, p(gl), p(gp), s), 3 * nbytes),
 }
+c4 = torch.empty(B, 4, device=dev)
+ws2 = torch.empty(B * Hh * W + 5 * B, device=dev)
+cases["crop_pixel_loss_fwd"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4), s),
+                                2 * nbytes)
+cases["crop_pixel_loss_bwd"] = (lambda: lib.art_flux_crop_pixel_loss_bwd(p(flux), p(dims), p(truth), p(c4), p(gl), B, Hh, W, 6.0, 6.0,
+                                                                         p(gflux), p(ws2), s), 3 * nbytes)
 res = {}
 for name, (fn, alg) in cases.items():
     ms = timed(fn)
