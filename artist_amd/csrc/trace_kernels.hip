@@ -2379,9 +2379,13 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const bool lean = !blocking && lean_ok;
         // Blocking on: the heliostats with an empty candidate list (with the reference's tree, almost all of them) go through
         // the lean kernel in a launch of their own; the blocking instantiation below skips them.
-        if (blocking && lean_ok && T > 0 && Tc == 0 && env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
+        // A tower with planar AND cylindrical receivers (no blocking) is a split call of the same kind: the lean launch, with
+        // its own geometry, for the heliostats that aim at a plane (the others skip themselves), the cylinder launch below.
+        const bool mixed_split = !blocking && lean_ok && T > 0 && Tc > 0;
+        bool planar_done = false;
+        if ((mixed_split || (blocking && lean_ok && T > 0 && Tc == 0)) && env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
             TraceArgs al = a;
-            al.split = 1;
+            al.split = mixed_split ? 0 : 1;
             FwdConfig cl = fwd_config();
             cl.facet_points = (int)facet_points;
             cl.block = kLeanFwdThreads;
@@ -2414,7 +2418,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                 }
                 return ART_OK;
             };
-            a.split = 2;
+            if (mixed_split) planar_done = true; else a.split = 2;
         }
         if (lean && T > 0 && Tc == 0) {
             // (the facet hint serves the lean kernels only: with blocking on, facet-sized items measured SLOWER - 37.8 vs
@@ -2462,7 +2466,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             else ART_LAUNCH_FWD(false, CY, false, false);                                                        \
         } while (0)
         const bool il = interleaved_layout(a);
-        if (T > 0) {
+        if (T > 0 && !planar_done) {
             if (lean && il) ART_LAUNCH_FWD(true, false, false, true);
             else if (lean) ART_LAUNCH_FWD(false, false, false, true);
             else ART_LAUNCH_FWD_TYPE(false);
@@ -2586,10 +2590,13 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         // Blocking on: the heliostats with an empty candidate list take the lean kernel in a launch of their own (see
         // art_trace_fwd) - for fields large enough that neither launch cuts a point's samples into chunks (the two would
         // need slabs of their own).
-        if (blocking && !atomic_out && T > 0 && Tc == 0 && env_int("ARTIST_HIP_LEAN", 1) != 0 &&
+        // (a tower with planar and cylindrical receivers, no blocking, is split the same way: see art_trace_fwd)
+        const bool mixed_split = !blocking && T > 0 && Tc > 0;
+        bool planar_done = false;
+        if ((mixed_split || (blocking && Tc == 0)) && !atomic_out && T > 0 && env_int("ARTIST_HIP_LEAN", 1) != 0 &&
             env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
             TraceArgs al = a;
-            al.split = 1;
+            al.split = mixed_split ? 0 : 1;
             FwdConfig cl = fwd_config();
             cl.block = kLeanBwdThreads;
             cl.exact_pblock = true;
@@ -2631,7 +2638,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                     }
                     return ART_OK;
                 };
-                a.split = 2;
+                if (mixed_split) planar_done = true; else a.split = 2;
             }
         }
         const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
@@ -2667,7 +2674,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         } while (0)
         if (T > 0 && Tc == 0 && lean) ART_LAUNCH_BWD_BL(false, false, true);
         else
-        if (T > 0) ART_LAUNCH_BWD_TYPE(false);
+        if (T > 0 && !planar_done) ART_LAUNCH_BWD_TYPE(false);
         if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
 #ifdef ART_DEBUG_TIMELINE
         if (const char* out = getenv("ART_TIMELINE_OUT_BWD")) {
