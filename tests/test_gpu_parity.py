@@ -665,6 +665,25 @@ def test_trace_backward_cylinders(golden, name):
         assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)
 
 
+def test_published_reflection_directions(golden):
+    """``heliostat_group.preferred_reflection_directions`` (heliostat_ray_tracer.py:285-290) comes from ``art_reflect``: the
+    oracle's ``reflect`` (= the reference's known answers, tests/test_oracle_golden.py) bit for bit, and the torch
+    formula of the mirror's fallback to rounding."""
+    from artist_amd import ops
+    from artist_amd.raytracing import reflect
+    d = golden("small_deg3")
+    nrm, inc = t(d["aligned_normals"]), t(d["incident"])
+    got = ops.reflect_directions(inc, nrm)
+    want = oracle.reflect(d["incident"], d["aligned_normals"])
+    np.testing.assert_array_equal(n(got), want)
+    with torch.no_grad():
+        via_mirror = reflect(inc.unsqueeze(1), nrm)
+    np.testing.assert_array_equal(n(via_mirror), n(got))
+    with torch.enable_grad():
+        formula = reflect(inc.unsqueeze(1), nrm.clone().requires_grad_(True))      # differentiable callers keep torch's ops
+    np.testing.assert_allclose(n(formula), n(got), rtol=0, atol=2e-7)
+
+
 def test_mixed_tower_traces_its_planar_heliostats_like_a_planar_tower(golden, monkeypatch):
     """A tower with planar AND cylindrical receivers is a split call: the lean launch (own geometry) for the heliostats
     that aim at a plane, the cylinder launch for the others.  The planar heliostats' bitmaps, factors and gradients are
