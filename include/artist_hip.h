@@ -160,7 +160,9 @@ int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t fa
  *   Cmax <= 32         capacity of a heliostat's candidate list;
  *   flags [N]          out: 1 = in the filtered set;
  *   cand [H,Cmax], cand_count [H]   out: filtered rectangles inside heliostat h's ray cone; cand_count[h] > Cmax
- *                      reports an overflow (the list is then truncated: raise Cmax);
+ *                      reports an overflow (the list is then truncated: raise Cmax) - and so does the device status
+ *                      word: ART_ECANDIDATES from art_async_status and from the next art_trace_fwd / art_trace_bwd,
+ *                      so a caller need not read the counts back;
  *   workspace          art_blocking_workspace_bytes(H, N) bytes of device memory, 256-byte aligned.
  * ------------------------------------------------------------------------------------------- */
 int64_t art_blocking_workspace_bytes(int64_t H, int64_t N);
