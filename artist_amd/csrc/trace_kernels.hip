@@ -471,6 +471,36 @@ __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int ite
     return w;
 }
 
+// The k-th heliostat (k = 0, 1, ...) with a non-empty candidate list, or -1.  Workgroup-wide (ballots + a scan of the wave
+// totals in LDS); s_scan holds 18 ints.  The blocking launch of a split call has one workgroup per item: mapping the
+// workgroups to the BLOCKED heliostats in order puts the (with the reference's tree: few dozen) workgroups that have work
+// at the head of the grid, where they start beside the lean launch instead of behind it - the others exit here.
+__device__ __forceinline__ int kth_blocked_heliostat(const TraceArgs& a, int k, int* s_scan)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    if (tid == 0) s_scan[17] = -1;
+    __syncthreads();
+    int running = 0;
+    for (int base = 0; base < a.H; base += blockDim.x) {
+        const int h = base + tid;
+        const bool flag = h < a.H && a.cand_count[h] > 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+        if (lane == 0) s_scan[wave] = __popcll(m);
+        __syncthreads();
+        int before = running, total = 0;
+        for (int w = 0; w < nwaves; ++w) {
+            const int c = s_scan[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        if (flag && before + __popcll(m & ((1ull << lane) - 1ull)) == k) s_scan[17] = h;
+        running += total;
+        __syncthreads();
+        if (running > k) break;                      // workgroup-uniform
+    }
+    return s_scan[17];
+}
+
 template <bool INTERLEAVED, bool CYL, bool BLOCKING>
 __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
                                                const int bid, const WorkItem item, unsigned int* __restrict__ work_counter,
@@ -1162,9 +1192,19 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 10
     constexpr bool single_item = CYL || (BLOCKING && !kBlockingPersistentFwd);
 #endif
     if constexpr (single_item) {
-        if ((int)blockIdx.x < work_item_count(launch.a))
-            trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(launch.a, launch.flux, launch.counts, (int)blockIdx.x,
-                                                       decode_work_item(launch.a, (int)blockIdx.x), launch.work_counter, &s_next);
+        int item = (int)blockIdx.x;
+        if (item >= work_item_count(launch.a)) return;
+        if constexpr (BLOCKING) {
+            if (launch.a.split == 2) {               // the blocked heliostats first (see kth_blocked_heliostat)
+                __shared__ int s_scan[18];
+                const int per = launch.a.n_pblocks * launch.a.n_rchunks;
+                const int hk = kth_blocked_heliostat(launch.a, item / per, s_scan);
+                if (hk < 0) return;                  // workgroup-uniform: fewer blocked heliostats than that
+                item = hk * per + item % per;
+            }
+        }
+        trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(launch.a, launch.flux, launch.counts, item, decode_work_item(launch.a, item),
+                                                   launch.work_counter, &s_next);
         return;
     }
     if (threadIdx.x == 0) {
