@@ -1411,6 +1411,56 @@ def test_random_scenes_all_features(seed, H, P, R, res, interleaved, lbvh_compat
         assert rel_l2(n(prims["corners"].grad), gpc) < 2e-5, rel_l2(n(prims["corners"].grad), gpc)
 
 
+@pytest.mark.parametrize("variant", ["blocking_on_planes", "mixed_tower_no_blocking"])
+@pytest.mark.parametrize("seed,H,P,R", [(5, 6, 300, 11), (6, 9, 128, 40), (7, 4, 1500, 6), (8, 12, 77, 17), (9, 5, 640, 24)])
+def test_random_scenes_split_calls(seed, H, P, R, variant, monkeypatch):
+    """The two kinds of split call on random scenes, against the oracle: blocking on with planar receivers only (lean
+    launch for the heliostats without candidate rectangles beside the blocking launch, whose workgroups are mapped to the
+    blocked heliostats in order) and a tower with planar and cylindrical receivers without blocking (lean launch for the
+    planes beside the cylinder launch).  ``ARTIST_HIP_FWD_BLOCKS=1`` keeps the samples in one chunk, so that the backward
+    call splits as well (a field this small would otherwise be chunked, and chunked launches are not split)."""
+    from artist_amd import trace_rays
+    monkeypatch.setenv("ARTIST_HIP_FWD_BLOCKS", "1")
+    sc = _random_feature_scene(seed, H, P, R)
+    dv = lambda x: x.to(DEV)
+    f32 = lambda x: np.ascontiguousarray(x.detach().cpu().numpy())
+    tix = sc["target_idx"].clone()
+    kw, okw = {}, {}
+    if variant == "blocking_on_planes":
+        tix = tix % 2                                                     # the two planes only
+        prims = {k: dv(v) for k, v in sc["prims"].items()}
+        kw["blocking"] = dict(prims, lbvh_compat=False)
+        okw["blocking"] = dict({k: f32(v) for k, v in sc["prims"].items()}, lbvh_compat=False)
+    else:
+        kw["cyl"] = tuple(dv(sc["cyl"][k]) for k in ("centers", "normals", "axes", "radii", "heights", "opening"))
+        okw["cyl"] = {k: f32(v) for k, v in sc["cyl"].items()}
+    o, nn_ = dv(sc["origins"]).requires_grad_(True), dv(sc["normals"]).requires_grad_(True)
+    both = dv(sc["both"])
+    args = (o, nn_, dv(sc["incident"]), both[..., 0], both[..., 1], dv(tix), dv(sc["planes"]["centers"]),
+            dv(sc["planes"]["normals"]), dv(sc["planes"]["dims"]))
+    res = (96, 64)
+    out = trace_rays(*args, ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=res, **kw)
+    flux, fac = out[0], out[1]
+    oracle_args = (f32(sc["origins"]), f32(sc["normals"]), f32(sc["incident"]), f32(sc["both"][..., 0]), f32(sc["both"][..., 1]),
+                   f32(tix), f32(sc["planes"]["centers"]), f32(sc["planes"]["normals"]), f32(sc["planes"]["dims"]), res)
+    o_flux, o_fac = oracle.trace_fwd(*oracle_args, 0.7, 0.05, 0.9, **okw)[:2]
+    assert o_flux.sum() > 0
+    planar = n(tix) < 2
+    assert rel_l2(n(flux)[planar], o_flux[planar]) < 1e-5, rel_l2(n(flux)[planar], o_flux[planar])
+    if (~planar).any():                                                   # (cylinders: the fp32 quadratic is ill-conditioned)
+        assert rel_l2(n(flux)[~planar], o_flux[~planar]) < 2e-3
+    np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=3.0 / (R * P) if variant == "blocking_on_planes" else 1e-3)
+    np.testing.assert_array_equal(n(fac[:2])[:, planar], o_fac[:2][:, planar])       # ray counters of the planes: exact
+    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(seed)).to(DEV)
+    (flux * w).sum().backward()
+    grads = oracle.trace_bwd(*oracle_args, f32(w), 0.7, 0.05, 0.9, **okw)
+    go, gn = grads[0], grads[1]
+    tol = 2e-5 if variant == "blocking_on_planes" else 2e-3
+    assert rel_l2(n(o.grad)[planar], go[planar]) < 2e-5, rel_l2(n(o.grad)[planar], go[planar])
+    assert rel_l2(n(nn_.grad)[planar], gn[planar]) < 2e-5, rel_l2(n(nn_.grad)[planar], gn[planar])
+    assert rel_l2(n(o.grad), go) < tol and rel_l2(n(nn_.grad), gn) < tol
+
+
 @pytest.mark.parametrize("res", [(700, 40), (40, 700), (2, 2), (3, 1500)])
 def test_extreme_bitmap_shapes(golden, res):
     """Very wide / very tall / minimal bitmaps: windows wider than half the LDS capacity, multi-pass row bands, and
