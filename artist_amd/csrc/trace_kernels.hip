@@ -424,7 +424,7 @@ struct WorkItem { int h, pblock, rchunk, r0, r1; };
 // a.split = 1 (lean: the unblocked heliostats) and 2 (blocking instantiation: the others).  Workgroup-uniform.
 __device__ __forceinline__ bool other_launch_owns(const TraceArgs& a, int h)
 {
-    if (a.split == 0) return false;
+    if (a.split == 0 || a.split == 3) return false;     // (3: the cylinder launch of a mixed tower - the receiver type decides)
     const bool blocked = a.cand_count[h] > 0;
     return a.split == 1 ? blocked : !blocked;
 }
@@ -475,6 +475,9 @@ __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int ite
 // totals in LDS); s_scan holds 18 ints.  The blocking launch of a split call has one workgroup per item: mapping the
 // workgroups to the BLOCKED heliostats in order puts the (with the reference's tree: few dozen) workgroups that have work
 // at the head of the grid, where they start beside the lean launch instead of behind it - the others exit here.
+// (CYLINDERS = true: the k-th heliostat that aims at a cylinder instead - the cylinder launch of a tower with both receiver
+//  types, a.split == 3, has the same problem beside the lean launch of the planes.)
+template <bool CYLINDERS = false>
 __device__ __forceinline__ int kth_blocked_heliostat(const TraceArgs& a, int k, int* s_scan)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -483,7 +486,7 @@ __device__ __forceinline__ int kth_blocked_heliostat(const TraceArgs& a, int k, 
     int running = 0;
     for (int base = 0; base < a.H; base += blockDim.x) {
         const int h = base + tid;
-        const bool flag = h < a.H && a.cand_count[h] > 0;
+        const bool flag = h < a.H && (CYLINDERS ? a.target_idx[h] >= a.T : a.cand_count[h] > 0);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
         if (lane == 0) s_scan[wave] = __popcll(m);
         __syncthreads();
@@ -1200,6 +1203,15 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 10
                 const int per = launch.a.n_pblocks * launch.a.n_rchunks;
                 const int hk = kth_blocked_heliostat(launch.a, item / per, s_scan);
                 if (hk < 0) return;                  // workgroup-uniform: fewer blocked heliostats than that
+                item = hk * per + item % per;
+            }
+        }
+        if constexpr (CYL && !BLOCKING) {
+            if (launch.a.split == 3) {               // the heliostats that aim at a cylinder first
+                __shared__ int s_scan[18];
+                const int per = launch.a.n_pblocks * launch.a.n_rchunks;
+                const int hk = kth_blocked_heliostat<true>(launch.a, item / per, s_scan);
+                if (hk < 0) return;
                 item = hk * per + item % per;
             }
         }
@@ -2025,9 +2037,18 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
     const int n_items = work_item_count(a);
     int item = blockIdx.x;
     if constexpr ((CYL && !kCylPersistentBwd) || (!CYL && BLOCKING && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
-        if (item < n_items)
-            trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
-                                                                   g_pnormals, decode_work_item(a, item), work_counter, &s_next);
+        if (item >= n_items) return;
+        if constexpr (CYL && !BLOCKING) {
+            if (a.split == 3) {                      // the heliostats that aim at a cylinder first (see art_trace_fwd)
+                __shared__ int s_scan[18];
+                const int per = a.n_pblocks * a.n_rchunks;
+                const int hk = kth_blocked_heliostat<true>(a, item / per, s_scan);
+                if (hk < 0) return;
+                item = hk * per + item % per;
+            }
+        }
+        trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
+                                                               g_pnormals, decode_work_item(a, item), work_counter, &s_next);
         return;
     }
     const bool reverse = a.reverse_bwd != 0;
@@ -2511,6 +2532,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             else if (lean) ART_LAUNCH_FWD(false, false, false, true);
             else ART_LAUNCH_FWD_TYPE(false);
         }
+        if (planar_done) a.split = 3;                // the cylinder launch of a mixed tower: cylinder heliostats first
         if (Tc > 0) ART_LAUNCH_FWD_TYPE(true);
 #undef ART_LAUNCH_FWD_TYPE
 #undef ART_LAUNCH_FWD
@@ -2715,6 +2737,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         if (T > 0 && Tc == 0 && lean) ART_LAUNCH_BWD_BL(false, false, true);
         else
         if (T > 0 && !planar_done) ART_LAUNCH_BWD_TYPE(false);
+        if (planar_done) a.split = 3;
         if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
 #ifdef ART_DEBUG_TIMELINE
         if (const char* out = getenv("ART_TIMELINE_OUT_BWD")) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cost of a cylindrical receiver at the metric size: 1000 heliostats x 100 rays x 10000 points, every heliostat aimed at
 the mantle of one cylinder (radius 6 m, height 12 m, opening 2 rad) - forward and forward + backward, against the same
-field aimed at the planar receiver."""
+field aimed at the planar receiver, and with every tenth heliostat on the cylinder."""
 import json, sys, pathlib, time
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import torch
@@ -35,8 +35,10 @@ def main(H=1000, R=100, steps=5):
     mask = torch.ones(H, dtype=torch.int32, device=dev)
     inc = torch.nn.functional.normalize(torch.tensor([[0.0, 0.94, -0.34, 0.0]], device=dev), dim=1).repeat(H, 1)
     out = {"H": H, "R": R}
-    for label, t in (("planar", 0), ("cylinder", 1)):
-        tix = torch.full((H,), t, dtype=torch.long, device=dev)
+    for label, t in (("planar", 0), ("cylinder", 1), ("every_tenth_on_the_cylinder", -1)):
+        tix = torch.full((H,), max(t, 0), dtype=torch.long, device=dev)
+        if t < 0:
+            tix[::10] = 1
         g.activate_heliostats(mask)              # (alignment starts from the unaligned surfaces)
         g.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask)
         pts = g.active_surface_points.detach().requires_grad_(True)
