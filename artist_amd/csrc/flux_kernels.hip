@@ -626,6 +626,198 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_bwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// get_center_of_mass (artist/flux/bitmap.py:12-71): PIXEL coordinates (e, u) of each bitmap's centre of mass,
+// sum_j j f / (sum f + 1e-8) - what FocalSpotLoss (artist/optim/loss.py:124-250) and the kinematics reconstructor's
+// validation (kinematics_reconstructor.py:120) ask of the tracer's bitmaps.  com[b] = (e px, u px, sum + 1e-8).
+// One streaming pass, fp64 sums; backward = one elementwise pass: d e_com / d f_ij = (j - e_com) / (S + 1e-8).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kReduceBlock) void flux_com_px_kernel(const float* __restrict__ flux, int Hh, int W,
+                                                                 float* __restrict__ com)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.x;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    double s = 0.0, xs = 0.0, ys = 0.0;
+    int x = threadIdx.x % W, y = threadIdx.x / W;
+    const int dx = blockDim.x % W, dy = blockDim.x / W;
+    for (int k = threadIdx.x; k < Hh * W; k += blockDim.x) {
+        const float v = f[k];
+        s += (double)v;
+        xs += (double)((float)x * v);
+        ys += (double)((float)y * v);
+        x += dx; y += dy;
+        if (x >= W) { x -= W; ++y; }
+    }
+    s = block_sum(s, s_red);
+    xs = block_sum(xs, s_red);
+    ys = block_sum(ys, s_red);
+    if (threadIdx.x == 0) {
+        const float S = (float)s + 1e-8f;
+        com[3 * b] = (float)(xs / (double)S); com[3 * b + 1] = (float)(ys / (double)S); com[3 * b + 2] = S;
+    }
+}
+
+__global__ __launch_bounds__(kFluxBlock) void flux_com_px_bwd_kernel(const float* __restrict__ com, const float* __restrict__ grad_com,
+                                                                     int Hh, int W, float* __restrict__ grad_flux)
+{
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Hh * W) return;
+    const int i = k / W, j = k - i * W;
+    const float S = com[3 * b + 2];
+    grad_flux[(int64_t)b * Hh * W + k] = (grad_com[2 * b] * ((float)j - com[3 * b]) + grad_com[2 * b + 1] * ((float)i - com[3 * b + 1])) / S;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused crop around the centre of mass + KLDivergenceLoss (artist/flux/bitmap.py:121-246 followed by
+// artist/optim/loss.py:321-410 with the reduction over the two bitmap dimensions), one workgroup per bitmap, the same
+// arithmetic as flux_com_kernel / flux_crop_fwd_kernel / flux_loss_kernel(mode 1): the cropped bitmap never reaches
+// HBM.  The KL terms need the crop's L1 norm first, so the crop is sampled twice (the taps hit L2: the workgroup has
+// just streamed the bitmap).  rec8[b] = (x centre, y centre, sum + 1e-8, |crop|_1, |truth|_1, dot, 0, 0) for the
+// backward pass, where dot = sum_k a_k crop_k with a_k = -exp(t_k) / (crop_k / dp + eps).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_com(const float* __restrict__ f, int Hh, int W, double* s_red, float* s_com)
+{
+    double s = 0.0, xs = 0.0, ys = 0.0;
+    if ((W & 3) == 0) {                                 // flux_com_kernel's loop
+        const int W4 = W >> 2;
+        int x4 = threadIdx.x % W4, y = threadIdx.x / W4;
+        const int dx = blockDim.x % W4, dy = blockDim.x / W4;
+        const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f);
+#pragma unroll 4
+        for (int k = threadIdx.x; k < Hh * W4; k += blockDim.x) {
+            const float4 v = f4[k];
+            const int x = 4 * x4;
+            s += (double)((v.x + v.y) + (v.z + v.w));
+            xs += (double)((lin11(x, W) * v.x + lin11(x + 1, W) * v.y) + (lin11(x + 2, W) * v.z + lin11(x + 3, W) * v.w));
+            ys += (double)(lin11(y, Hh) * ((v.x + v.y) + (v.z + v.w)));
+            x4 += dx; y += dy;
+            if (x4 >= W4) { x4 -= W4; ++y; }
+        }
+    } else {
+        int x = threadIdx.x % W, y = threadIdx.x / W;
+        const int dx = blockDim.x % W, dy = blockDim.x / W;
+        for (int k = threadIdx.x; k < Hh * W; k += blockDim.x) {
+            const float v = f[k];
+            s += (double)v; xs += (double)(lin11(x, W) * v); ys += (double)(lin11(y, Hh) * v);
+            x += dx; y += dy;
+            if (x >= W) { x -= W; ++y; }
+        }
+    }
+    s = block_sum(s, s_red); xs = block_sum(xs, s_red); ys = block_sum(ys, s_red);
+    if (threadIdx.x == 0) {
+        const float S = (float)s + 1e-8f;
+        s_com[0] = (float)(xs / (double)S); s_com[1] = (float)(ys / (double)S); s_com[2] = S;
+    }
+    __syncthreads();
+}
+
+// f(k, crop_k, v00, v01, v10, v11, tx, ty) for every output pixel k of the crop of bitmap `f`, each thread in its own
+// fixed order (a thread owns one column when the workgroup size is a multiple of the bitmap width)
+template <typename F>
+__device__ __forceinline__ void for_each_crop_pixel(const float* __restrict__ f, const CropMap& m, F&& fn)
+{
+    const int W = m.W, Hh = m.Hh;
+    if ((int)blockDim.x % W == 0) {
+        const int j = threadIdx.x % W, di = blockDim.x / W;
+        const CropColumn col = crop_column(m, j);
+#pragma unroll 4
+        for (int i = threadIdx.x / W; i < Hh; i += di) {
+            float v00, v01, v10, v11, ty;
+            const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
+            fn(i * W + j, c, v00, v01, v10, v11, col.tx, ty);
+        }
+    } else {
+        for (int k = threadIdx.x; k < Hh * W; k += blockDim.x) {
+            const int i = k / W, j = k - i * W;
+            float v00, v01, v10, v11, tx, ty;
+            const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
+            fn(k, c, v00, v01, v10, v11, tx, ty);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_kl_loss_fwd_kernel(const float* __restrict__ flux,
+                                                                            const float* __restrict__ dims,
+                                                                            const float* __restrict__ truth, int Hh, int W,
+                                                                            float crop_w, float crop_h, float* __restrict__ loss,
+                                                                            float* __restrict__ rec8)
+{
+    __shared__ double s_red[16];
+    __shared__ float s_com[3];
+    const int b = blockIdx.x;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
+    block_com(f, Hh, W, s_red, s_com);
+    CropMap m;
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.xc = s_com[0]; m.yc = s_com[1]; m.W = W; m.Hh = Hh;
+    const float eps = 1e-12f;                                  // loss.py:385-410, as flux_loss_kernel mode 1
+    double np_ = 0.0, ng = 0.0;
+    for_each_crop_pixel(f, m, [&](int k, float c, float, float, float, float, float, float) {
+        np_ += (double)fabsf(c); ng += (double)fabsf(g[k]);
+    });
+    const float npf = (float)block_sum(np_, s_red), ngf = (float)block_sum(ng, s_red);
+    const float dp = fmaxf(npf, eps), dg = fmaxf(ngf, eps);
+    double acc = 0.0, dot = 0.0;
+    for_each_crop_pixel(f, m, [&](int k, float c, float, float, float, float, float, float) {
+        const float t = logf(g[k] / dg + eps), q = logf(c / dp + eps);
+        const float et = expf(t);
+        acc += (double)(et * (t - q));
+        dot += (double)((-et / (c / dp + eps)) * c);
+    });
+    acc = block_sum(acc, s_red);
+    const float dotf = (float)block_sum(dot, s_red);
+    if (threadIdx.x == 0) {
+        loss[b] = (float)acc;
+        float* r = rec8 + 8 * b;
+        r[0] = s_com[0]; r[1] = s_com[1]; r[2] = s_com[2]; r[3] = npf; r[4] = ngf; r[5] = dotf; r[6] = 0.0f; r[7] = 0.0f;
+    }
+}
+
+// grad_crop[b] = gl[b] dKL/dcrop (written), gcom[b] = its gradient w.r.t. the two centre coordinates, com3 for the tiled gather
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_kl_loss_bwd_kernel(const float* __restrict__ flux,
+                                                                            const float* __restrict__ dims,
+                                                                            const float* __restrict__ truth,
+                                                                            const float* __restrict__ rec8,
+                                                                            const float* __restrict__ grad_loss, int Hh, int W,
+                                                                            float crop_w, float crop_h,
+                                                                            float* __restrict__ grad_crop, float* __restrict__ com3,
+                                                                            float* __restrict__ gcom)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.x;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
+    float* __restrict__ gc = grad_crop + (int64_t)b * Hh * W;
+    const float* r = rec8 + 8 * b;
+    CropMap m;
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.xc = r[0]; m.yc = r[1]; m.W = W; m.Hh = Hh;
+    const float eps = 1e-12f;
+    const float npf = r[3], ngf = r[4], dotf = r[5], gl = grad_loss[b];
+    const float dp = fmaxf(npf, eps), dg = fmaxf(ngf, eps);
+    double gx = 0.0, gy = 0.0;
+    for_each_crop_pixel(f, m, [&](int k, float c, float v00, float v01, float v10, float v11, float tx, float ty) {
+        const float t = logf(g[k] / dg + eps);                    // flux_loss_kernel's gradient (mode 1)
+        const float a = -expf(t) / (c / dp + eps);
+        const float sgn = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
+        const float through_norm = npf > eps ? sgn * dotf / (dp * dp) : 0.0f;
+        const float go = gl * (a / dp - through_norm);
+        gc[k] = go;
+        gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));     // flux_crop_bwd_com_kernel
+        gy += (double)(go * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
+    });
+    gx = block_sum(gx, s_red);
+    gy = block_sum(gy, s_red);
+    if (threadIdx.x == 0) {
+        gcom[2 * b] = (float)(gx * (double)((float)(W - 1) / 2.0f));
+        gcom[2 * b + 1] = (float)(gy * (double)((float)(Hh - 1) / 2.0f));
+        com3[3 * b] = m.xc; com3[3 * b + 1] = m.yc; com3[3 * b + 2] = r[2];
+    }
+}
+
 }  // namespace art
 
 using namespace art;
@@ -707,6 +899,63 @@ extern "C" int art_flux_crop_pixel_loss_bwd(const float* flux, const float* targ
     float* gcom = com3 + 3 * B;                        // [B,2]
     hipLaunchKernelGGL(flux_crop_pixel_loss_bwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
                        ground_truth, centers4, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height, grad_crop, com3,
+                       gcom);
+    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel,
+                       dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),
+                       dim3(256), 0, stream, target_dims, com3, gcom, grad_crop, (int)Hh, (int)W, (float)crop_width,
+                       (float)crop_height, grad_flux);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_center_of_mass(const float* flux, int64_t B, int64_t Hh, int64_t W, float* com, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(flux, com, flux, com, B, Hh, W)) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    hipLaunchKernelGGL(flux_com_px_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, (int)Hh, (int)W, com);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_center_of_mass_bwd(const float* com, const float* grad_com, int64_t B, int64_t Hh, int64_t W,
+                                           float* grad_flux, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(com, grad_com, grad_flux, com, B, Hh, W)) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    hipLaunchKernelGGL(flux_com_px_bwd_kernel, dim3((unsigned)((Hh * W + kFluxBlock - 1) / kFluxBlock), (unsigned)B), dim3(kFluxBlock),
+                       0, stream, com, grad_com, (int)Hh, (int)W, grad_flux);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_crop_kl_loss_fwd(const float* flux, const float* target_dims, const float* ground_truth, int64_t B,
+                                         int64_t Hh, int64_t W, double crop_width, double crop_height, float* loss,
+                                         float* record8, void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(flux, target_dims, ground_truth, loss, B, Hh, W) || !record8) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    hipLaunchKernelGGL(flux_crop_kl_loss_fwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
+                       ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, loss, record8);
+    ART_HIP(hipGetLastError());
+    return ART_OK;
+}
+
+extern "C" int art_flux_crop_kl_loss_bwd(const float* flux, const float* target_dims, const float* ground_truth,
+                                         const float* record8, const float* grad_loss, int64_t B, int64_t Hh, int64_t W,
+                                         double crop_width, double crop_height, float* grad_flux, float* workspace,
+                                         void* stream_)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!crop_args_ok(flux, target_dims, ground_truth, record8, B, Hh, W) || !grad_loss || !grad_flux || !workspace) return ART_EINVAL;
+    if (B == 0) return ART_OK;
+    float* grad_crop = workspace;                      // [B,Hh,W]
+    float* com3 = workspace + B * Hh * W;              // [B,3]
+    float* gcom = com3 + 3 * B;                        // [B,2]
+    hipLaunchKernelGGL(flux_crop_kl_loss_bwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
+                       ground_truth, record8, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height, grad_crop, com3,
                        gcom);
     hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel,
                        dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),

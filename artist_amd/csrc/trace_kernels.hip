@@ -504,6 +504,19 @@ __device__ __forceinline__ int kth_blocked_heliostat(const TraceArgs& a, int k, 
     return s_scan[17];
 }
 
+// One fetch from a launch's work counter.  A launch of n_items items makes EXACTLY n_items fetches - one per item it
+// processes or skips - which return 0 .. n_items - 1, each once: whoever gets n_items - 1 has made the launch's last access to
+// the counter and puts it back to zero.  The counter (one per stream and role, stream_work_counters) is therefore zero
+// whenever a launch starts, with no memset per launch and no ring of slots that a long queue of launches could wrap around.
+// work_counter == nullptr: a launch with one workgroup per item (nothing to fetch).
+__device__ __forceinline__ unsigned fetch_work_item(unsigned int* __restrict__ work_counter, const TraceArgs& a)
+{
+    if (work_counter == nullptr) return 0u;
+    const unsigned v = atomicAdd(work_counter, 1u);
+    if (v + 1u == (unsigned)(a.H * a.n_pblocks * a.n_rchunks)) __hip_atomic_store(work_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+
 template <bool INTERLEAVED, bool CYL, bool BLOCKING>
 __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
                                                const int bid, const WorkItem item, unsigned int* __restrict__ work_counter,
@@ -521,7 +534,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
 
     const int t = a.target_idx[h];
     if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // workgroup-uniform: a bad index, or another launch owns this heliostat
-        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+        if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
     Plane pl; Cyl cy;
@@ -763,7 +776,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     ART_TIMELINE(5);
     // the next work item is requested now and published after the flush: the counter's round trip hides behind it
     unsigned next_item = 0u;
-    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
+    if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
 
     // ---- phase 3: flush (one wave per window row; lanes along e -> contiguous global atomics) ----
     for (int row = wave; row < pth; row += nwaves) {
@@ -914,7 +927,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
 
     const int t = a.target_idx[h];
     if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // a bad index, another launch's heliostat (cylinder, blocked) or an empty item
-        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+        if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
@@ -1146,7 +1159,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     if (first && lane == 0) { atomicAdd(&s_cnt[0], n_valid); atomicAdd(&s_cnt[1], n_valid); }
     __syncthreads();
     unsigned next_item = 0u;
-    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
+    if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
 
     // ---- phase 3: flush ------------------------------------------------------------------------
     for (int row = wave; row < pth; row += nwaves) {
@@ -1216,7 +1229,7 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 10
             }
         }
         trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(launch.a, launch.flux, launch.counts, item, decode_work_item(launch.a, item),
-                                                   launch.work_counter, &s_next);
+                                                   nullptr, &s_next);
         return;
     }
     if (threadIdx.x == 0) {
@@ -1250,19 +1263,26 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 10
 // What a forward call zeroes before its kernels start - the three ray counters per heliostat (they alias `factors`) and the
 // work counters of its (at most two) launches - in ONE launch: three memsets were three 5 us kernels, a tenth of the
 // forward pass of a 16-heliostat field.
-__global__ void trace_fwd_prep_kernel(unsigned* __restrict__ counts, int n, unsigned* __restrict__ c0, unsigned* __restrict__ c1,
-                                      unsigned* __restrict__ c2)
+__global__ void trace_fwd_prep_kernel(unsigned* __restrict__ counts, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) counts[i] = 0u;
-    if (i == 0) { *c0 = 0u; *c1 = 0u; *c2 = 0u; }
 }
 
 // counts (uint32, rows 0,1 of factors) -> fractions (heliostat_ray_tracer.py:498-506).
-__global__ void finalize_factors_kernel(float* factors, int H, float rays_per_heliostat, int blocking, const int32_t* unblocked_if_empty)
+__global__ void finalize_factors_kernel(float* factors, int H, float rays_per_heliostat, int blocking, const int32_t* unblocked_if_empty,
+                                        const int32_t* cand_count, int Cmax)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= H) return;
+    // More candidate rectangles than the tables hold (art_blocking_filter kept the count): the heliostat was traced with an
+    // incomplete blocking mask.  Its factors are NaN (poison_overflow_kernel does the same to its bitmap), so the call that
+    // overflowed cannot be mistaken for a result even by a caller who never asks art_async_status.
+    if (cand_count != nullptr && cand_count[h] > Cmax) {
+        const float nan = __builtin_nanf("");
+        factors[h] = nan; factors[H + h] = nan; factors[2 * H + h] = nan;
+        return;
+    }
     const unsigned* c = reinterpret_cast<const unsigned*>(factors);
     const unsigned n_int = c[h], n_on = c[H + h], n_free = c[2 * H + h];
     factors[h] = (float)n_int / rays_per_heliostat;
@@ -1274,6 +1294,24 @@ __global__ void finalize_factors_kernel(float* factors, int H, float rays_per_he
     // (split launches: a heliostat with an empty candidate list went through the lean kernel, which does not count free rays)
     if (unblocked_if_empty != nullptr && unblocked_if_empty[h] == 0) blocking = 0;
     factors[2 * H + h] = (blocking ? (float)n_free : rays_per_heliostat) / rays_per_heliostat;
+}
+
+// The bitmap of a heliostat whose candidate list overflowed (see finalize_factors_kernel) becomes NaN: row h in mode 0, its
+// target's bitmap in mode 1.  One workgroup per heliostat; all but the overflowed ones exit at once.  Blocking calls only.
+__global__ __launch_bounds__(256) void poison_overflow_kernel(const int32_t* __restrict__ cand_count, int Cmax,
+                                                              const int32_t* __restrict__ target_idx, int n_targets,
+                                                              float* __restrict__ flux, int64_t npix, int mode)
+{
+    const int h = blockIdx.x;
+    if (cand_count[h] <= Cmax) return;
+    int64_t map = h;
+    if (mode == 1) {
+        const int t = target_idx[h];
+        if ((unsigned)t >= (unsigned)n_targets) return;
+        map = t;
+    }
+    const float nan = __builtin_nanf("");
+    for (int64_t i = threadIdx.x; i < npix; i += blockDim.x) flux[map * npix + i] = nan;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1413,6 +1451,22 @@ __device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsDo
     return out;
 }
 
+// A heliostat that is skipped because its target index is outside the tables (ART_ETARGET, target_in_range) gets ZERO
+// gradients for the item's points - `grad_origins` / `grad_normals` (or the item's chunk slab) are the caller's uninitialised
+// memory, and the status word may not have reached the host before the optimiser reads them.  (Both launches of a split call
+// may do this for the same heliostat: the same zeros.)
+__device__ __forceinline__ void zero_block_gradients(const TraceArgs& a, const WorkItem item, float4* __restrict__ grad_origins,
+                                                     float4* __restrict__ grad_normals)
+{
+    int p0, p1;
+    block_range(a, item.pblock, p0, p1);
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int p = p0 + (int)threadIdx.x; p < p1; p += (int)blockDim.x) {
+        grad_origins[(int64_t)item.h * a.P + p] = z;
+        grad_normals[(int64_t)item.h * a.P + p] = z;
+    }
+}
+
 // (The cylinder and blocking instantiations keep ~60 more live values per ray; they run 768-thread workgroups =
 // 168 VGPRs, see kCylBwdThreads.)
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
@@ -1440,8 +1494,10 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     }
 
     const int t = a.target_idx[h];
-    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // workgroup-uniform: a bad index, or another launch owns this heliostat
-        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+    const bool bad_target = !target_in_range(a, t);
+    if (bad_target || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // workgroup-uniform: a bad index, or another launch owns this heliostat
+        if (bad_target) zero_block_gradients(a, item, grad_origins, grad_normals);
+        if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
     Plane pl; Cyl cy;
@@ -1476,7 +1532,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const int pth = min(win.ths, win.u0 + win.th - pu0);
     const bool first = pass == 0;
     // the next work item is requested at the start of the last pass and published at its end
-    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
+    if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
     // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped
     // Four floats per lane (one 16-byte load, 4-byte aligned: a wave covers a 256-pixel row segment in one instruction)
     // and four rows per trip, all four loads in flight before the first LDS store.  One float and one row at a time
@@ -1725,7 +1781,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     if (tid == 0 && bid < kTimelineSlots) g_timeline[8 * bid + 7] = __builtin_amdgcn_s_memtime() - clk0;
 #endif
   }
-    if (win.npass < 1 && tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));   // (never: npass >= 1)
+    if (win.npass < 1 && tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));   // (never: npass >= 1)
     if constexpr (BLOCKING) {      // rectangle gradients of this workgroup -> the primitive tables
         for (int c = tid; c < n_prims * 12; c += blockDim.x) {
             const float v = (float)s_tab.grad[c];
@@ -1770,8 +1826,10 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         grad_normals += (int64_t)item.rchunk * a.H * a.P;
     }
     const int t = a.target_idx[h];
-    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {
-        if (tid == 0) *s_next = (int)(gridDim.x + atomicAdd(work_counter, 1u));
+    const bool bad_target = !target_in_range(a, t);
+    if (bad_target || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {
+        if (bad_target) zero_block_gradients(a, item, grad_origins, grad_normals);
+        if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
     const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
@@ -1813,7 +1871,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const int pu0 = win.u0 + pass * (win.ths - 1);
     const int pth = min(win.ths, win.u0 + win.th - pu0);
     const bool first = pass == 0;
-    if (tid == 0 && pass == win.npass - 1) next_item = atomicAdd(work_counter, 1u);
+    if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
     {   // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped: see trace_bwd_item
         struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;
@@ -2048,7 +2106,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
             }
         }
         trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
-                                                               g_pnormals, decode_work_item(a, item), work_counter, &s_next);
+                                                               g_pnormals, decode_work_item(a, item), nullptr, &s_next);
         return;
     }
     const bool reverse = a.reverse_bwd != 0;
@@ -2060,7 +2118,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
             trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
                                                                    g_pnormals, decode_work_item(a, item, reverse), work_counter, &s_next);
         __syncthreads();
-        item = s_next;
+        item = __builtin_amdgcn_readfirstlane(s_next);       // wave-uniform by construction: say so (the item's fields then live in SGPRs)
         __syncthreads();
     }
 }
@@ -2205,26 +2263,34 @@ static FwdConfig fwd_config()
 
 static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_target);
 
-// Work counters of the persistent kernels: 4 KB of device memory per GPU, allocated on the first trace call and kept
-// for the life of the process.  Each launch takes the next of 1024 slots and zeroes it on its stream.
-static unsigned* next_work_counter(hipStream_t stream, bool zero = true)
+// Work counters of the persistent kernels: eight 4-byte counters per (device, stream) - forward: planar, cylinder and lean
+// launch of a split call; backward: main, lean, (spare) - carved from 4 KB pages of device memory that the library allocates
+// on first use and keeps.  A counter is zero whenever no launch is using it: the launch's last fetch resets it
+// (fetch_work_item), and launches that share a counter are ordered by their stream.  So there is no per-launch memset, and no
+// bound on how many launches may be queued (round 2 took the next of 1024 slots per launch, unguarded).
+constexpr int kCountersPerStream = 8;
+static unsigned* stream_work_counters(hipStream_t stream)
 {
-    constexpr int kSlots = 1024, kMaxDevices = 64;
-    static unsigned* base[kMaxDevices] = {};
-    static std::atomic<unsigned> seq{0};
+    struct Entry { int dev; hipStream_t stream; unsigned* base; };
+    static std::vector<Entry> table;
+    static unsigned* page = nullptr;
+    static int page_dev = -1, page_used = 0;
     static std::mutex lock;
+    constexpr int kPageEntries = 4096 / (int)(sizeof(unsigned) * kCountersPerStream);
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
-    {
-        std::lock_guard<std::mutex> guard(lock);
-        if (base[dev] == nullptr && hipMalloc(reinterpret_cast<void**>(&base[dev]), sizeof(unsigned) * kSlots) != hipSuccess) {
-            base[dev] = nullptr;
-            return nullptr;
-        }
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> guard(lock);
+    for (const Entry& e : table)
+        if (e.dev == dev && e.stream == stream) return e.base;
+    if (page == nullptr || page_dev != dev || page_used == kPageEntries) {
+        unsigned* fresh = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&fresh), 4096) != hipSuccess) return nullptr;
+        if (hipMemset(fresh, 0, 4096) != hipSuccess) { (void)hipFree(fresh); return nullptr; }
+        page = fresh; page_dev = dev; page_used = 0;
     }
-    unsigned* slot = base[dev] + (seq.fetch_add(1) % kSlots);
-    if (zero && hipMemsetAsync(slot, 0, sizeof(unsigned), stream) != hipSuccess) return nullptr;
-    return slot;
+    unsigned* base = page + (page_used++) * kCountersPerStream;
+    table.push_back({dev, stream, base});
+    return base;
 }
 
 
@@ -2232,7 +2298,8 @@ static unsigned* next_work_counter(hipStream_t stream, bool zero = true)
 // others) runs its two launches side by side: with the reference's tree the blocking launch has a few dozen items for 256
 // CUs and would otherwise hold the stream for the length of one item (0.5 ms forward, 1 ms backward at the metric size);
 // in exact mode the second launch fills the first one's tail.  One side stream + two events per host thread and device,
-// created on first use and kept; fork/join by events, so it also works under stream capture.
+// created on first use and kept; fork/join by events, so it also works under stream capture.  (Two host threads that drive
+// the SAME caller stream would share that stream's work counters: one stream, one thread at a time - as for any HIP stream.)
 struct SideStream {
     hipStream_t side = nullptr; hipEvent_t fork = nullptr, join = nullptr; int dev = -1; bool pending = false;
     hipStream_t main = nullptr;
@@ -2242,7 +2309,7 @@ struct SideStream {
         int d = 0;
         if (hipGetDevice(&d) != hipSuccess) return false;
         if (dev != d) {
-            if (dev >= 0) return false;                 // (one device per process in this framework: no second set)
+            if (dev >= 0) return false;                 // (never: side_stream() keeps one set per device)
             if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { dev = -2; return false; }
@@ -2271,8 +2338,11 @@ struct SideStream {
 struct SideJoin { SideStream* s; ~SideJoin() { if (s) s->end(); } };      // error returns join too
 static SideStream* side_stream()
 {
-    thread_local SideStream s;
-    return env_int("ARTIST_HIP_BLOCKING_CONCURRENT", 1) != 0 ? &s : nullptr;
+    constexpr int kMaxDevices = 64;
+    thread_local SideStream s[kMaxDevices];          // one side stream + two events per host thread AND device
+    int d = 0;
+    if (env_int("ARTIST_HIP_BLOCKING_CONCURRENT", 1) == 0 || hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
+    return &s[d];
 }
 
 
@@ -2410,13 +2480,13 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     const int64_t n_maps = mode == 0 ? H : T + Tc;
     unsigned* counts = reinterpret_cast<unsigned*>(factors);
     // planar launch, cylinder launch, lean launch of a split call
-    unsigned* work_counters[3] = {next_work_counter(stream, false), next_work_counter(stream, false), next_work_counter(stream, false)};
-    if (work_counters[0] == nullptr || work_counters[1] == nullptr || work_counters[2] == nullptr) {
+    unsigned* const wc_base = stream_work_counters(stream);
+    if (wc_base == nullptr) {
         g_last_hip_error = (int)hipErrorOutOfMemory;
         return ART_ELAUNCH;
     }
-    hipLaunchKernelGGL(trace_fwd_prep_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, stream, counts, (int)(3 * H),
-                       work_counters[0], work_counters[1], work_counters[2]);
+    unsigned* work_counters[3] = {wc_base, wc_base + 1, wc_base + 2};
+    hipLaunchKernelGGL(trace_fwd_prep_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, stream, counts, (int)(3 * H));
     FwdConfig cfg = fwd_config();
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
@@ -2557,8 +2627,12 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         hipLaunchKernelGGL(accum_to_flux_kernel, dim3((unsigned)((npix / 2 + 1 + 255) / 256)), dim3(256), 0, stream, a.accum, flux, npix,
                            sign_unit);
     }
+    if (blocking)
+        hipLaunchKernelGGL(poison_overflow_kernel, dim3((unsigned)H), dim3(256), 0, stream, a.cand_count, a.Cmax, a.target_idx,
+                           a.T + a.Tc, flux, (int64_t)Hh * W, mode);
     hipLaunchKernelGGL(finalize_factors_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, factors,
-                       (int)H, (float)(R * P), blocking ? 1 : 0, a.split == 2 ? a.cand_count : nullptr);
+                       (int)H, (float)(R * P), blocking ? 1 : 0, a.split == 2 ? a.cand_count : nullptr,
+                       blocking ? a.cand_count : nullptr, a.Cmax);
     ART_HIP(hipGetLastError());
 #ifdef ART_DEBUG_TIMELINE
     if (const char* out = getenv("ART_TIMELINE_OUT")) {     // the last call's records: [blocks][8] u64, raw
@@ -2676,8 +2750,9 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                 if (items_l > 2147483647LL - 65536) return ART_EINVAL;
                 const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
                 const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(float) + perm_l;
-                unsigned* wc = next_work_counter(stream);
+                unsigned* wc = stream_work_counters(stream);
                 if (wc == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
+                wc += 4;                                 // backward, lean launch of a split call
                 const int threads_l = cl.block;
                 // submitted AFTER the blocking launch (see art_trace_fwd)
                 SideStream* ss = side_stream();
@@ -2716,8 +2791,9 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             const int64_t blocks = ((CY && !kCylPersistentBwd) || (!CY && BL && !kBlockingPersistentBwd)) ? items : persistent_blocks; \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL, LN>),\
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            unsigned* work_counter = next_work_counter(stream);                                                  \
+            unsigned* work_counter = stream_work_counters(stream);                                               \
             if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
+            work_counter += CY ? 6 : 5;                       /* backward: planar / cylinder launch */          \
             hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL, LN>), dim3((unsigned)blocks),               \
                                dim3(std::min(cfg.block, CY ? kCylBwdThreads : (BL ? kBlockingBwdThreads : 1024))), lds, stream, a, grad_flux, \
                                go, gn,                                                                           \

@@ -48,6 +48,42 @@ def all_reduce_sum_async(tensor: torch.Tensor, group=None):
     return None
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """SUM all-reduce inside the autograd graph; see ``all_reduce_sum_autograd``."""
+
+    @staticmethod
+    def forward(ctx, tensor, group, backward):
+        ctx.group, ctx.backward_mode = group, backward
+        out = tensor.detach().clone(memory_format=torch.contiguous_format)
+        if _exchanging(group):
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.backward_mode == "local" or not _exchanging(ctx.group):
+            return grad_out, None, None
+        grad = grad_out.contiguous().clone()
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=ctx.group)
+        return grad, None, None
+
+
+def all_reduce_sum_autograd(tensor: torch.Tensor, group=None, backward: str = "sum") -> torch.Tensor:
+    """Differentiable SUM all-reduce of the receiver flux: what ``torch.distributed.nn.functional.all_reduce`` does in
+    ``AimPointOptimizer`` (artist/optim/aim_point_optimizer.py:515-519) - the total flux of all ranks stays in the autograd
+    graph, so a loss on the REDUCED bitmap (flux integral, local flux density, KL against the target distribution) reaches
+    every rank's heliostats.  Not in place: the input keeps its value.  A no-op in a single-process run.
+
+    ``backward="sum"`` (default) is the reference's: the backward pass all-reduces the incoming gradient, so when every
+    rank evaluates the same loss on the same reduced flux - as the reference's optimiser does - a rank's parameters
+    receive ``world_size`` x the single-process gradient (Adam, which the reference uses, does not see the factor).
+    ``backward="local"`` passes the rank's own upstream gradient through (no second collective): exactly the
+    single-process gradient in that situation."""
+    if backward not in ("sum", "local"):
+        raise ValueError("backward must be 'sum' (torch.distributed.nn.functional.all_reduce) or 'local'")
+    return _AllReduceSum.apply(tensor, group, backward)
+
+
 class _PendingRows:
     """Handle of ``gather_owned_rows(..., async_op=True)``: ``wait()`` returns the gathered tensor."""
 

@@ -48,7 +48,11 @@ _CONVERTED: "collections.OrderedDict" = collections.OrderedDict()
 
 
 def _converted(t: torch.Tensor, what: str, make):
-    key = (what, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version, str(t.device))
+    try:
+        version = t._version
+    except (RuntimeError, AttributeError):          # inference-mode tensors have no version counter: no caching
+        return make(t)
+    key = (what, t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, version, str(t.device))
     hit = _CONVERTED.get(key)
     if hit is not None:
         _CONVERTED.move_to_end(key)
@@ -136,12 +140,18 @@ def reflect_directions(incident: torch.Tensor, normals: torch.Tensor) -> torch.T
 
 
 def check_async_errors(device=None, clear: bool = True) -> None:
-    """Synchronise the current stream of ``device`` and raise if a kernel met a target index outside the target
-    tables or the blocking filter found more candidate rectangles for a heliostat than the kernels hold
-    (``art_async_status``): the entry points are asynchronous, so the device-side checks report here - or at the
-    next trace call, which refuses to start while the status is set."""
+    """Synchronise ``device`` and raise if a kernel met a target index outside the target tables or the blocking filter
+    found more candidate rectangles for a heliostat than the kernels hold (``art_async_status``): the entry points are
+    asynchronous, so the device-side checks report here - or at the next trace call, which refuses to start while the
+    status is set.  The status is ONE sticky word per GPU, shared by every stream and tracer of the process: whoever
+    calls this clears it for all of them (``clear=False`` only looks).  A heliostat that was skipped or traced with an
+    incomplete rectangle list is also marked in the results themselves: zero bitmap and factors for a bad target index,
+    NaN bitmap and factors for a candidate overflow."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     with torch.cuda.device(dev):
+        # the status word is one per GPU (include/artist_hip.h): a kernel on ANY stream of this process may have set it,
+        # so wait for the whole device, not only for the current stream
+        torch.cuda.synchronize(dev)
         rc = _lib.lib().art_async_status(_stream(dev), 1 if clear else 0)
     if rc == -2:
         _ACCUM.clear()              # a skipped heliostat leaves nothing behind, but take no chances with the invariant
@@ -233,6 +243,11 @@ class TraceRays(torch.autograd.Function):
         if rc == -2:
             raise IndexError("target_area_indices out of range (found by the kernels of an earlier call; "
                              "artist_amd.ops.check_async_errors() clears the status)")
+        if rc == -5:
+            raise _lib.ArtistHipError(
+                f"a heliostat has more than {BLOCKING_CANDIDATES} blocking rectangles inside its ray cone (found by "
+                "art_blocking_filter in an earlier call, whose bitmaps and factors for that heliostat are NaN; "
+                "artist_amd.ops.check_async_errors() clears the status)")
         _lib.check(rc, "art_trace_fwd")
         ctx.save_for_backward(origins, normals, incident, dist_u, dist_e, target_idx, centers, plane_normals, dims,
                               *cyl_tabs, *block_tabs)
@@ -275,6 +290,9 @@ class TraceRays(torch.autograd.Function):
                 1 if per_target else 0, grad_flux.data_ptr(), g_o.data_ptr(), g_n.data_ptr(),
                 *(t.data_ptr() if t is not None else None for t in (g_pc, g_ps, g_pn)),
                 None if scratch is None else scratch.data_ptr(), n_scratch, _stream(dev))
+        if rc == -2:
+            raise IndexError("target_area_indices out of range (found by the kernels of an earlier call; "
+                             "artist_amd.ops.check_async_errors() clears the status)")
         _lib.check(rc, "art_trace_bwd")
         return (g_o, g_n) + (None,) * 14 + (g_pc, g_ps, g_pn, None, None, None, None)
 

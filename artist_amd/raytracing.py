@@ -43,6 +43,16 @@ def reflect(incident_ray_directions: torch.Tensor, reflection_surface_normals: t
     return i - 2 * torch.sum(i * nrm, dim=-1, keepdim=True) * nrm
 
 
+def _version_of(t: torch.Tensor):
+    """``t._version`` or None where there is no version counter (inference-mode tensors): no caching then.  The per-call
+    caches of this module key on tensor identity + version, so index tensors and masks have to be changed with tracked
+    in-place ops (or replaced): a write through ``.data`` or by a raw kernel is invisible to them."""
+    try:
+        return t._version
+    except (RuntimeError, AttributeError):
+        return None
+
+
 def target_area_counts(tower) -> tuple[int, int]:
     """(planar, cylindrical) target areas of a tower, from the HOST side of its tables (``number_of_target_areas`` is
     ``len(names)``, artist/field/tower_target_areas.py:62): ``solar_tower.number_of_target_areas_per_type``
@@ -175,6 +185,7 @@ class HeliostatRayTracer:
             du, de = both[..., 0], both[..., 1]
         idx = None if owns_all else torch.tensor(idx_list, dtype=torch.long, device=device)
         self._local_cache = (device, idx, du, de)
+        self._owner_cache = None                       # (keyed on `idx`: rebuilt with it)
         return idx, du, de
 
     def trace_rays(self, incident_ray_directions: torch.Tensor, active_heliostats_mask: torch.Tensor,
@@ -222,7 +233,18 @@ class HeliostatRayTracer:
         that never looks at it has no host-device synchronisation in its ray tracing."""
         if self._filtered is None and self._filter_flags is not None:
             self._filtered = torch.nonzero(self._filter_flags, as_tuple=True)[0]
+            # this read waited for the device anyway: the moment to learn that the filter met more candidate rectangles
+            # than the kernels hold (the device-side report of the asynchronous call, ops.check_async_errors)
+            ops.check_async_errors(self._filter_flags.device, clear=False)
         return self._filtered
+
+    def finish(self, device: torch.device | None = None) -> None:
+        """Wait for the ray tracing queued so far and raise what only the device could find out (a target index outside
+        the tables, more blocking rectangles inside one heliostat's ray cone than the kernels hold) -
+        ``ops.check_async_errors``.  ``trace_rays`` itself never waits; call this after a single prediction or the last
+        epoch (an overflowed heliostat's bitmap and factors are NaN either way)."""
+        points = self.heliostat_group.active_surface_points
+        ops.check_async_errors(points.device if device is None else device)
 
     @filtered_blocking_primitive_indices.setter
     def filtered_blocking_primitive_indices(self, value) -> None:
@@ -242,12 +264,13 @@ class HeliostatRayTracer:
         (one host-device synchronisation, not one per epoch).  The C ABI checks them again on the device and reports
         ``ART_ETARGET`` instead of reading out of bounds (include/artist_hip.h)."""
         checked = self._checked_targets
-        if target_area_indices.numel() > 0 and not (checked is not None and checked[0]() is target_area_indices and
-                                                     checked[1] == target_area_indices._version):
+        version = _version_of(target_area_indices)
+        if target_area_indices.numel() > 0 and not (version is not None and checked is not None and
+                                                     checked[0]() is target_area_indices and checked[1] == version):
             lo, hi = int(target_area_indices.min()), int(target_area_indices.max())
             if lo < 0 or hi >= sum(target_area_counts(tower)):
                 raise IndexError("target_area_indices out of range")
-            self._checked_targets = (weakref.ref(target_area_indices), target_area_indices._version)
+            self._checked_targets = (weakref.ref(target_area_indices), version)
 
     def _blocking_arguments(self, idx, active_heliostats_mask):
         """Rectangles of all heliostats (:291-301) + the rectangle index of each traced heliostat (:445-448)."""
@@ -256,11 +279,14 @@ class HeliostatRayTracer:
         corners, spans, normals = create_blocking_primitives_rectangles_by_index(self.blocking_heliostat_surfaces_active)
         # rectangle index of each active heliostat: once per mask tensor object and version (nonzero() waits for the device)
         cached = self._owner_cache
-        if cached is None or cached[0]() is not active_heliostats_mask or cached[1] != active_heliostats_mask._version:
+        version = _version_of(active_heliostats_mask)
+        key = (version, None if idx is None else id(idx), str(active_heliostats_mask.device))
+        if version is None or cached is None or cached[0]() is not active_heliostats_mask or cached[1] != key:
             owner = torch.nonzero(active_heliostats_mask, as_tuple=True)[0]
             if idx is not None:
                 owner = owner.index_select(0, idx.to(owner.device))
-            self._owner_cache = cached = (weakref.ref(active_heliostats_mask), active_heliostats_mask._version, owner)
+            # (`idx` is kept alive by the entry, so its id cannot be handed to another tensor while the entry lives)
+            self._owner_cache = cached = (weakref.ref(active_heliostats_mask), key, owner, idx)
         owner = cached[2]
         return corners, spans, normals, owner, self._max_scatter_angle(), self.lbvh_compat
 
@@ -271,9 +297,10 @@ class HeliostatRayTracer:
         u, e = ds.distortions_u, ds.distortions_e
         cached = self._scatter_angle_cache[0]
         # valid for the SAME tensor objects at the same versions only: a bound that is too small would change results
-        if cached is None or cached[0]() is not u or cached[1]() is not e or cached[2:] != (u._version, e._version):
+        vu, ve = _version_of(u), _version_of(e)
+        if vu is None or ve is None or cached is None or cached[0]() is not u or cached[1]() is not e or cached[2:] != (vu, ve):
             value = float(torch.maximum(u.abs().max(), e.abs().max()))
-            self._scatter_angle_cache = ((weakref.ref(u), weakref.ref(e), u._version, e._version), value)
+            self._scatter_angle_cache = ((weakref.ref(u), weakref.ref(e), vu, ve), value)
         return self._scatter_angle_cache[1]
 
     def trace_rays_per_target(self, incident_ray_directions, active_heliostats_mask, target_area_indices,

@@ -51,6 +51,12 @@ class DistortionsDataset(torch.utils.data.Dataset):
             self.distortions_u, self.distortions_e = both[..., 0], both[..., 1]      # one interleaved buffer again
 
     def _sample_rows(self, light_source, n_points, n_heliostats, seed):
+        if not self.rows:
+            # an idle rank (more ranks than active heliostats, sampling.py:107-157 `number_of_active_ranks`): no rows
+            n_rays = int(getattr(light_source, "number_of_rays", 0) or 0)
+            device = getattr(getattr(getattr(light_source, "distribution", None), "loc", None), "device", None)
+            both = torch.empty((0, n_rays, int(n_points), 2), device=device)
+            return both[..., 0], both[..., 1]
         if hasattr(light_source, "get_distortions_rows"):
             got = light_source.get_distortions_rows(self.rows, number_of_points=n_points,
                                                     number_of_active_heliostats=n_heliostats, random_seed=seed)

@@ -155,6 +155,15 @@ def correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops, points_per_
             "against": "oracle (C restatement of the reference, fp32 op for op) on the same inputs"}
 
 
+def flux_checksum(per_target):
+    """What an N-rank line and the 1-rank line can be compared by: sum, L2 norm and a 16x16 block-sum of the REDUCED
+    per-target flux (fp64 on the host, printed to 9 digits)."""
+    f = per_target.detach().double().cpu()
+    t, hh, w = f.shape
+    down = f.reshape(t, 16, hh // 16, 16, w // 16).sum(dim=(2, 4)) if hh % 16 == 0 and w % 16 == 0 else f.sum(dim=(1, 2), keepdim=True)
+    return {"sum": float(f.sum()), "l2": float(f.norm()), "down16": [float(f"{v:.9g}") for v in down.flatten().tolist()]}
+
+
 def launch_ranks(n: int) -> int:
     """``python bench.py --gpus N`` without a launcher: start N ranks of this script under ``torch.distributed.run``
     (one process per GPU, rendezvous on 127.0.0.1) as a CHILD process and hand back its exit code.  The parent never
@@ -226,10 +235,12 @@ def main():
     degrees = group.nurbs_degrees
     planar = scenario.solar_tower.target_areas[0]
     T = planar.centers.shape[0]
-    # distortions for the owned rows only: ONE interleaved [H,R,P,2] buffer, (u,e) = stride-2 views
-    g = torch.Generator(device=dev).manual_seed(7 + rank)
-    both = torch.randn((H, R, P, 2), generator=g, device=dev, dtype=torch.float32).mul_(4.3681e-06 ** 0.5)
-    dist_u, dist_e = both[..., 0], both[..., 1]
+    # Distortions: this rank's ROWS of the field-wide seed-7 sample (artist/raytracing/sampling.py:49-53 samples [H,R,P] for the
+    # whole field with random_seed=7; the product's DistortionsDataset(rows=...) / Sun.get_distortions_rows draw row i from a
+    # stream keyed by (seed, i)): an N-rank run traces EXACTLY the rays of the 1-rank run, whatever N is - which is what lets
+    # the reduced flux be compared with the single-rank flux below.  ONE interleaved [H,R,P,2] buffer, (u,e) = stride-2 views.
+    sun = scenario.light_sources.light_source_list[0]
+    dist_u, dist_e = sun.get_distortions_rows(own, number_of_points=P, number_of_active_heliostats=H_total, random_seed=7)
 
     from artist_amd import ops
     from artist_amd.flux import FluxCrop, FluxCropPixelLoss
@@ -354,6 +365,33 @@ def main():
     if rank == 0 and not args.no_check:
         check = correctness_stamp(ap, an, inc, dist_u, dist_e, tix, planar, ops, n_eval * n_eval)
 
+    # ---- did sharding preserve the result?  (outside every timed region) --------------------------------------------------
+    # The flux of the whole field as the ranks produced it - local per-target sums + ONE all-reduce, the exchange of
+    # tutorials/02_heliostat_raytracing_distributed_tutorial.py:185-190 - against the same field traced by ONE rank: rank 0
+    # gathers everybody's control points (they were trained for warmup + steps epochs), draws ALL rows of the seed-7 sample
+    # and traces the 1000 heliostats alone.  An N = 1 run prints the same checksum, so lines of different N can be compared
+    # with each other as well (bit-identical per-heliostat bitmaps; the per-target sums differ by fp32 summation order).
+    with torch.no_grad():
+        reduced = step(False)                                    # forward only: NURBS -> trace -> per-target sum -> all-reduce
+    sharding = {"reduced_flux": flux_checksum(reduced)} if rank == 0 else None
+    if (world > 1 or rehearse) and not args.no_check:
+        cp_field = gather_owned_rows(cp.detach(), H_total)       # collective: every rank takes part
+        if rank == 0:
+            with torch.no_grad():
+                du_all, de_all = sun.get_distortions_rows(list(range(H_total)), number_of_points=P,
+                                                          number_of_active_heliostats=H_total, random_seed=7)
+                ap_all, an_all = NURBSSurfaces(degrees, cp_field, device=dev).calculate_surface_points_and_normals(
+                    uv[:1].expand(H_total, -1, -1, -1), group.active_canting, group.active_facet_translations,
+                    orientations=orientation_all)
+                flux_all, _ = ops.trace_rays(ap_all.reshape(H_total, P, 4), an_all.reshape(H_total, P, 4), inc_all, du_all, de_all,
+                                             tix_all, planar.centers, planar.normals, planar.dimensions, 1.0, 0.0, 0.935, (256, 256),
+                                             points_per_facet=n_eval * n_eval)
+                single = ops.per_target_sum(flux_all, tix_all, T)
+                rel = float((reduced.double() - single.double()).norm() / single.double().norm())
+                del du_all, de_all, ap_all, an_all, flux_all
+            sharding.update({"single_rank_flux": flux_checksum(single), "reduced_vs_single_rank_rel_l2": rel,
+                             "tolerance": 2e-6, "ok": bool(rel < 2e-6)})
+
     if rank == 0:
         total_rays = H_total * R * P
         out = {
@@ -394,6 +432,7 @@ def main():
                                          "section 4.4, issue rates in 4.0 (profiles/r02_issue_bench.json, r02_ablation.txt); stated from "
                                          "profiles/, not measured by this run"},
             "check": check,
+            "sharding_check": sharding,
         }
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
@@ -407,6 +446,8 @@ def main():
             out["cpu_baseline"]["reference_shape_torch"] = torch_eager_baseline(
                 args, ap[:min(H, 64)].cpu(), an[:min(H, 64)].cpu(), inc[:min(H, 64)].cpu(), planar, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+        if sharding is not None and sharding.get("ok") is False:
+            raise SystemExit(f"sharded flux differs from the single-rank flux: rel L2 {sharding['reduced_vs_single_rank_rel_l2']:.3e}")
     if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()

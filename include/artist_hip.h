@@ -10,8 +10,15 @@
  * Conventions
  *   - plain pointers + sizes, no torch types; all tensors fp32, row-major, contiguous unless
  *     an explicit element stride is passed; all pointers are DEVICE pointers;
- *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream
- *     and allocates nothing that outlives it; no global state -> re-entrant;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream.  Calls on DIFFERENT
+ *     streams (from one host thread or several) may overlap freely - each brings its own output, scratch and
+ *     accumulator buffers; calls on the SAME stream must come from one host thread at a time, like any HIP work;
+ *   - process-wide state, all of it created on first use and kept: per GPU one sticky status word in mapped host
+ *     memory (art_async_status below - shared by every stream: an error found by a kernel of one stream makes the
+ *     trace entry points refuse on all of them until somebody clears it), per (GPU, stream) eight 4-byte work
+ *     counters in device memory (zero whenever no launch is using them: the launch's last fetch resets them, so
+ *     there is no bound on the number of queued launches), per (host thread, GPU) one side stream + two events
+ *     for the second launch of a split call (blocking on / mixed towers); nothing else survives a call;
  *   - return 0 on success, a negative ART_E* code otherwise (never throws across the ABI);
  *     art_strerror() maps a code to text;
  *   - outputs are fully written by the callee (zero-filled first where they are accumulators).
@@ -88,8 +95,9 @@ int art_last_hip_error(void);
  *                     pixel: the flux does not depend on the order in which workgroups finish - two calls with the
  *                     same inputs give the same bits (the reference needs torch.use_deterministic_algorithms for
  *                     that, tests/conftest.py:109).  `flux` itself needs no initialisation.
- * Device memory: every buffer is the caller's, except 4 KB per GPU that the library allocates on the first trace
- * call and keeps (work counters of its persistent workgroups, one slot per launch, zeroed on the launch stream)
+ * Device memory: every buffer is the caller's, except 4 KB pages that the library allocates on first use and keeps
+ * (work counters of its persistent workgroups: 32 bytes per stream that has made a trace call, see Conventions; the
+ * first trace call on a stream must therefore not be made while that stream is being captured into a graph)
  * and 64 bytes of mapped host memory per GPU (the status word of art_async_status).
  * ------------------------------------------------------------------------------------------- */
 int art_trace_fwd(const float *origins, const float *normals, const float *incident,
@@ -107,11 +115,16 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
  * art_async_status - the entry points are asynchronous, so what only the DEVICE can find out is reported here:
  * synchronises `stream` and returns ART_ETARGET if a kernel launched through this library met a target index
  * outside [0, T + Tc) since the status was last cleared (the heliostat was skipped - no table is indexed out of
- * bounds - and its bitmap and factors are zero), ART_ECANDIDATES if art_blocking_filter found more than Cmax
- * rectangles inside a heliostat's ray cone (the surplus is not evaluated: that heliostat's blocking is incomplete;
- * cand_count[h] holds the number found), ART_OK otherwise.  `clear` != 0 resets the status.  Until it is
- * cleared, every later art_trace_fwd / art_trace_bwd call returns the same code at once (checked without a
- * synchronisation).  The reference fails in the same situation with an IndexError from its target-area gather
+ * bounds - its bitmap and factors are zero, and so are its gradients in art_trace_bwd), ART_ECANDIDATES if
+ * art_blocking_filter found more than Cmax rectangles inside a heliostat's ray cone (the surplus is not evaluated:
+ * that heliostat's blocking is incomplete; cand_count[h] holds the number found, and art_trace_fwd writes NaN
+ * into that heliostat's bitmap - its target's bitmap in mode 1 - and factors, so the call that overflowed cannot
+ * be mistaken for a result), ART_OK otherwise.  `clear` != 0 resets the status.  Until it is cleared, every later
+ * art_trace_fwd / art_trace_bwd call returns the same code at once (checked without a synchronisation).
+ * SCOPE: one status word per GPU, not per stream or call.  Work of OTHER streams is not waited for here - a
+ * caller with several streams synchronises the device first (artist_amd.ops.check_async_errors does) - and a status
+ * raised by one stream's kernel stops the trace calls of every stream until it is cleared (by any of them).
+ * The reference fails in the same situation with an IndexError from its target-area gather
  * (artist/raytracing/geometry.py:104-105).
  * ------------------------------------------------------------------------------------------- */
 int art_async_status(void *stream, int clear);
@@ -248,8 +261,13 @@ int art_align_bwd(const float *points, const float *normals, const float *orient
  *   flux [B,Hh,W]; target_dims [B,2] = (width, height) in metres of each bitmap's target area - planar
  *   dimensions, or radius x opening angle and height for cylinders (the gather of :183-216 is host logic);
  *   out [B,Hh,W]; centers [B,3] out = (x centre, y centre, sum + 1e-8), needed by the backward.
- * art_flux_crop_bwd - its autograd w.r.t. flux: the sampled values (as a gather: deterministic) and the path
- * XX
+ * art_flux_crop_bwd - its autograd w.r.t. flux (what torch derives for :165-246), both paths: the sampled values -
+ *   grid_sample's input gradient, here a GATHER over the output pixels that sampled an input pixel (the map is
+ *   axis-aligned and monotone), so bit-reproducible where torch's CUDA backward scatters with float atomics
+ *   (tests/conftest.py:93-97) - and the path through the centre of mass (grid_sample's grid gradient, reduced to
+ *   the two centre coordinates and chained through x centre = sum(x flux) / (sum flux + 1e-8), :165-182).
+ *   centers [B,3] as written by the forward call; grad_out [B,Hh,W]; grad_flux [B,Hh,W] out (fully written);
+ *   workspace: at least 2 * B floats of device memory (per bitmap the gradients of the two centre coordinates).
  * ------------------------------------------------------------------------------------------- */
 int art_flux_crop_fwd(const float *flux, const float *target_dims, int64_t B, int64_t Hh, int64_t W,
                       double crop_width, double crop_height, float *out, float *centers, void *stream);
@@ -284,6 +302,36 @@ int art_flux_crop_pixel_loss_bwd(const float *flux, const float *target_dims, co
                                  const float *centers4, const float *grad_loss, int64_t B, int64_t Hh, int64_t W,
                                  double crop_width, double crop_height, float *grad_flux, float *workspace,
                                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_flux_crop_kl_loss_fwd / _bwd - crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246) followed by
+ * KLDivergenceLoss (artist/optim/loss.py:321-410: L1-normalise both bitmaps, KLDivLoss(log_target) on log(. + 1e-12),
+ * summed over the bitmap) as ONE pass per direction, like the PixelLoss pair above; results equal art_flux_crop_fwd +
+ * art_flux_loss(kind 1) and their backward calls (same arithmetic, same order).
+ *   flux [B,Hh,W], target_dims [B,2], ground_truth [B,Hh,W] (already cropped); loss [B] out;
+ *   record8 [B,8] out (centre of mass x, y, bitmap sum + 1e-8, |crop|_1, |truth|_1, the normalisation's dot product,
+ *   2 spare): pass it back to the backward call.  grad_loss [B]; grad_flux [B,Hh,W] out; workspace B*Hh*W + 5*B floats.
+ * ------------------------------------------------------------------------------------------- */
+int art_flux_crop_kl_loss_fwd(const float *flux, const float *target_dims, const float *ground_truth, int64_t B,
+                              int64_t Hh, int64_t W, double crop_width, double crop_height, float *loss,
+                              float *record8, void *stream);
+int art_flux_crop_kl_loss_bwd(const float *flux, const float *target_dims, const float *ground_truth,
+                              const float *record8, const float *grad_loss, int64_t B, int64_t Hh, int64_t W,
+                              double crop_width, double crop_height, float *grad_flux, float *workspace,
+                              void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * art_flux_center_of_mass - get_center_of_mass (artist/flux/bitmap.py:12-71): bitmap (pixel) coordinates of each
+ * bitmap's centre of mass, e = sum_ij j f_ij / (sum f + 1e-8), u likewise with i; (0, 0) for an empty bitmap.  It is
+ * what FocalSpotLoss (artist/optim/loss.py:124-250) and the kinematics reconstructor's validation
+ * (artist/optim/kinematics_reconstructor.py:120) compute from the tracer's bitmaps.
+ *   flux [B,Hh,W]; com [B,3] out = (e pixel, u pixel, sum + 1e-8).
+ * art_flux_center_of_mass_bwd - its autograd: grad_flux[b,i,j] = (g_e (j - e) + g_u (i - u)) / (sum + 1e-8).
+ *   com [B,3] as written by the forward call; grad_com [B,2]; grad_flux [B,Hh,W] out (fully written).
+ * ------------------------------------------------------------------------------------------- */
+int art_flux_center_of_mass(const float *flux, int64_t B, int64_t Hh, int64_t W, float *com, void *stream);
+int art_flux_center_of_mass_bwd(const float *com, const float *grad_com, int64_t B, int64_t Hh, int64_t W,
+                                float *grad_flux, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * art_rigid_body_fwd - RigidBody kinematics of H heliostats in one launch

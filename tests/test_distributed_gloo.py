@@ -87,3 +87,55 @@ def test_sharded_flux_reduces_to_single_rank(tmp_path, world, case):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, case, tmp_path), nprocs=world, join=True)
     assert sorted(p.name for p in tmp_path.iterdir()) == [f"ok_{r}" for r in range(world)]
+
+
+def _autograd_worker(rank, world, port, out_dir):
+    """A loss on the REDUCED flux (aim_point_optimizer.py:515-519 keeps the all-reduce in the graph): each rank's rows of
+    the gradient against the single-process gradient."""
+    from artist_amd.distributed import all_reduce_sum_autograd, owned_heliostats
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, npix = 7, 48
+        gen = torch.Generator().manual_seed(3)
+        bitmaps = torch.rand((H, npix), generator=gen, dtype=torch.float64)       # each heliostat's unit image
+        target = torch.rand((npix,), generator=gen, dtype=torch.float64) * H / 2
+        theta0 = torch.rand((H,), generator=gen, dtype=torch.float64) + 0.5
+
+        def loss_of(total):                                                        # pixel loss + a flux-integral term
+            return ((total - target) ** 2).sum() + 0.1 * total.sum() ** 2
+
+        theta = theta0.clone().requires_grad_(True)
+        loss_of((theta[:, None] * bitmaps).sum(0)).backward()
+        single = theta.grad.clone()
+
+        own = owned_heliostats(H, world, rank)
+        for mode, factor in (("sum", float(world)), ("local", 1.0)):
+            local = theta0[own].clone().requires_grad_(True)
+            flux_local = (local[:, None] * bitmaps[own]).sum(0)
+            before = flux_local.detach().clone()
+            total = all_reduce_sum_autograd(flux_local, backward=mode)
+            assert torch.equal(flux_local.detach(), before)                        # not in place
+            torch.testing.assert_close(total.detach(), (theta0[:, None] * bitmaps).sum(0), rtol=1e-13, atol=0)
+            loss_of(total).backward()
+            torch.testing.assert_close(local.grad, factor * single[own], rtol=1e-12, atol=0)
+        with pytest.raises(ValueError):
+            all_reduce_sum_autograd(torch.zeros(3), backward="mean")
+        (out_dir / f"ok_{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_differentiable_flux_all_reduce(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_autograd_worker, args=(world, port, tmp_path), nprocs=world, join=True)
+    assert sorted(p.name for p in tmp_path.iterdir()) == [f"ok_{r}" for r in range(world)]
+
+
+def test_differentiable_flux_all_reduce_is_the_identity_in_one_process():
+    from artist_amd.distributed import all_reduce_sum_autograd
+    x = torch.arange(6.0, requires_grad=True)
+    y = all_reduce_sum_autograd(x * 2.0)
+    (y ** 2).sum().backward()
+    assert torch.equal(y.detach(), torch.arange(6.0) * 2.0) and torch.equal(x.grad, 8.0 * torch.arange(6.0))

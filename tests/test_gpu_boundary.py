@@ -1,0 +1,168 @@
+"""GPU tests of the C-ABI boundary's process-wide state (``-m gpu``): streams, the sticky status word, the work
+counters, and what a heliostat the device had to skip leaves in the outputs (include/artist_hip.h, "Conventions")."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import DEV, blocking_inputs, n, trace_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_streams_trace_concurrently(golden):
+    """Two streams drive art_trace_fwd / art_trace_bwd at the same time (each with its own accumulator buffer and work
+    counters): every result equals the single-stream one bit for bit."""
+    from artist_amd import trace_rays
+    d = golden("mid_256")
+    base = trace_inputs(d)
+    ref_flux, ref_fac = trace_rays(**base)
+    w = torch.rand(ref_flux.shape, device=DEV)
+    o0, n0 = base["origins"].clone().requires_grad_(True), base["normals"].clone().requires_grad_(True)
+    f0, _ = trace_rays(**dict(base, origins=o0, normals=n0))
+    ref_go, ref_gn = torch.autograd.grad(f0, (o0, n0), w)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    results = [[], []]
+    for rep in range(6):                                  # interleaved submissions: the launches overlap on the device
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                o, nn_ = base["origins"].clone().requires_grad_(True), base["normals"].clone().requires_grad_(True)
+                flux, fac = trace_rays(**dict(base, origins=o, normals=nn_))
+                go, gn = torch.autograd.grad(flux, (o, nn_), w)
+                results[k].append((flux, fac, go, gn))
+    torch.cuda.synchronize()
+    for per_stream in results:
+        for flux, fac, go, gn in per_stream:
+            np.testing.assert_array_equal(n(flux), n(ref_flux))
+            np.testing.assert_array_equal(n(fac), n(ref_fac))
+            np.testing.assert_array_equal(n(go), n(ref_go))
+            np.testing.assert_array_equal(n(gn), n(ref_gn))
+
+
+def test_status_word_is_per_device_and_any_stream_may_clear_it(golden):
+    """The status word is one per GPU: a bad target index met by a kernel of stream A makes a trace call on stream B
+    refuse, and a caller on stream B can clear it (``check_async_errors`` synchronises the device)."""
+    from artist_amd import _lib, ops
+    d = golden("small_deg3")
+    inp = trace_inputs(d)
+    good, _ = ops.trace_rays(**inp)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    bad = dict(inp, target_idx=inp["target_idx"].clone())
+    bad["target_idx"][0] = 5
+    with torch.cuda.stream(a):
+        ops.trace_rays(**bad)                                     # asynchronous: no error yet
+    a.synchronize()
+    with torch.cuda.stream(b):
+        with pytest.raises(IndexError, match="out of range"):
+            ops.trace_rays(**inp)                                 # another stream, same GPU: refused
+        with pytest.raises(IndexError, match="out of range"):
+            ops.check_async_errors(DEV)                           # ... and cleared from here
+        assert _lib.lib().art_async_status(b.cuda_stream, 0) == 0
+        again, _ = ops.trace_rays(**inp)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(n(again), n(good))
+
+
+def test_skipped_heliostat_has_zero_gradients(golden):
+    """The functional API has no host-side validation: a heliostat with a stale target index is skipped on the device -
+    and its rows of BOTH gradient tensors are zero (not the allocator's garbage), the others' are untouched."""
+    from artist_amd import ops
+    d = golden("small_deg3")
+    inp = trace_inputs(d)
+    H = inp["origins"].shape[0]
+
+    def grads(target_idx, bad=False):
+        o, nn_ = inp["origins"].clone().requires_grad_(True), inp["normals"].clone().requires_grad_(True)
+        flux, _ = ops.trace_rays(**dict(inp, origins=o, normals=nn_, target_idx=target_idx))
+        if bad:          # the forward kernels have reported the index: clear, so that the backward call starts at all
+            with pytest.raises(IndexError):
+                ops.check_async_errors(DEV)
+        return torch.autograd.grad(flux, (o, nn_), torch.ones_like(flux))
+
+    go_ref, gn_ref = grads(inp["target_idx"])
+    # poison the allocator's free blocks of that size, so that "uninitialised" cannot look like zero by luck
+    for _ in range(4):
+        junk = torch.full_like(inp["origins"], float("nan"))
+        del junk
+    bad = inp["target_idx"].clone()
+    bad[1] = 9
+    go, gn = grads(bad, bad=True)
+    with pytest.raises(IndexError):                               # ... and the backward kernels report it again
+        ops.check_async_errors(DEV)
+    assert float(go[1].abs().sum()) == 0 and float(gn[1].abs().sum()) == 0
+    assert not bool(torch.isnan(go).any()) and not bool(torch.isnan(gn).any())
+    for h in range(H):
+        if h != 1:
+            np.testing.assert_array_equal(n(go[h]), n(go_ref[h]))
+            np.testing.assert_array_equal(n(gn[h]), n(gn_ref[h]))
+
+
+def test_candidate_overflow_poisons_the_overflowed_heliostat(golden, monkeypatch):
+    """More rectangles inside one heliostat's ray cone than the tables hold.  (1) Whatever the host learns and when, the
+    RESULTS of the call that overflowed say so: NaN bitmap and factors for that heliostat, finite ones for the others -
+    shown by clearing the status word between the filter and the trace call, which is the race a caller can lose.
+    (2) Unpatched, the overflow is raised by the same call or the next one, with the hint how to clear the status."""
+    from artist_amd import ArtistHipError, _lib, ops, trace_rays
+    d = golden("small_blocking")
+    inp = trace_inputs(d)
+    blk = blocking_inputs(d)
+    good, good_fac, flags = trace_rays(**inp, blocking=blk)
+    k = int(np.nonzero(n(flags))[0][0])                          # a rectangle that does block somebody
+    shifts = torch.arange(1, 41, device=DEV, dtype=torch.float32)[:, None, None] * 1e-3
+    extra = blk["corners"][k][None] + shifts * blk["normals"][k][None, None, :] * torch.tensor([1.0, 1.0, 1.0, 0.0], device=DEV)
+    crowded = dict(blk, corners=torch.cat([blk["corners"], extra]), spans=torch.cat([blk["spans"], blk["spans"][k][None].expand(40, -1, -1)]),
+                   normals=torch.cat([blk["normals"], blk["normals"][k][None].expand(40, -1)]))
+    handle = _lib.lib()
+    real = handle.art_trace_fwd
+    stream = torch.cuda.current_stream(DEV).cuda_stream
+
+    def trace_after_losing_the_race(*args):
+        assert handle.art_async_status(stream, 1) == -5          # the filter did report it - and somebody cleared it
+        return real(*args)
+
+    monkeypatch.setattr(handle, "art_trace_fwd", trace_after_losing_the_race)
+    flux, fac, _ = trace_rays(**inp, blocking=crowded)
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    over = np.isnan(n(fac)).any(axis=0)                          # [H]
+    assert over.any() and not over.all()
+    for h in range(flux.shape[0]):
+        if over[h]:
+            assert np.isnan(n(flux[h])).all() and np.isnan(n(fac[:, h])).all()
+        else:
+            assert np.isfinite(n(flux[h])).all()
+    assert handle.art_async_status(stream, 0) == 0
+    # (2) the product path
+    try:
+        trace_rays(**inp, blocking=crowded)                       # asynchronous: the status may or may not be visible yet
+        with pytest.raises(ArtistHipError, match="check_async_errors"):
+            trace_rays(**inp, blocking=blk)                       # refused, and the message says how to go on
+    except ArtistHipError as exc:
+        assert "check_async_errors" in str(exc)
+    with pytest.raises(ArtistHipError, match="blocking rectangles"):
+        ops.check_async_errors(DEV)
+    again, again_fac, _ = trace_rays(**inp, blocking=blk)
+    np.testing.assert_array_equal(n(again), n(good))
+    np.testing.assert_array_equal(n(again_fac), n(good_fac))
+
+
+def test_many_queued_launches_share_their_counters_safely(golden):
+    """1500 trace calls queued without one synchronisation (round 2's ring of 1024 work-counter slots would have
+    wrapped): the counters are per stream and reset by each launch's last fetch, so the last result equals the first."""
+    from artist_amd import trace_rays
+    d = golden("small_deg3")
+    inp = trace_inputs(d)
+    first, _ = trace_rays(**inp)
+    o, nn_ = inp["origins"].clone().requires_grad_(True), inp["normals"].clone().requires_grad_(True)
+    w = torch.ones_like(first)
+    g_first = None
+    last = None
+    for k in range(750):
+        last, _ = trace_rays(**dict(inp, origins=o, normals=nn_))
+        g = torch.autograd.grad(last, (o, nn_), w)
+        g_first = g if g_first is None else g_first
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(n(last), n(first))
+    np.testing.assert_array_equal(n(g[0]), n(g_first[0]))
+    np.testing.assert_array_equal(n(g[1]), n(g_first[1]))

@@ -291,6 +291,30 @@ def test_distortions_dataset_keeps_owned_rows_of_the_same_seeded_stream():
         assert sorted(seen) == list(range(H))
 
 
+def test_idle_rank_constructs_an_empty_dataset_and_tracer():
+    """More ranks than active heliostats: the surplus ranks are idle (artist/raytracing/sampling.py:107-157,
+    ``number_of_active_ranks``) - their sampler is empty, their DistortionsDataset holds zero rows (for ARTIST's own
+    CPU ``Sun`` recipe as well as for any other light source) and ``HeliostatRayTracer`` can be constructed for them."""
+    from artist_amd import HeliostatRayTracer
+    from artist_amd.sampling import DistortionsDataset, RestrictedDistributedSampler
+    from artist_amd.scene import Sun
+
+    sampler = RestrictedDistributedSampler(2, 2, 4, 3)
+    assert list(sampler) == [] and len(sampler) == 0
+    for (R, P) in [(4, 64), (3, 63)]:                        # both branches of the owned-rows recipe
+        sun = Sun(R, device=torch.device("cpu"))
+        empty = DistortionsDataset(sun, P, 2, random_seed=7, rows=[])
+        assert len(empty) == 0
+        assert tuple(empty.distortions_u.shape) == (0, R, P) and tuple(empty.distortions_e.shape) == (0, R, P)
+    scenario, group = _tiny_scene(n_heliostats=2, n_rays=4, n_points=8)
+    group.activate_heliostats(torch.tensor([1, 1], dtype=torch.int32))
+    for rank in range(4):
+        rt = HeliostatRayTracer(scenario, group, blocking_active=False, world_size=4, rank=rank)
+        owned = rt.get_sampler_indices().tolist()
+        assert owned == ([rank] if rank < 2 else [])
+        assert len(rt.distortions_dataset) == len(owned)
+
+
 @pytest.mark.parametrize("name", ["test_blocking.h5", "test_scenario_paint_four_heliostats.h5", "test_scenario_stral_single_heliostat.h5"])
 def test_h5lite_is_pinned_by_an_independent_scan_of_the_raw_bytes(name):
     """h5py is absent, so h5lite reads the reference's scenario files for the fixture generator AND for the product: a
