@@ -161,6 +161,149 @@ def crop_and_pixel_loss(flux_distributions: torch.Tensor, solar_tower, target_ar
     return FluxCropPixelLoss.apply(flux_distributions, dims, ground_truth, crop_width, crop_height)
 
 
+class FluxCropKLLoss(torch.autograd.Function):
+    """``KLDivergenceLoss()(crop_flux_distributions_around_center(flux, ...), ground_truth, reduction_dimensions=(1, 2))``
+    as one pass per direction (``art_flux_crop_kl_loss_fwd/bwd``): the cropped bitmaps never reach HBM.  Differentiable
+    w.r.t. ``flux``."""
+
+    @staticmethod
+    def forward(ctx, flux, dims, ground_truth, crop_width, crop_height):
+        dev = _require_cuda(flux, dims, ground_truth)
+        flux, dims, ground_truth = _f32c(flux), _f32c(dims), _f32c(ground_truth)
+        if flux.dim() != 3 or dims.shape != (flux.shape[0], 2) or ground_truth.shape != flux.shape:
+            raise ValueError("flux and ground truth must be [B,Hh,W] and the target dimensions [B,2]")
+        B, Hh, W = flux.shape
+        loss = torch.empty((B,), dtype=torch.float32, device=dev)
+        record = torch.empty((B, 8), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_flux_crop_kl_loss_fwd(flux.data_ptr(), dims.data_ptr(), ground_truth.data_ptr(), B, Hh, W,
+                                                      float(crop_width), float(crop_height), loss.data_ptr(),
+                                                      record.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_flux_crop_kl_loss_fwd")
+        ctx.save_for_backward(flux, dims, ground_truth, record)
+        ctx.crop = (float(crop_width), float(crop_height))
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_loss):
+        flux, dims, ground_truth, record = ctx.saved_tensors
+        dev = flux.device
+        B, Hh, W = flux.shape
+        grad_loss = _f32c(grad_loss)
+        grad_flux = torch.empty_like(flux)
+        workspace = torch.empty((B * Hh * W + 5 * B,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_flux_crop_kl_loss_bwd(flux.data_ptr(), dims.data_ptr(), ground_truth.data_ptr(),
+                                                      record.data_ptr(), grad_loss.data_ptr(), B, Hh, W, *ctx.crop,
+                                                      grad_flux.data_ptr(), workspace.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_flux_crop_kl_loss_bwd")
+        return grad_flux, None, None, None, None
+
+
+def crop_and_kl_loss(flux_distributions: torch.Tensor, solar_tower, target_area_indices: torch.Tensor,
+                     ground_truth: torch.Tensor, crop_width: float = 6, crop_height: float = 6) -> torch.Tensor:
+    """Per-sample KL divergence of the flux cropped around its centre of mass against the measured (cropped) flux
+    (artist/flux/bitmap.py:121-246 + artist/optim/loss.py:321-410) in one fused pass."""
+    dims = target_dimensions(solar_tower, target_area_indices.to(flux_distributions.device))
+    return FluxCropKLLoss.apply(flux_distributions, dims, ground_truth, crop_width, crop_height)
+
+
+class _CenterOfMass(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bitmaps):
+        dev = _require_cuda(bitmaps)
+        bitmaps = _f32c(bitmaps)
+        if bitmaps.dim() != 3:
+            raise ValueError("bitmaps must be [number_of_active_heliostats, bitmap_resolution_u, bitmap_resolution_e]")
+        B, Hh, W = bitmaps.shape
+        com = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_flux_center_of_mass(bitmaps.data_ptr(), B, Hh, W, com.data_ptr(), _stream(dev))
+        _lib.check(rc, "art_flux_center_of_mass")
+        ctx.save_for_backward(com)
+        ctx.shape = (B, Hh, W)
+        return com[:, :2]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_com):
+        (com,) = ctx.saved_tensors
+        B, Hh, W = ctx.shape
+        dev = com.device
+        grad_com = _f32c(grad_com)
+        grad = torch.empty((B, Hh, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().art_flux_center_of_mass_bwd(com.data_ptr(), grad_com.data_ptr(), B, Hh, W, grad.data_ptr(),
+                                                        _stream(dev))
+        _lib.check(rc, "art_flux_center_of_mass_bwd")
+        return grad
+
+
+def get_center_of_mass(bitmaps: torch.Tensor, device: torch.device | None = None) -> torch.Tensor:
+    """Bitmap coordinates ``[B,2]`` = (e pixel, u pixel) of each bitmap's centre of mass; (0, 0) for an empty bitmap
+    (artist/flux/bitmap.py:12-71).  One streaming pass (``art_flux_center_of_mass``); differentiable."""
+    if device is not None:
+        bitmaps = bitmaps.to(device)
+    return _CenterOfMass.apply(bitmaps)
+
+
+def bitmap_coordinates_to_target_coordinates(bitmap_coordinates: torch.Tensor, bitmap_resolution, solar_tower,
+                                             target_area_indices: torch.Tensor, device: torch.device | None = None) -> torch.Tensor:
+    """Pixel coordinates (e, u) -> homogeneous world coordinates ``[B,4]`` on the target surface
+    (artist/geometry/coordinates.py:119-249): planar areas linearly, cylindrical ones over angle and height; pixel centres,
+    e axis flipped.  ``[B]``-sized arithmetic on the host side of the op (torch, differentiable); unlike the reference no
+    branch reads a device tensor, so nothing here waits for the device."""
+    from .raytracing import target_area_counts
+    bc = bitmap_coordinates if device is None else bitmap_coordinates.to(device)
+    dev, dt = bc.device, bc.dtype
+    width, height = float(bitmap_resolution[0]), float(bitmap_resolution[1])
+    e_norm = (bc[:, 0] + 0.5) / width
+    u_norm = (bc[:, 1] + 0.5) / height
+    n_planar, n_cyl = target_area_counts(solar_tower)
+    tix = target_area_indices.to(dev).long()
+    out3 = torch.zeros((bc.shape[0], 3), dtype=dt, device=dev)
+    if n_planar > 0:
+        planar = solar_tower.target_areas[0]
+        pi_ = tix.clamp(0, n_planar - 1)
+        centers, dims = planar.centers.to(dev, dt)[pi_][:, :3], planar.dimensions.to(dev, dt)[pi_]
+        e_local, u_local = (0.5 - e_norm) * dims[:, 0], (0.5 - u_norm) * dims[:, 1]
+        on_plane = centers + e_local[:, None] * torch.tensor([1.0, 0.0, 0.0], dtype=dt, device=dev) \
+            + u_local[:, None] * torch.tensor([0.0, 0.0, 1.0], dtype=dt, device=dev)
+        out3 = torch.where((tix < n_planar)[:, None], on_plane, out3)
+    if n_cyl > 0:
+        cyl = solar_tower.target_areas[1]
+        ci = (tix - n_planar).clamp(0, n_cyl - 1)
+        centers, axes, normals = (t.to(dev, dt)[ci][:, :3] for t in (cyl.centers, cyl.axes, cyl.normals))
+        radii, heights, opening = (t.to(dev, dt).reshape(-1)[ci] for t in (cyl.radii, cyl.heights, cyl.opening_angles))
+        v = torch.cross(axes, normals, dim=-1)
+        theta, z = (e_norm - 0.5) * opening, (0.5 - u_norm) * heights
+        on_cyl = centers + radii[:, None] * torch.cos(theta)[:, None] * normals + radii[:, None] * torch.sin(theta)[:, None] * v \
+            + z[:, None] * axes
+        out3 = torch.where((tix >= n_planar)[:, None], on_cyl, out3)
+    return torch.cat((out3, torch.ones((bc.shape[0], 1), dtype=dt, device=dev)), dim=1)
+
+
+class FocalSpotLoss:
+    """Distance between the predicted and the ground-truth focal spot on the target area, per sample
+    (artist/optim/loss.py:124-250): centres of mass of both bitmaps (``get_center_of_mass``) mapped to world coordinates."""
+
+    def __init__(self, scenario) -> None:
+        self.loss_function = None
+        self.scenario = scenario
+
+    def __call__(self, prediction: torch.Tensor, ground_truth: torch.Tensor, **kwargs: Any) -> torch.Tensor:
+        expected_kwargs = ["device", "target_area_indices"]
+        errors = [f"Please add '{key}' as keyword argument." for key in expected_kwargs if key not in kwargs]
+        if errors:                                   # same message as artist/optim/loss.py:187-196
+            raise ValueError(f"The focal spot loss expects {expected_kwargs} as keyword arguments. " + " ".join(errors))
+        tower = self.scenario.solar_tower
+        resolution = (prediction.shape[2], prediction.shape[1])             # (width, height), loss.py:212-216
+        spots = [bitmap_coordinates_to_target_coordinates(get_center_of_mass(b), resolution, tower, kwargs["target_area_indices"])
+                 for b in (prediction, ground_truth)]
+        return torch.norm(spots[0][:, :3] - spots[1][:, :3], dim=1)
+
+
 def _check_reduction(kwargs: dict, what: str) -> None:
     if "reduction_dimensions" not in kwargs:          # same messages as artist/optim/loss.py:300-311, 376-383
         if what == "pixel":

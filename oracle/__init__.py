@@ -253,6 +253,61 @@ def kl_loss(pred, truth, grad_loss=None):
     return _loss("orc_kl_loss", pred, truth, grad_loss)
 
 
+def center_of_mass(bitmaps, grad_com=None):
+    """get_center_of_mass (artist/flux/bitmap.py:12-71) in numpy, the reference's operation order in the bitmaps' dtype:
+    normalise by (sum + 1e-8), then the first moments with pixel indices as coordinates.  Returns ``[B,2]`` = (e pixel,
+    u pixel); with ``grad_com [B,2]`` the gradient w.r.t. the bitmaps instead ((index - centre) / (sum + 1e-8))."""
+    dt = bitmaps.dtype
+    b, hh, w = bitmaps.shape
+    s = bitmaps.sum(axis=(1, 2), keepdims=True, dtype=dt) + dt.type(1e-8)                  # :46-53
+    normalized = bitmaps / s
+    e = np.linspace(0, w - 1, w, dtype=dt)[None, None, :]                                   # :55-61
+    u = np.linspace(0, hh - 1, hh, dtype=dt)[None, :, None]
+    com = np.stack([(e * normalized).sum(axis=(1, 2), dtype=dt), (u * normalized).sum(axis=(1, 2), dtype=dt)], axis=1)   # :64-71
+    if grad_com is None:
+        return com
+    g = np.asarray(grad_com, dt)
+    return (g[:, 0, None, None] * (e - com[:, 0, None, None]) + g[:, 1, None, None] * (u - com[:, 1, None, None])) / s
+
+
+def bitmap_to_target_coordinates(bitmap_coordinates, resolution, target_idx, centers, dims, cyl=None):
+    """bitmap_coordinates_to_target_coordinates (artist/geometry/coordinates.py:119-249): pixel (e, u) -> homogeneous world
+    coordinates on the target surface.  ``centers [T,4]``, ``dims [T,2]`` are the planar tables, ``cyl`` the dict of
+    ``cyl_tables``; global index, planar first.  ``resolution`` = (width, height)."""
+    bc = np.asarray(bitmap_coordinates)
+    dt = bc.dtype
+    out = np.zeros((bc.shape[0], 4), dt)
+    out[:, 3] = 1
+    e_norm = (bc[:, 0] + dt.type(0.5)) / dt.type(resolution[0])                             # :185-186
+    u_norm = (bc[:, 1] + dt.type(0.5)) / dt.type(resolution[1])
+    T = 0 if centers is None else centers.shape[0]
+    tix = np.asarray(target_idx)
+    for k in range(bc.shape[0]):
+        t = int(tix[k])
+        if t < T:                                                                             # :193-218
+            e_local = (dt.type(0.5) - e_norm[k]) * dims[t, 0]
+            u_local = (dt.type(0.5) - u_norm[k]) * dims[t, 1]
+            out[k, :3] = centers[t, :3] + e_local * np.array([1, 0, 0], dt) + u_local * np.array([0, 0, 1], dt)
+        else:                                                                                 # :220-247
+            c = t - T
+            axis, normal = cyl["axes"][c, :3].astype(dt), cyl["normals"][c, :3].astype(dt)
+            v = np.cross(axis, normal)
+            theta = (e_norm[k] - dt.type(0.5)) * dt.type(np.ravel(cyl["opening"])[c])
+            z = (dt.type(0.5) - u_norm[k]) * dt.type(np.ravel(cyl["heights"])[c])
+            r = dt.type(np.ravel(cyl["radii"])[c])
+            out[k, :3] = cyl["centers"][c, :3].astype(dt) + r * np.cos(theta) * normal + r * np.sin(theta) * v + z * axis
+    return out
+
+
+def focal_spot_loss(prediction, ground_truth, target_idx, centers, dims, cyl=None):
+    """FocalSpotLoss (artist/optim/loss.py:124-250): distance between the world positions of the two bitmaps' centres
+    of mass on their target area, per sample."""
+    res = (prediction.shape[2], prediction.shape[1])                                        # (width, height), :212-216
+    a = bitmap_to_target_coordinates(center_of_mass(prediction), res, target_idx, centers, dims, cyl)
+    b = bitmap_to_target_coordinates(center_of_mass(ground_truth), res, target_idx, centers, dims, cyl)
+    return np.linalg.norm(a[:, :3] - b[:, :3], axis=1).astype(prediction.dtype)               # :245-249
+
+
 def rigid_body_orientations(positions, rot_dev, trans_dev, act_nonopt, act_opt, offsets, incident=None, aim=None,
                             motor_positions=None, max_iter=4, min_eps=1e-4):
     """RigidBody.incident_ray_directions_to_orientations (artist/field/kinematics_rigid_body.py:540-634) when

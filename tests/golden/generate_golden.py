@@ -737,6 +737,22 @@ CONFIG1 = dict(n_heliostats=1, n_cp=(10, 10), degrees=(3, 3), n_eval=50, n_rays=
 CONFIG2 = dict(n_heliostats=1, n_cp=(10, 10), degrees=(3, 3), n_eval=50, n_rays=100, resolution=[256, 256], **RECEIVER)
 
 
+# More 1e6-ray pins of the north-star bound (one seed was a one-sample claim): another seed of the same heliostat, and an
+# off-axis heliostat under a slanted sun (oblique incidence on the receiver, asymmetric image).
+CONFIG2_SEED11 = dict(CONFIG2, seed=11)
+CONFIG2_OFFAXIS = dict(CONFIG2, seed=23, positions=[[40.0, 75.0, 0.0, 1.0]], incident=[[0.25, 0.9, -0.35, 0.0]])
+
+# A WELL-CONDITIONED cylinder through the reference (radius 25 m, mirrors ~40 m from the mantle: the quadratic cancels
+# ~10-fold, not the 400-fold of the 3 m test cylinders above), so that a tight tolerance on the cylinder arithmetic can be
+# asserted against reference output and not only against the restatement.
+CASES["wide_cyl"] = dict(
+    n_heliostats=3, n_cp=(6, 6), degrees=(3, 3), n_eval=16, n_rays=8, resolution=[192, 64], curvature=1e-3,
+    positions=[[-30.0, 60.0, 0.0, 1.0], [5.0, 75.0, 0.0, 1.0], [40.0, 55.0, 0.0, 1.0]],
+    target_centers=[[0.0, 0.0, 55.0, 1.0]], target_normals=[[0.0, 1.0, 0.0, 0.0]], target_dims=[[8.0, 8.0]],
+    cyl_centers=[[0.0, 0.0, 40.0, 1.0]], cyl_normals=[[0.0, 1.0, 0.0, 0.0]], cyl_axes=[[0.0, 0.0, 1.0, 0.0]],
+    cyl_radii=[25.0], cyl_heights=[12.0], cyl_opening=[2.6], target_idx=[1, 1, 1], extinction=0.1, reflectivity=0.9)
+
+
 def summarize_large(arrs, keep):
     return {k: v for k, v in arrs.items() if k in keep}
 
@@ -937,6 +953,100 @@ def known_answers():
     out.update(cropgrad_image=npy(img32), cropgrad_weights=npy(weights32), cropgrad_target_idx=np.asarray([0, 1, 0, 1]),
                cropgrad_dims=np.asarray([[3.0, 3.0]] * 4, np.float32), loss_ground_truth=npy(ground_truth32),
                loss_sample_weights=np.asarray([1.0, 2.0, 3.0, 4.0], np.float32))
+    # crop -> KLDivergenceLoss as ONE autograd chain (what the fused crop + KL pass replaces): loss per sample and the
+    # gradient w.r.t. the uncropped bitmaps, fp32 and fp64
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        torch.set_default_dtype(dtype)
+        img = (img32.to(dtype) + 0.01).clone().requires_grad_(True)
+        cropped = ref_bitmap.crop_flux_distributions_around_center(img, crop_tower(dtype), torch.tensor([0, 1, 0, 1]), device=CPU)
+        per_sample = KLDivergenceLoss()(cropped, ground_truth32.to(dtype), reduction_dimensions=(1, 2))
+        (per_sample * torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=dtype)).sum().backward()
+        out.update({f"cropkl_{tag}_loss": npy(per_sample), f"cropkl_{tag}_grad": npy(img.grad)})
+        torch.set_default_dtype(torch.float32)
+    out["cropkl_offset"] = np.float64(0.01)
+    # get_center_of_mass (artist/flux/bitmap.py:12-71) + FocalSpotLoss (artist/optim/loss.py:124-250):
+    #  * the inline known answers of tests/optim/test_loss_functions.py:130-170 (planar area of 2 m x 2 m, index 0),
+    #  * tests/geometry/test_coordinates.py:126-163 (bitmap -> target coordinates, two planar areas and a half cylinder),
+    #  * a random case on a tower with a planar area and a cylinder, with autograd gradients, fp32 and fp64.
+    from artist.optim.loss import FocalSpotLoss
+
+    class _Scn:          # FocalSpotLoss reads scenario.solar_tower only
+        def __init__(self, tower):
+            self.solar_tower = tower
+
+    def focal_tower(dtype, center):
+        planar = TowerTargetAreasPlanar(names=["multi_focus_tower"], centers=torch.tensor(center, dtype=dtype),
+                                        normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]], dtype=dtype),
+                                        dimensions=torch.tensor([[2.0, 2.0]], dtype=dtype))
+        cyl = TowerTargetAreasCylindrical(names=["receiver"], centers=torch.zeros(1, 4, dtype=dtype),
+                                          normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]], dtype=dtype),
+                                          axes=torch.tensor([[0.0, 0.0, 1.0, 0.0]], dtype=dtype),
+                                          radii=torch.tensor([1.0], dtype=dtype), heights=torch.tensor([3.0], dtype=dtype),
+                                          opening_angles=torch.tensor([3.0], dtype=dtype))
+        return SolarTower([planar, cyl], device=CPU)
+
+    focal_cases = [
+        (torch.ones((1, 2, 2)), [[0.0, 0.0, 0.0, 1.0]], torch.ones((1, 2, 2)), [0.0]),
+        (torch.ones((1, 2, 2)), [[1.5, 0.0, 0.0, 1.0]], torch.ones((1, 2, 2)), [0.0]),
+        (torch.ones((1, 2, 2)), [[0.0, 0.0, 0.0, 1.0]], torch.tensor([[[0.0, 1.0], [0.0, 0.0]]]), [0.7071]),
+    ]
+    for i, (pred, center, truth, expected) in enumerate(focal_cases):
+        got = FocalSpotLoss(_Scn(focal_tower(torch.float32, center)))(pred, truth, target_area_indices=torch.tensor([0]), device=CPU)
+        torch.testing.assert_close(got, torch.tensor(expected), atol=1e-5, rtol=1e-6)
+        out.update({f"focal{i}_prediction": npy(pred), f"focal{i}_center": np.asarray(center, np.float32),
+                    f"focal{i}_ground_truth": npy(truth), f"focal{i}_expected": np.asarray(expected, np.float32),
+                    f"focal{i}_reference": npy(got)})
+    out["focal_count"] = np.int64(i + 1)
+    from artist.geometry import coordinates as ref_coordinates
+
+    def coord_tower(dtype):
+        planar = TowerTargetAreasPlanar(names=["planar1", "planar2"],
+                                        centers=torch.tensor([[0.0, 0.0, 0.0, 1.0], [1.0, 0.0, 2.0, 1.0]], dtype=dtype),
+                                        normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]] * 2, dtype=dtype),
+                                        dimensions=torch.tensor([[6.0, 6.0], [2.0, 4.0]], dtype=dtype))
+        cyl = TowerTargetAreasCylindrical(names=["cylinder1"], centers=torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=dtype),
+                                          normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]], dtype=dtype),
+                                          axes=torch.tensor([[0.0, 0.0, 1.0, 0.0]], dtype=dtype),
+                                          radii=torch.tensor([2.0], dtype=dtype), heights=torch.tensor([6.0], dtype=dtype),
+                                          opening_angles=torch.tensor([3.141592653589793], dtype=dtype))
+        return SolarTower([planar, cyl], device=CPU)
+
+    coord_cases = [
+        ([[127.5, 127.5], [63.75, 255.0], [0.0, 0.0]], [0, 0, 1],
+         [[0.0, 0.0, 0.0, 1.0], [1.4941, 0.0, -2.9883, 1.0], [1.9961, 0.0, 3.9922, 1.0]]),
+        ([[127.5, 127.5], [127.5, 255.0], [0.0, 63.75]], [2, 2, 2],
+         [[0.0, 2.0, 0.0, 1.0], [0.0, 2.0, -2.9883, 1.0], [2.0, 0.0123, 1.4941, 1.0]]),
+        ([[255.0, 191.25], [255.0, 255.0]], [2, 0], [[-2.0, 0.0123, -1.4941, 1.0], [-2.9883, 0.0, -2.9883, 1.0]]),
+    ]
+    for i, (bc, tix, expected) in enumerate(coord_cases):
+        got = ref_coordinates.bitmap_coordinates_to_target_coordinates(
+            bitmap_coordinates=torch.tensor(bc), bitmap_resolution=torch.tensor([256, 256]), solar_tower=coord_tower(torch.float32),
+            target_area_indices=torch.tensor(tix), device=CPU)
+        torch.testing.assert_close(got, torch.tensor(expected), rtol=1e-4, atol=1e-4)
+        out.update({f"coord{i}_bitmap_coordinates": np.asarray(bc, np.float32), f"coord{i}_target_idx": np.asarray(tix),
+                    f"coord{i}_expected": np.asarray(expected, np.float32), f"coord{i}_reference": npy(got)})
+    out["coord_count"] = np.int64(i + 1)
+    g3 = torch.Generator().manual_seed(777)
+    com_img32 = torch.rand((5, 40, 56), generator=g3) ** 3
+    com_img32[1, :, 20:] = 0.0
+    com_img32[3] = 0.0                                    # empty bitmap: (0, 0) by the 1e-8 in the normalisation
+    focal_truth32 = torch.rand((5, 40, 56), generator=g3) ** 2
+    com_w32 = torch.rand((5, 2), generator=g3)
+    focal_tix = torch.tensor([0, 1, 2, 2, 1])
+    for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        torch.set_default_dtype(dtype)
+        img = com_img32.to(dtype).clone().requires_grad_(True)
+        com = ref_bitmap.get_center_of_mass(img, device=CPU)
+        (com * com_w32.to(dtype)).sum().backward()
+        out.update({f"com_{tag}": npy(com), f"com_{tag}_grad": npy(img.grad)})
+        img2 = (com_img32.to(dtype) + 0.02).clone().requires_grad_(True)
+        loss = FocalSpotLoss(_Scn(coord_tower(dtype)))(img2, focal_truth32.to(dtype), target_area_indices=focal_tix, device=CPU)
+        (loss * torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0], dtype=dtype)).sum().backward()
+        out.update({f"focalrand_{tag}_loss": npy(loss), f"focalrand_{tag}_grad": npy(img2.grad)})
+        torch.set_default_dtype(torch.float32)
+    out.update(com_image=npy(com_img32), com_weights=npy(com_w32), focalrand_ground_truth=npy(focal_truth32),
+               focalrand_target_idx=npy(focal_tix), focalrand_offset=np.float64(0.02),
+               focalrand_sample_weights=np.asarray([1.0, 2.0, 3.0, 4.0, 5.0], np.float32))
     # rotate_distortions: tests/geometry/test_transforms.py (test_distortion_rotations)
     tt = importlib.import_module("tests.geometry.test_transforms")
     k = 0
@@ -1027,7 +1137,8 @@ def main():
             "aligned_points", "aligned_normals", "incident", "target_idx", "target_centers", "target_normals",
             "target_dims", "resolution", "ray_magnitude", "extinction", "reflectivity", "n_rays", "seed", "covariance",
             "degrees", "eval_points_grid", "canting", "facet_translations", "nurbs_points", "nurbs_normals"}
-    for name, case in (("config1", CONFIG1), ("config2", CONFIG2)):
+    for name, case in (("config1", CONFIG1), ("config2", CONFIG2), ("config2_seed11", CONFIG2_SEED11),
+                       ("config2_offaxis", CONFIG2_OFFAXIS)):
         if only is not None and name not in only:
             continue
         arrs32, dist = run_case(name, case, with_grads=False, store_rays=False, dtype=torch.float32)
