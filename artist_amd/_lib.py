@@ -41,7 +41,7 @@ SIGNATURES = {
                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_dbl,
                       _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr],
-    "art_trace_bwd_scratch_floats": [_c_i64, _c_i64, _c_i64, _c_i64],
+    "art_trace_bwd_scratch_floats": [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64],
     "art_flux_crop_fwd": [_ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],
     "art_flux_crop_bwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr],
     "art_flux_loss": [_ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr],

@@ -431,7 +431,7 @@ constexpr float kBlockOffset = 0.05f;         // :220
 constexpr float kBlockEps = 1e-12f;           // :217
 constexpr float kBlockMargin = 0.026f;        // sigmoid(-1000 * 0.026) = 5e-12
 
-struct alignas(16) Prim {   // one blocking rectangle, 20 floats in LDS (five 128-bit reads)
+struct alignas(16) Prim {   // one blocking rectangle, 24 floats in LDS (six 128-bit reads)
     float c0x, c0y, c0z;     // corner 0
     float sux, suy, suz;     // span u = corner 1 - corner 0
     float svx, svy, svz;     // span v = corner 3 - corner 0
@@ -439,6 +439,8 @@ struct alignas(16) Prim {   // one blocking rectangle, 20 floats in LDS (five 12
     float suu, svv, suv;     // :333-335
     float det_safe;          // :338-339
     float cx, cy, cz, rho;   // bounding sphere of the rectangle + its soft edge (per-point culling)
+    float inv_det;           // RN(1 / det_safe) for div_const(): the two divisions of :340-345 in three instructions each
+    float pad0, pad1, pad2;
 };
 
 __device__ __forceinline__ Prim make_prim(const float* __restrict__ corners, const float* __restrict__ spans,
@@ -459,6 +461,8 @@ __device__ __forceinline__ Prim make_prim(const float* __restrict__ corners, con
     // half diagonals |su + sv| / 2 and |su - sv| / 2; the mask reaches 2.6 % of a span beyond the edges
     const float d1 = q.suu + q.svv + 2.0f * q.suv, d2 = q.suu + q.svv - 2.0f * q.suv;
     q.rho = 0.5f * sqrtf(fmaxf(fmaxf(d1, d2), 0.0f)) * 1.06f + 2e-3f;
+    q.inv_det = 1.0f / q.det_safe;
+    q.pad0 = q.pad1 = q.pad2 = 0.0f;
     return q;
 }
 
@@ -478,7 +482,13 @@ __device__ __forceinline__ bool soft_plane(const Prim& q, float ox, float oy, fl
     s.den = (rx * q.nx + ry * q.ny) + rz * q.nz;
     s.den_safe = fabsf(s.den) < kBlockEps ? (s.den >= 0.0f ? kBlockEps : -kBlockEps) : s.den;
     const float num = ((q.c0x - ox) * q.nx + (q.c0y - oy) * q.ny) + (q.c0z - oz) * q.nz;
+    // (the IEEE quotient without the generic sequence's range scaling: |den_safe| >= 1e-12 and |num| is a distance in
+    //  metres, so neither operand nor quotient leaves the normal range - bit-identical, see div_noscale)
+#ifdef ART_OLD_SOFT_DIV
     s.d = num / s.den_safe;
+#else
+    s.d = div_noscale(num, s.den_safe);
+#endif
     return s.d > kBlockOffset - kBlockMargin;
 }
 
@@ -488,8 +498,15 @@ __device__ __forceinline__ void soft_uv(const Prim& q, float ox, float oy, float
     s.offx = (ox + s.d * rx) - q.c0x; s.offy = (oy + s.d * ry) - q.c0y; s.offz = (oz + s.d * rz) - q.c0z;
     s.pu = (s.offx * q.sux + s.offy * q.suy) + s.offz * q.suz;
     s.pv = (s.offx * q.svx + s.offy * q.svy) + s.offz * q.svz;
+    // (division by a per-rectangle constant whose correctly rounded reciprocal is in the table: the IEEE quotient, bit for
+    //  bit, in three instructions - div_const)
+#ifdef ART_OLD_SOFT_DIV
     s.u = (s.pu * q.svv - s.pv * q.suv) / q.det_safe;
     s.v = (s.pv * q.suu - s.pu * q.suv) / q.det_safe;
+#else
+    s.u = div_const(s.pu * q.svv - s.pv * q.suv, q.det_safe, q.inv_det);
+    s.v = div_const(s.pv * q.suu - s.pu * q.suv, q.det_safe, q.inv_det);
+#endif
     // NaN coordinates (degenerate rectangle) fail the comparisons and are skipped; the reference would carry NaN
     s.near = in_front && s.u > -kBlockMargin && s.u < 1.0f + kBlockMargin && s.v > -kBlockMargin &&
              s.v < 1.0f + kBlockMargin;

@@ -56,6 +56,8 @@ struct TraceArgs {
     int split;                // 0, or which heliostats this launch owns when blocking is on: 1 unblocked (lean kernels), 2 blocked
     int pack_edge;            // lean backward kernel: 0, or the edge margin in 1/64 of the scatter pad (edge points are packed)
     int multipass_ratio;      // footprints above ratio x capacity are swept in several passes
+    int h_group, n_groups;    // forward, mode 1, few samples per point: an item is a group of h_group consecutive heliostats
+                              // (trace_fwd_item_field); 1: one heliostat per item row
     int win_sample;           // window phase on one evenly spaced point per thread (1) or on every point of the block (0)
     // Forward accumulation (windowed kernels): every bitmap pixel has a 64-bit FIXED-POINT accumulator in `accum`
     // ([n_maps,Hh,W], all zero on entry).  Window flushes, cell carries and stray rays add integers to it - integer
@@ -169,7 +171,7 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
     a.n_ptiles = (int)((P + kBlock - 1) / kBlock);
     a.facet_points = (int)P; a.blocks_per_facet = 1; a.pack_edge = 0; a.split = 0;
     a.accum = nullptr; a.ex_g = 0; a.scale_g = 1.0f; a.status = nullptr;
-    a.win_sample = 0;
+    a.win_sample = 0; a.h_group = 1; a.n_groups = 0;
     return true;
 }
 

@@ -248,53 +248,144 @@ __device__ __forceinline__ int window_sample_point(int p0, int p1)
     return p0 + (int)(((unsigned)threadIdx.x * (unsigned)(p1 - p0)) / blockDim.x);
 }
 
+// What the window phase collects per thread, wave and workgroup: the bounding box of the chief-ray hits, their first and
+// second moments, the hit-point travel per radian of scatter (ke / ku: metres along world E / U, |t| sqrt(1 + (r_E/a)^2) -
+// the footprint of an oblique beam is stretched by the obliquity along the projection of the ray only), the largest scatter
+// angle of the sample looked at and the largest squared length of a reflected direction.
+struct WindowStats {
+    float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, ke = 0.0f, ku = 0.0f, angmax = 0.0f;
+    float dmax2 = 0.0f, esum = 0.0f, usum = 0.0f, cnt = 0.0f, esq = 0.0f, usq = 0.0f;
+};
+
+// One surface point's chief ray (no scatter) and its first distortion sample (u, e) -> the thread's statistics.
+template <bool CYL>
+__device__ __forceinline__ void window_consume(WindowStats& w, const Plane& pl, const Cyl& cy, const float4 inc, const float4 o,
+                                               const float4 n, const float u, const float e)
+{
+    float4 d; float s;
+    reflect(inc, n, d, s);
+    w.dmax2 = fmaxf(w.dmax2, d.x * d.x + d.y * d.y + d.z * d.z);
+    bool valid; float hbe, hbu, hke, hku;
+    if constexpr (CYL) {
+        // chief ray on the cylinder; hit-point travel per radian ~ t / cos(incidence) along both axes
+        const CylPoint cp = cyl_point(cy, o);
+        const CylHit ch = cyl_hit(cy, cp, d.x, d.y, d.z);
+        valid = ch.ok; hbe = ch.be; hbu = ch.bu;
+        hke = hku = ch.t / fmaxf(ch.abi, 0.1f);
+    } else {
+        const float numer = plane_numer(pl, o);
+        const Hit hit = intersect(pl, o, numer, d.x, d.y, d.z);
+        valid = hit.valid; hbe = hit.be; hbu = hit.bu;
+        const float ia = 1.0f / hit.a, qe = d.x * ia, qu = d.z * ia;
+        hke = hit.t * sqrtf(1.0f + qe * qe);
+        hku = hit.t * sqrtf(1.0f + qu * qu);
+    }
+    if (valid) {
+        w.emin = fminf(w.emin, hbe); w.emax = fmaxf(w.emax, hbe);
+        w.umin = fminf(w.umin, hbu); w.umax = fmaxf(w.umax, hbu);
+        w.esum += hbe; w.usum += hbu; w.cnt += 1.0f;
+        w.esq += hbe * hbe; w.usq += hbu * hbu;
+        w.ke = fmaxf(w.ke, hke);
+        w.ku = fmaxf(w.ku, hku);
+    }
+    w.angmax = fmaxf(w.angmax, fmaxf(fabsf(u), fabsf(e)));
+}
+
+// Threads' statistics -> the workgroup's, valid in thread 0 (one __syncthreads inside; s_red is free for reuse after the
+// caller's next barrier).
+__device__ __forceinline__ void window_reduce(WindowStats& w, float (*s_red)[16])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    w.emin = wave_reduce<kMin>(w.emin); w.emax = wave_reduce<kMax>(w.emax); w.umin = wave_reduce<kMin>(w.umin); w.umax = wave_reduce<kMax>(w.umax);
+    w.ke = wave_reduce<kMax>(w.ke); w.ku = wave_reduce<kMax>(w.ku); w.angmax = wave_reduce<kMax>(w.angmax); w.dmax2 = wave_reduce<kMax>(w.dmax2);
+    w.esum = wave_reduce<kSum>(w.esum); w.usum = wave_reduce<kSum>(w.usum); w.cnt = wave_reduce<kSum>(w.cnt);
+    w.esq = wave_reduce<kSum>(w.esq); w.usq = wave_reduce<kSum>(w.usq);
+    if (lane == 0) {
+        s_red[8][wave] = w.esum; s_red[9][wave] = w.usum; s_red[10][wave] = w.cnt; s_red[11][wave] = w.esq; s_red[12][wave] = w.usq;
+        s_red[0][wave] = w.emin; s_red[1][wave] = w.emax; s_red[2][wave] = w.umin; s_red[3][wave] = w.umax;
+        s_red[4][wave] = w.ke; s_red[5][wave] = w.ku; s_red[6][wave] = w.angmax; s_red[7][wave] = w.dmax2;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // the (at most 16) wave partials sit in the lanes of DPP row 0: one row reduction per quantity
+        const bool has = lane < nwaves;
+        const int k = has ? lane : 0;
+        w.emin = row_reduce<kMin>(has ? s_red[0][k] : 3.0e38f); w.emax = row_reduce<kMax>(has ? s_red[1][k] : -3.0e38f);
+        w.umin = row_reduce<kMin>(has ? s_red[2][k] : 3.0e38f); w.umax = row_reduce<kMax>(has ? s_red[3][k] : -3.0e38f);
+        w.ke = row_reduce<kMax>(has ? s_red[4][k] : -3.0e38f); w.ku = row_reduce<kMax>(has ? s_red[5][k] : -3.0e38f);
+        w.angmax = row_reduce<kMax>(has ? s_red[6][k] : -3.0e38f); w.dmax2 = row_reduce<kMax>(has ? s_red[7][k] : -3.0e38f);
+        w.esum = row_reduce<kSum>(has ? s_red[8][k] : 0.0f); w.usum = row_reduce<kSum>(has ? s_red[9][k] : 0.0f);
+        w.cnt = row_reduce<kSum>(has ? s_red[10][k] : 0.0f); w.esq = row_reduce<kSum>(has ? s_red[11][k] : 0.0f);
+        w.usq = row_reduce<kSum>(has ? s_red[12][k] : 0.0f);
+    }
+}
+
+// The workgroup's statistics -> its window (thread 0).  ppm_e / ppm_u: pixels per metre on the receiver surface; pad_k: how
+// much of the largest scatter angle SEEN is kept as the pad (the sample looked at holds the extreme of a few thousand
+// draws, a little below what is worth keeping in the window: ~4.2 sigma).
+__device__ __forceinline__ Window window_decide(const TraceArgs& a, const WindowStats& w, const float ppm_e, const float ppm_u,
+                                                const float pad_k)
+{
+    // The cell unit is the SAME for every item of a launch - 2^(kCellShift) accumulator units, i.e. 2^-21 of 2^ex_g
+    // > |mag k_ext k_refl| - and a stray ray is rounded to it like a window ray (to_cell): a ray contributes the same
+    // integer whichever workgroup traces it and whether or not it meets a window, so the bitmap does not depend on
+    // the launch geometry.  |contribution| <= |k| |d| |m| (the scatter matrix is a rotation; cylinder: |d| ||R_xy||_F
+    // = sqrt 2 |d|), i.e. < 2^22 cell units for unit normals; a returning add copes with up to 2^31.
+    // (scale and shift are set even for an EMPTY window: its rays are all strays, and strays are rounded to the cell unit)
+    Window win = {0, 0, 0, 0, 0, 1, a.scale_g * (1.0f / (float)(1 << kCellShift)), kCellShift, 0, 0};
+    if (w.emax >= w.emin) {
+        // + 2 px for the bilinear footprint and rounding
+        const float pad_e = fminf(pad_k * w.angmax * w.ke * ppm_e + 2.0f, 32768.0f);
+        const float pad_u = fminf(pad_k * w.angmax * w.ku * ppm_u + 2.0f, 32768.0f);
+        int e0 = max((int)w.emin - (int)pad_e, 0), e1 = min((int)w.emax + 1 + (int)pad_e, a.W - 1);
+        int u0 = max((int)w.umin - (int)pad_u, 0), u1 = min((int)w.umax + 1 + (int)pad_u, a.Hh - 1);
+        int tw = e1 - e0 + 1, th = u1 - u0 + 1;
+        if ((int64_t)tw * th > a.tile_cap && (int64_t)tw * th <= (int64_t)a.tile_cap * a.multipass_ratio) {
+            // Too large, but by less than multipass_ratio: keep the densest part, centred on the mean
+            // chief-ray hit, and let the tails take the global-memory path.  A stray ray costs more than a
+            // window ray (scattered global atomics) while a second pass costs every ray 2x, so trimming
+            // wins as long as the tails hold a few percent of the rays - which a peaked (Gaussian-like) footprint does.
+            // Aspect ratio from the second moments of the chief-ray hits widened by the scatter pad
+            // (pad ~ 4.25 sigma of the sun shape): the window spans the same number of standard deviations
+            // along E and U, which minimises the stray fraction of a Gaussian-like footprint.
+            const float n1 = fmaxf(w.cnt, 1.0f);
+            const float me = w.esum / n1, mu = w.usum / n1;
+            const float se = sqrtf(fmaxf(w.esq / n1 - me * me, 0.0f) + (pad_e * pad_e) * (1.0f / 18.0f)) + 0.5f;
+            const float su = sqrtf(fmaxf(w.usq / n1 - mu * mu, 0.0f) + (pad_u * pad_u) * (1.0f / 18.0f)) + 0.5f;
+            const float kk = sqrtf((float)a.tile_cap / (se * su));
+            int tw2 = max(2, min(tw, (int)(kk * se)));
+            int th2 = max(2, min(th, a.tile_cap / tw2));
+            tw2 = max(2, min(tw, a.tile_cap / th2));             // hand back what the clamp on th freed
+            const int ce = (int)me, cu = (int)mu;
+            e0 = min(max(ce - tw2 / 2, e0), e0 + tw - tw2);
+            u0 = min(max(cu - th2 / 2, u0), u0 + th - th2);
+            tw = tw2; th = th2;
+        }
+        if (tw > a.tile_cap / 2) { e0 += (tw - a.tile_cap / 2) / 2; tw = a.tile_cap / 2; }   // absurdly wide bitmaps
+        win.e0 = e0; win.u0 = u0; win.tw = tw; win.th = th;
+        win.pad_e = (int)pad_e; win.pad_u = (int)pad_u;
+        // larger footprints (near, oblique heliostats) are swept in several passes over row bands
+        win.ths = min(th, a.tile_cap / tw);
+        win.npass = win.ths >= th ? 1 : (th - 1 + win.ths - 2) / (win.ths - 1);
+    }
+    return win;
+}
+
 template <bool INTERLEAVED, bool CYL>
 __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& pl, const Cyl& cy, const float4 inc,
                                                const float4* __restrict__ org, const float4* __restrict__ nrm,
                                                int p0, int p1, int64_t dbase, float (*s_red)[16], Window* s_win,
                                                const FirstPoint* first = nullptr)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    // ke / ku: metres of hit-point travel along world E / U per radian of scatter, |t| sqrt(1 + (r_E/a)^2):
-    // the footprint of an oblique beam is stretched by the obliquity along the projection of the ray only.
-    float emin = 3.0e38f, emax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, ke = 0.0f, ku = 0.0f, angmax = 0.0f;
-    float dmax2 = 0.0f, esum = 0.0f, usum = 0.0f, cnt = 0.0f, esq = 0.0f, usq = 0.0f;
+    const int tid = threadIdx.x;
+    WindowStats w;
     // One point per trip, the NEXT point's loads issued before the current one is worked on: a workgroup that owns
     // many points per thread (one sun sample per point at field scale: 10 trips) is otherwise a chain of exposed
     // HBM round trips (30 us of a 77 us workgroup, tools/timeline.sh).
-    auto consume = [&](const float4 o, const float4 n, const float u, const float e) {
-        float4 d; float s;
-        reflect(inc, n, d, s);
-        dmax2 = fmaxf(dmax2, d.x * d.x + d.y * d.y + d.z * d.z);
-        bool valid; float hbe, hbu, hke, hku;
-        if constexpr (CYL) {
-            // chief ray on the cylinder; hit-point travel per radian ~ t / cos(incidence) along both axes
-            const CylPoint cp = cyl_point(cy, o);
-            const CylHit ch = cyl_hit(cy, cp, d.x, d.y, d.z);
-            valid = ch.ok; hbe = ch.be; hbu = ch.bu;
-            hke = hku = ch.t / fmaxf(ch.abi, 0.1f);
-        } else {
-            const float numer = plane_numer(pl, o);
-            const Hit hit = intersect(pl, o, numer, d.x, d.y, d.z);
-            valid = hit.valid; hbe = hit.be; hbu = hit.bu;
-            const float ia = 1.0f / hit.a, qe = d.x * ia, qu = d.z * ia;
-            hke = hit.t * sqrtf(1.0f + qe * qe);
-            hku = hit.t * sqrtf(1.0f + qu * qu);
-        }
-        if (valid) {
-            emin = fminf(emin, hbe); emax = fmaxf(emax, hbe);
-            umin = fminf(umin, hbu); umax = fmaxf(umax, hbu);
-            esum += hbe; usum += hbu; cnt += 1.0f;
-            esq += hbe * hbe; usq += hbu * hbu;
-            ke = fmaxf(ke, hke);
-            ku = fmaxf(ku, hku);
-        }
-        angmax = fmaxf(angmax, fmaxf(fabsf(u), fabsf(e)));
-    };
+    // a.win_sample: the window is a guess that only affects speed, so a block with more points than threads takes ONE
+    // evenly spaced point per thread (window_sample_point) instead of walking all of them in dependent trips
+    const bool sampled = a.win_sample != 0 && p1 - p0 > (int)blockDim.x;
     {
-        // a.win_sample: the window is a guess that only affects speed, so a block with more points than threads takes ONE
-        // evenly spaced point per thread (window_sample_point) instead of walking all of them in dependent trips
-        const bool sampled = a.win_sample != 0 && p1 - p0 > (int)blockDim.x;
         int p = sampled ? window_sample_point(p0, p1) : p0 + tid;
         bool have = p < p1;
         float4 o = {0.0f, 0.0f, 0.0f, 1.0f}, n = {0.0f, 0.0f, 1.0f, 0.0f};
@@ -309,83 +400,18 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
             float4 o2 = o, n2 = n;
             float u2 = 0.0f, e2 = 0.0f;
             if (have_n) { o2 = org[pn]; n2 = nrm[pn]; load_dist<INTERLEAVED>(a, dbase + (int64_t)pn * a.sp, u2, e2); }
-            consume(o, n, u, e);
+            window_consume<CYL>(w, pl, cy, inc, o, n, u, e);
             o = o2; n = n2; u = u2; e = e2; p = pn; have = have_n;
         }
     }
-    emin = wave_reduce<kMin>(emin); emax = wave_reduce<kMax>(emax); umin = wave_reduce<kMin>(umin); umax = wave_reduce<kMax>(umax);
-    ke = wave_reduce<kMax>(ke); ku = wave_reduce<kMax>(ku); angmax = wave_reduce<kMax>(angmax); dmax2 = wave_reduce<kMax>(dmax2);
-    esum = wave_reduce<kSum>(esum); usum = wave_reduce<kSum>(usum); cnt = wave_reduce<kSum>(cnt);
-    esq = wave_reduce<kSum>(esq); usq = wave_reduce<kSum>(usq);
-    if (lane == 0) {
-        s_red[8][wave] = esum; s_red[9][wave] = usum; s_red[10][wave] = cnt; s_red[11][wave] = esq; s_red[12][wave] = usq;
-        s_red[0][wave] = emin; s_red[1][wave] = emax; s_red[2][wave] = umin; s_red[3][wave] = umax;
-        s_red[4][wave] = ke; s_red[5][wave] = ku; s_red[6][wave] = angmax; s_red[7][wave] = dmax2;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        // the (at most 16) wave partials sit in the lanes of DPP row 0: one row reduction per quantity
-        const bool has = lane < nwaves;
-        const int w = has ? lane : 0;
-        emin = row_reduce<kMin>(has ? s_red[0][w] : 3.0e38f); emax = row_reduce<kMax>(has ? s_red[1][w] : -3.0e38f);
-        umin = row_reduce<kMin>(has ? s_red[2][w] : 3.0e38f); umax = row_reduce<kMax>(has ? s_red[3][w] : -3.0e38f);
-        ke = row_reduce<kMax>(has ? s_red[4][w] : -3.0e38f); ku = row_reduce<kMax>(has ? s_red[5][w] : -3.0e38f);
-        angmax = row_reduce<kMax>(has ? s_red[6][w] : -3.0e38f); dmax2 = row_reduce<kMax>(has ? s_red[7][w] : -3.0e38f);
-        esum = row_reduce<kSum>(has ? s_red[8][w] : 0.0f); usum = row_reduce<kSum>(has ? s_red[9][w] : 0.0f);
-        cnt = row_reduce<kSum>(has ? s_red[10][w] : 0.0f); esq = row_reduce<kSum>(has ? s_red[11][w] : 0.0f);
-        usq = row_reduce<kSum>(has ? s_red[12][w] : 0.0f);
-    }
+    window_reduce(w, s_red);
     if (tid == 0) {
-        // The cell unit is the SAME for every item of a launch - 2^(kCellShift) accumulator units, i.e. 2^-21 of 2^ex_g
-        // > |mag k_ext k_refl| - and a stray ray is rounded to it like a window ray (to_cell): a ray contributes the same
-        // integer whichever workgroup traces it and whether or not it meets a window, so the bitmap does not depend on
-        // the launch geometry.  |contribution| <= |k| |d| |m| (the scatter matrix is a rotation; cylinder: |d| ||R_xy||_F
-        // = sqrt 2 |d|), i.e. < 2^22 cell units for unit normals; a returning add copes with up to 2^31.
-        // (scale and shift are set even for an EMPTY window: its rays are all strays, and strays are rounded to the cell unit)
-        Window win = {0, 0, 0, 0, 0, 1, a.scale_g * (1.0f / (float)(1 << kCellShift)), kCellShift, 0, 0};
-        if (emax >= emin) {
-            // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is
-            // worth keeping in the window (~4.2 sigma); +2 px for the bilinear footprint and rounding.
-            float ppm_e, ppm_u;   // pixels per metre on the receiver surface
-            if constexpr (CYL) { ppm_e = cy.wm1 / fabsf(cy.opening * sqrtf(cy.r2)); ppm_u = cy.hm1 / fabsf(cy.height); }
-            else { ppm_e = pl.wm1 / fabsf(pl.w); ppm_u = pl.hm1 / fabsf(pl.h); }
-            // (a sampled window phase sees the extreme of fewer draws: 1024 of 2500 points ~ 3.65 instead of 3.9 sigma)
-            const float pad_k = (a.win_sample != 0 && p1 - p0 > (int)blockDim.x) ? 1.15f * 1.06f : 1.15f;
-            const float pad_e = fminf(pad_k * angmax * ke * ppm_e + 2.0f, 32768.0f);
-            const float pad_u = fminf(pad_k * angmax * ku * ppm_u + 2.0f, 32768.0f);
-            int e0 = max((int)emin - (int)pad_e, 0), e1 = min((int)emax + 1 + (int)pad_e, a.W - 1);
-            int u0 = max((int)umin - (int)pad_u, 0), u1 = min((int)umax + 1 + (int)pad_u, a.Hh - 1);
-            int tw = e1 - e0 + 1, th = u1 - u0 + 1;
-            if ((int64_t)tw * th > a.tile_cap && (int64_t)tw * th <= (int64_t)a.tile_cap * a.multipass_ratio) {
-                // Too large, but by less than multipass_ratio (2): keep the densest part, centred on the mean
-                // chief-ray hit, and let the tails take the global-memory path.  A stray ray costs ~30x a
-                // window ray (scattered global atomics) while a second pass costs every ray 2x, so trimming
-                // wins as long as the tails hold less than a few percent of the rays - which a peaked
-                // (Gaussian-like) footprint does at <= 2x the capacity.
-                // Aspect ratio from the second moments of the chief-ray hits widened by the scatter pad
-                // (pad ~ 4.25 sigma of the sun shape): the window spans the same number of standard deviations
-                // along E and U, which minimises the stray fraction of a Gaussian-like footprint.
-                const float n1 = fmaxf(cnt, 1.0f);
-                const float me = esum / n1, mu = usum / n1;
-                const float se = sqrtf(fmaxf(esq / n1 - me * me, 0.0f) + (pad_e * pad_e) * (1.0f / 18.0f)) + 0.5f;
-                const float su = sqrtf(fmaxf(usq / n1 - mu * mu, 0.0f) + (pad_u * pad_u) * (1.0f / 18.0f)) + 0.5f;
-                const float kk = sqrtf((float)a.tile_cap / (se * su));
-                int tw2 = max(2, min(tw, (int)(kk * se)));
-                int th2 = max(2, min(th, a.tile_cap / tw2));
-                tw2 = max(2, min(tw, a.tile_cap / th2));             // hand back what the clamp on th freed
-                const int ce = (int)me, cu = (int)mu;
-                e0 = min(max(ce - tw2 / 2, e0), e0 + tw - tw2);
-                u0 = min(max(cu - th2 / 2, u0), u0 + th - th2);
-                tw = tw2; th = th2;
-            }
-            if (tw > a.tile_cap / 2) { e0 += (tw - a.tile_cap / 2) / 2; tw = a.tile_cap / 2; }   // absurdly wide bitmaps
-            win.e0 = e0; win.u0 = u0; win.tw = tw; win.th = th;
-            win.pad_e = (int)pad_e; win.pad_u = (int)pad_u;
-            // larger footprints (near, oblique heliostats) are swept in several passes over row bands
-            win.ths = min(th, a.tile_cap / tw);
-            win.npass = win.ths >= th ? 1 : (th - 1 + win.ths - 2) / (win.ths - 1);
-        }
-        *s_win = win;
+        float ppm_e, ppm_u;   // pixels per metre on the receiver surface
+        if constexpr (CYL) { ppm_e = cy.wm1 / fabsf(cy.opening * sqrtf(cy.r2)); ppm_u = cy.hm1 / fabsf(cy.height); }
+        else { ppm_e = pl.wm1 / fabsf(pl.w); ppm_u = pl.hm1 / fabsf(pl.h); }
+        // x1.15: the first sample's extreme (~3.7 sigma over 2 p_block draws) is a little below what is worth keeping in
+        // the window (~4.2 sigma); a sampled window phase sees the extreme of fewer draws (1024 of 2500 points: ~3.65 sigma)
+        *s_win = window_decide(a, w, ppm_e, ppm_u, sampled ? 1.15f * 1.06f : 1.15f);
     }
     __syncthreads();
 }
@@ -449,7 +475,8 @@ __device__ __forceinline__ void block_range(const TraceArgs& a, int pblock, int&
     p0 = f * a.facet_points + i * a.p_block;
     p1 = min(p0 + a.p_block, min((f + 1) * a.facet_points, a.P));
 }
-__device__ __forceinline__ int work_item_count(const TraceArgs& a) { return a.H * a.n_pblocks * a.n_rchunks; }
+// (a.h_group > 1: an item is a GROUP of consecutive heliostats - trace_fwd_item_field - and the queue holds a.n_groups rows)
+__device__ __forceinline__ int work_item_count(const TraceArgs& a) { return (a.h_group > 1 ? a.n_groups : a.H) * a.n_pblocks * a.n_rchunks; }
 // Longest items first: an item's cost grows with the distance between heliostat and target (wider image, more rays
 // beyond the window: 83 -> 115 us from the nearest to the farthest tenth of the metric field), and a queue that ends
 // with the long items ends with idle CUs.  Fields are usually listed row by row, so the cheap test is which END of the
@@ -525,7 +552,7 @@ __device__ __forceinline__ unsigned fetch_work_item(unsigned int* __restrict__ w
 {
     if (work_counter == nullptr) return 0u;
     const unsigned v = atomicAdd(work_counter, 1u);
-    if (v + 1u == (unsigned)(a.H * a.n_pblocks * a.n_rchunks)) __hip_atomic_store(work_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v + 1u == (unsigned)work_item_count(a)) __hip_atomic_store(work_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
 }
 
@@ -1192,6 +1219,194 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     if (tid < 2 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
+// --------------------------------------------------------------------------------------------
+// Field-scale prediction (BASELINE config 5: 10 000 heliostats x 10 000 points x ONE sun sample, all bitmaps summed per
+// target): with a handful of samples per point an item of one heliostat is 1e4 rays between a window build, a 158 KB clear
+// and a flush of ~36 000 non-zero cells - and in per-target mode every one of those flushes adds 64-bit integers onto the
+// SAME bitmap (3.6e8 atomics per launch at the memory side: 1.1 of the launch's 2.45 ms).  Here an item is a GROUP of
+// a.h_group consecutive heliostats: runs of heliostats aimed at the same planar target share ONE window - placed on the
+// union of their (sampled) chief-ray images - and flush it once.  Nothing else changes: the same ray body as
+// trace_fwd_item_lean, the same integers into the same accumulators (a ray contributes the same cell-unit integer whichever
+// window it meets or misses), so the bitmap is bit-identical to the ungrouped launch's
+// (tests/test_gpu_configs.py::test_field_groups_change_speed_only).  Mode 1, planar, no blocking, R < 8 samples per point,
+// whole heliostats per item (n_pblocks == n_rchunks == 1).  A footprint larger than the window is trimmed, never swept.
+// Each thread's NEXT point (origin, normal, first sample) is requested before the current one is traced: with one ray per
+// point the loop is otherwise a chain of exposed HBM round trips.
+// --------------------------------------------------------------------------------------------
+template <bool INTERLEAVED>
+__device__ __forceinline__ void trace_fwd_item_field(const TraceArgs& a, unsigned int* __restrict__ counts, const int group,
+                                                     unsigned int* __restrict__ work_counter, int* s_next)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned tile[];
+    __shared__ float s_red[13][16];
+    __shared__ Window s_win;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int g0 = group * a.h_group, g1 = min(g0 + a.h_group, a.H);
+    const int nr = a.R;
+    const float Wf = (float)a.W, Hf = (float)a.Hh;
+    const Cyl cy = {};
+    unsigned next_item = 0u;
+    bool fetched = false;
+    for (int hs = g0; hs < g1;) {
+        const int t = a.target_idx[hs];
+        // workgroup-uniform: a bad index (reported), a cylinder's or a blocked heliostat (another launch's)
+        if (!target_in_range(a, t) || t >= a.T || other_launch_owns(a, hs)) { ++hs; continue; }
+        int he = hs + 1;
+        while (he < g1 && a.target_idx[he] == t && !other_launch_owns(a, he)) ++he;      // the run that shares a window
+        const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+        unsigned long long* __restrict__ acc = a.accum + (int64_t)t * a.Hh * a.W;        // (mode 1: the target's accumulators)
+        // ---- phase 1: clear, then the window of the run (one evenly spaced point per thread and heliostat) ---------------
+        {
+            uint4* t4 = reinterpret_cast<uint4*>(tile);
+            for (int i = tid; i < a.tile_cap / 4; i += blockDim.x) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < 2) tile[a.tile_cap + tid] = 0u;
+        }
+        {
+            WindowStats w;
+            const int ps = a.P > (int)blockDim.x ? window_sample_point(0, a.P) : tid;
+            for (int hh = hs; hh < he; ++hh) {
+                if (ps < a.P) {
+                    float u, e;
+                    load_dist_row<INTERLEAVED>(a.dist_u + (int64_t)hh * a.sh, a.dist_e + (int64_t)hh * a.sh, ps * (int)a.sp, u, e);
+                    window_consume<false>(w, pl, cy, a.incident[hh], a.origins[(int64_t)hh * a.P + ps], a.normals[(int64_t)hh * a.P + ps], u, e);
+                }
+            }
+            window_reduce(w, s_red);
+            if (tid == 0) {
+                TraceArgs trimmed_only = a;                      // never swept in bands: trimmed to the window's capacity
+                trimmed_only.multipass_ratio = 1 << 20;
+                // the sample holds (he - hs) x blockDim draws: about the extreme a full block of the other kernels sees
+                s_win = window_decide(trimmed_only, w, pl.wm1 / fabsf(pl.w), pl.hm1 / fabsf(pl.h), 1.15f);
+                if (s_win.npass > 1) { s_win.th = s_win.ths; s_win.npass = 1; }     // (cannot happen with that ratio)
+            }
+            __syncthreads();
+        }
+        const Window win = s_win;
+        const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
+        const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
+        const float kS = kI * win.scale;
+        const float lds_base = (float)(unsigned)(size_t)(lds_u32*)tile;
+        const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
+        const unsigned twm2_bits = f32_bits((float)(win.tw - 2)), thm2_bits = f32_bits((float)(win.th - 2));
+        const unsigned tw4 = 4u * (unsigned)win.tw;
+        const unsigned long long win_ok = (win.tw >= 2 && win.th >= 2) ? ~0ull : 0ull;
+        const float addr_hi_f = lds_base + (float)(4 * (win.tw * (win.th - 2) + win.tw - 2));
+        // ---- phase 2: trace every heliostat of the run (the ray body of trace_fwd_item_lean) ---------------------------------
+        unsigned long long m_parked = 0ull;
+        float pk_be = 0.0f, pk_bu = 0.0f, pk_ah = 0.0f;
+        auto unpark = [&]() {
+            if ((m_parked >> lane) & 1ull) {
+                const float tbe = truncf(pk_be), tbu = truncf(pk_bu);
+                if ((tbe + 1.0f < Wf) && (tbu + 1.0f < Hf)) {
+                    const float che = pk_be - tbe, chu = pk_bu - tbu, cle = 1.0f - che, clu = 1.0f - chu;
+                    const float Is = fabsf(pk_ah) * kS;
+                    const float wa = chu * Is, wb = clu * Is;
+                    unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;
+                    unsigned long long* row_lo = row_hi + a.W;
+                    atomicAdd(row_hi, cell_to_accum(cle * wa)); atomicAdd(row_hi + 1, cell_to_accum(che * wa));
+                    atomicAdd(row_lo + 1, cell_to_accum(che * wb)); atomicAdd(row_lo, cell_to_accum(cle * wb));
+                }
+            }
+            m_parked = 0ull;
+        };
+        unsigned po1 = 0u, po2 = 0u, po3 = 0u, po4 = 0u, pq1 = 0u, pq2 = 0u, pq3 = 0u, pq4 = 0u;
+        float ptbe = 0.0f, ptbu = 0.0f;
+        for (int hh = hs; hh < he; ++hh) {
+            const float4 inc = a.incident[hh];
+            const float4* __restrict__ org = a.origins + (int64_t)hh * a.P;
+            const float4* __restrict__ nrm = a.normals + (int64_t)hh * a.P;
+            const float* __restrict__ row_u = a.dist_u + (int64_t)hh * a.sh;       // sample 0 of this heliostat (wave-uniform)
+            const float* __restrict__ row_e = a.dist_e + (int64_t)hh * a.sh;
+            unsigned n_valid = 0;
+            int p = tid;
+            float4 o = {0.0f, 0.0f, 0.0f, 1.0f}, n = {0.0f, 0.0f, 1.0f, 0.0f};
+            float u0 = 0.0f, e0 = 0.0f;
+            if (p < a.P) { o = org[p]; n = nrm[p]; load_dist_stream<INTERLEAVED>(row_u, row_e, p * (int)a.sp, u0, e0); }
+            while (p < a.P) {
+                const int pn = p + (int)blockDim.x;
+                float4 o2 = o, n2 = n;
+                float u2 = 0.0f, e2 = 0.0f;
+                if (pn < a.P) { o2 = org[pn]; n2 = nrm[pn]; load_dist_stream<INTERLEAVED>(row_u, row_e, pn * (int)a.sp, u2, e2); }
+                float4 d; float s;
+                reflect(inc, n, d, s);
+                const float numer = plane_numer(pl, o);
+                for (int r = 0; r < nr; ++r) {
+                    float u = u0, e = e0;
+                    if (r > 0) load_dist_stream<INTERLEAVED>(row_u + (int64_t)r * a.sr, row_e + (int64_t)r * a.sr, p * (int)a.sp, u, e);
+                    Rot m = make_rot_t<true>(e, u);
+                    if (__builtin_expect(wave_any(!(fabsf(u) + fabsf(e) <= kSmallAngle)), 0)) m = make_rot(e, u);
+                    float rx, ry, rz;
+                    scatter(m, d, rx, ry, rz);
+                    const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
+                    const unsigned long long m_front = ballot64(ah < 0.0f);
+                    const float tt = div_noscale(numer, ah);                           // :130-131 (back-facing: masked below)
+                    const float hx = o.x + rx * tt, hz = o.z + rz * tt;                // :133-136
+                    const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
+                    const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;    // :154-174
+                    const float be = pl.wm1 - be0;                                     // :195-197
+                    const float tbe = truncf(be), tbu = truncf(bu);                    // heliostat_ray_tracer.py:674-675
+                    const float che = be - tbe, chu = bu - tbu;                        // :694-700 (exact)
+                    const float cle = 1.0f - che, clu = 1.0f - chu;
+                    const float lef = tbe - e0f, luf = tbu - u0f;
+                    const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
+                    const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
+                    n_valid += __popcll(m_valid);
+                    const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
+                    const unsigned addr_lo = (unsigned)af;
+                    const unsigned addr_up = addr_lo + tw4;
+                    const float Is = select_or_zero(m_in, fabsf(ah) * kS);
+                    const float wa = chu * Is, wb = clu * Is;
+                    if (__builtin_expect(wave_any(((po1 | po2 | po3 | po4) >> 31) != 0u), 0)) {
+                        PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
+                        resolve_carries(ps, acc, a.W, a.Hh, win.shift);
+                    }
+                    pq1 = cvt_nearest_u32(cle * wa); pq2 = cvt_nearest_u32(che * wa);
+                    pq3 = cvt_nearest_u32(che * wb); pq4 = cvt_nearest_u32(cle * wb);
+                    ptbe = tbe; ptbu = tbu;
+                    lds_u32* up = (lds_u32*)(size_t)addr_up;
+                    lds_u32* lo = (lds_u32*)(size_t)addr_lo;
+                    po1 = __hip_atomic_fetch_add(up, pq1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    po2 = __hip_atomic_fetch_add(up + 1, pq2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    po3 = __hip_atomic_fetch_add(lo + 1, pq3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    po4 = __hip_atomic_fetch_add(lo, pq4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const unsigned long long m_out = m_valid & ~m_in;                  // strays park (see trace_fwd_item_lean)
+                    if (__builtin_expect(m_out != 0ull, 0)) {
+                        if (m_out & m_parked) unpark();
+                        pk_be = select_mask(m_out, be, pk_be); pk_bu = select_mask(m_out, bu, pk_bu); pk_ah = select_mask(m_out, ah, pk_ah);
+                        m_parked |= m_out;
+                    }
+                }
+                o = o2; n = n2; u0 = u2; e0 = e2; p = pn;
+            }
+            // this heliostat's ray counters (a valid ray carries intensity: one count serves both factors)
+            if (lane == 0 && n_valid != 0u) { atomicAdd(&counts[hh], n_valid); atomicAdd(&counts[a.H + hh], n_valid); }
+        }
+        {
+            PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
+            resolve_carries(ps, acc, a.W, a.Hh, win.shift);
+        }
+        if (m_parked != 0ull) unpark();
+        __syncthreads();
+        // the next work item is requested before the group's last flush and published after it
+        if (he >= g1 && tid == 0) { next_item = fetch_work_item(work_counter, a); fetched = true; }
+        // ---- phase 3: flush ------------------------------------------------------------------------
+        for (int row = wave; row < win.th; row += nwaves) {
+            unsigned long long* g = acc + (int64_t)(a.Hh - 1 - (win.u0 + row)) * a.W + win.e0;
+            const unsigned* trow = tile + row * win.tw;
+            for (int c = lane; c < win.tw; c += 64) {
+                const unsigned q = trow[c];
+                if (q != 0u) atomicAdd(g + c, (unsigned long long)q << win.shift);
+            }
+        }
+        __syncthreads();                 // flushed before the next run clears the tile
+        hs = he;
+    }
+    if (tid == 0) {
+        if (!fetched) next_item = fetch_work_item(work_counter, a);     // (the group ended with skipped heliostats)
+        *s_next = (int)(gridDim.x + next_item);
+    }
+}
+
 // Everything the forward kernel is launched with, as ONE argument: the persistent loop below re-reads what an item
 // needs from the kernarg segment instead of carrying it in registers.
 struct FwdLaunch { TraceArgs a; float* flux; unsigned int* counts; unsigned int* work_counter; };
@@ -1207,7 +1422,8 @@ constexpr bool kCylPersistentBwd = false;       // (measured neutral: 18.57 vs 1
 #endif
 constexpr int kLeanFwdThreads = ART_LEAN_FWD_THREADS;
 constexpr int kCylFwdThreads = 1024;             // (768: within the noise of the box, 512: 17 % slower)
-template <bool INTERLEAVED, bool CYL, bool BLOCKING, bool LEAN = false>
+// LEAN: 0 the generic item, 1 trace_fwd_item_lean, 2 trace_fwd_item_field (groups of heliostats, see there)
+template <bool INTERLEAVED, bool CYL, bool BLOCKING, int LEAN = 0>
 __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
     static_assert(!LEAN || (!CYL && !BLOCKING), "the lean ray body is the planar, non-blocking one");
@@ -1262,7 +1478,9 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 10
         const int item = __builtin_amdgcn_readfirstlane(s_next);
         __syncthreads();                                     // everybody has read s_next before this item overwrites it
         if (item >= work_item_count(L.a)) break;             // workgroup-uniform
-        if constexpr (LEAN)
+        if constexpr (LEAN == 2)
+            trace_fwd_item_field<INTERLEAVED>(L.a, L.counts, s_reverse != 0 ? work_item_count(L.a) - 1 - item : item, L.work_counter, &s_next);
+        else if constexpr (LEAN == 1)
             trace_fwd_item_lean<INTERLEAVED>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0), L.work_counter,
                                              &s_next);
         else
@@ -1412,28 +1630,36 @@ __global__ __launch_bounds__(kBlock) void trace_bwd_kernel(TraceArgs a, const fl
 // outside the window read global memory.  Gradients are accumulated per point in registers.
 // --------------------------------------------------------------------------------------------
 // Adjoint of the blocking mask for one ray of every lane: `near` = the rectangles whose mask the lane's ray entered
-// (0 for lanes without a gradient), g_sigma = dL/dsigma.  Ray-side gradients come back per lane; the rectangles'
-// gradients are accumulated in LDS (12 floats per candidate: corner 0, span u, span v, normal) and flushed once
-// per workgroup - few rays sit in the soft edge of a rectangle, so the LDS float atomics are off the common path.
+// (0 for lanes without a gradient), g_sigma = dL/dsigma.  Ray-side gradients come back per lane.
+// The RECTANGLES' gradients (12 floats per candidate: corner 0, span u, span v, normal) are summed in a fixed order, so that
+// they are bit-reproducible like everything else (round 2 added them to LDS doubles and then to the tables with float
+// atomics): the 64 lanes' contributions to one rectangle are reduced on the DPP network (a fixed tree), and the wave's
+// running sums live in REGISTERS - lanes 2k and 2k + 1 own rectangle k's components 0-5 and 6-11, six registers per lane
+// for the 32 candidates.  The waves' sums are combined in wave order at the end of the item (trace_bwd_item), the items'
+// in item order by reduce_prim_grads_kernel.  Few rays sit in the soft edge of a rectangle, so all of this is off the
+// common path: with up to four such rays in the wave their values go to the owner lanes ray by ray (v_readlane, lane
+// order), with more through twelve reductions on the DPP network - either way a fixed function of the data.
 // The function is a real call (eight inlined copies would not fit the instruction cache), so its interface is kept in
-// registers: the tables come as LDS pointers (a generic pointer costs a null check per access), the wave-uniform mask
-// goes back to an SGPR, the ray-side gradients return by value (references would go through scratch memory).
+// registers: the table comes as an LDS pointer (a generic pointer costs a null check per access), the wave-uniform mask
+// goes back to an SGPR, gradients and sums travel by value (references would go through scratch memory).
 struct RayGrad { float ox, oy, oz, rx, ry, rz; };
+struct PrimSums { float v[6]; };                      // this lane's share of the wave's rectangle gradients
+struct AdjointOut { RayGrad ray; PrimSums sums; };
 typedef const __attribute__((address_space(3))) Prim* LdsPrims;
-typedef __attribute__((address_space(3))) double* LdsDoubles;
-__device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsDoubles s_gprim, unsigned wave_mask, unsigned near,
-                                                           float ox, float oy, float oz, float rx, float ry, float rz,
-                                                           float g_sigma)
+__device__ __attribute__((noinline)) AdjointOut block_adjoint(LdsPrims prims, PrimSums sums, unsigned wave_mask, unsigned near,
+                                                              float ox, float oy, float oz, float rx, float ry, float rz,
+                                                              float g_sigma)
 {
-    RayGrad out = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    AdjointOut out = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sums};
+    const int lane = threadIdx.x & 63;
     for (unsigned m = __builtin_amdgcn_readfirstlane(wave_mask); m != 0u; m &= m - 1u) {
         const int k = __builtin_ctz(m);
         const bool on = (near >> k) & 1u;
         if (!wave_any(on)) continue;
         typedef float v4f __attribute__((ext_vector_type(4)));
-        static_assert(sizeof(Prim) == 5 * sizeof(v4f), "Prim is five 128-bit LDS reads");
+        static_assert(sizeof(Prim) == 6 * sizeof(v4f), "Prim is six 128-bit LDS reads");
         const __attribute__((address_space(3))) v4f* src = (const __attribute__((address_space(3))) v4f*)(prims + k);
-        const v4f words[5] = {src[0], src[1], src[2], src[3], src[4]};
+        const v4f words[6] = {src[0], src[1], src[2], src[3], src[4], src[5]};
         Prim q;
         __builtin_memcpy(&q, words, sizeof(Prim));
         SoftHit sh;
@@ -1444,21 +1670,40 @@ __device__ __attribute__((noinline)) RayGrad block_adjoint(LdsPrims prims, LdsDo
         SoftGrad g;
         soft_sigma_bwd(q, ox, oy, oz, rx, ry, rz, sh, sg, on ? g_sigma : 0.0f, g);
         if (on) {     // other lanes may hold non-finite intermediates: branch, do not multiply
-            out.ox += g.ox; out.oy += g.oy; out.oz += g.oz;
-            out.rx += g.rx; out.ry += g.ry; out.rz += g.rz;
-            LdsDoubles acc = s_gprim + 12 * k;
-#ifndef ART_ABLATE_NO_BLOCK_ATOMICS
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                __hip_atomic_fetch_add(acc + c, (double)g.c0[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + 3 + c, (double)g.su[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + 6 + c, (double)g.sv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(acc + 9 + c, (double)g.n[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-#else
-            acc[0] = g.c0[0] + g.su[1] + g.sv[2] + g.n[0];
-#endif
+            out.ray.ox += g.ox; out.ray.oy += g.oy; out.ray.oz += g.oz;
+            out.ray.rx += g.rx; out.ray.ry += g.ry; out.ray.rz += g.rz;
         }
+#ifndef ART_ABLATE_NO_BLOCK_ATOMICS
+        // (lanes without a gradient contribute exact zeros - selected, not multiplied)
+        const float part[12] = {on ? g.c0[0] : 0.f, on ? g.c0[1] : 0.f, on ? g.c0[2] : 0.f, on ? g.su[0] : 0.f, on ? g.su[1] : 0.f,
+                                on ? g.su[2] : 0.f, on ? g.sv[0] : 0.f, on ? g.sv[1] : 0.f, on ? g.sv[2] : 0.f, on ? g.n[0] : 0.f,
+                                on ? g.n[1] : 0.f, on ? g.n[2] : 0.f};
+        const bool lo = lane == 2 * k, hi = lane == 2 * k + 1;
+        const unsigned long long m_on = __builtin_amdgcn_ballot_w64(on);
+#ifdef ART_PRIM_TREE_ONLY
+        if (false) {
+#else
+        if (__popcll(m_on) <= 4) {
+#endif
+            // the usual case - one or two rays of the wave sit in this rectangle's soft edge: their twelve values are handed to
+            // the owner lanes one ray after the other, in lane order (v_readlane: no reduction network)
+            for (unsigned long long mm = m_on; mm != 0ull; mm &= mm - 1ull) {
+                const int src = __builtin_ctzll(mm);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const float a_lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[c]), src));
+                    const float a_hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[6 + c]), src));
+                    out.sums.v[c] += lo ? a_lo : (hi ? a_hi : 0.0f);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const float a_lo = wave_reduce<kSum>(part[c]), a_hi = wave_reduce<kSum>(part[6 + c]);   // wave-uniform
+                out.sums.v[c] += lo ? a_lo : (hi ? a_hi : 0.0f);
+            }
+        }
+#endif
     }
     return out;
 }
@@ -1484,8 +1729,7 @@ __device__ __forceinline__ void zero_block_gradients(const TraceArgs& a, const W
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
 __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* __restrict__ grad_flux,
                                                float4* __restrict__ grad_origins, float4* __restrict__ grad_normals,
-                                               float* __restrict__ g_corners, float* __restrict__ g_spans,
-                                               float* __restrict__ g_pnormals, const WorkItem item,
+                                               float* __restrict__ prim_slabs, const WorkItem item,
                                                unsigned int* __restrict__ work_counter, int* s_next)
 {
     extern __shared__ __attribute__((aligned(16))) float gtile[];
@@ -1508,7 +1752,13 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const int t = a.target_idx[h];
     const bool bad_target = !target_in_range(a, t);
     if (bad_target || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // workgroup-uniform: a bad index, or another launch owns this heliostat
-        if (bad_target) zero_block_gradients(a, item, grad_origins, grad_normals);
+        if (bad_target) {
+            zero_block_gradients(a, item, grad_origins, grad_normals);
+            if constexpr (BLOCKING) {                // ... and no rectangle gradients from this item either
+                float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
+                for (int c = tid; c < a.Cmax * 12; c += blockDim.x) slab[c] = 0.0f;
+            }
+        }
         if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
@@ -1539,6 +1789,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const Window win = s_win;
     ART_TIMELINE(2);
     unsigned next_item = 0u;
+    PrimSums prim_sums = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};               // this wave's rectangle gradients (see block_adjoint)
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);                       // first flat row of this pass
     const int pth = min(win.ths, win.u0 + win.th - pu0);
@@ -1591,7 +1842,12 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     const unsigned twm1 = (unsigned)max(win.tw - 1, 0), thm1 = (unsigned)max(pth - 1, 0), uthm1 = (unsigned)max(win.th - 1, 0);
     const int dummy = a.tile_cap;                    // two spare cells holding 0
-    for (int p = p0 + tid; p < p1; p += blockDim.x) {
+    // (blocking: a WAVE walks a trip as long as its first lane has a point - a lane beyond the block's end repeats the last
+    //  point with its gradients masked out - because the rectangle gradients are handed to fixed owner lanes of the whole
+    //  wave, block_adjoint; without blocking the loop ends lane by lane as before)
+    for (int pt = p0 + tid; (BLOCKING ? pt - lane : pt) < p1; pt += blockDim.x) {
+        const bool lane_live = pt < p1;
+        const int p = lane_live ? pt : p1 - 1;
         const float4 o = org[p];
         const float4 n = nrm[p];
         float4 d; float s;
@@ -1631,11 +1887,13 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
 #ifdef ART_ABLATE_NO_BLOCK_ADJ
                     const bool adj = false;
 #else
-                    const bool adj = near != 0u && g_keep != 0.0f && trans > 1e-30f;
+                    const bool adj = lane_live && near != 0u && g_keep != 0.0f && trans > 1e-30f;
 #endif
                     if (wave_any(adj)) {
-                        const RayGrad b = block_adjoint((LdsPrims)s_tab.prim, (LdsDoubles)s_tab.grad, wmask, adj ? near : 0u, o.x, o.y,
-                                                        o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+                        const AdjointOut ao = block_adjoint((LdsPrims)s_tab.prim, prim_sums, wmask, adj ? near : 0u, o.x, o.y,
+                                                            o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+                        prim_sums = ao.sums;
+                        const RayGrad b = ao.ray;
                         bgx += b.ox; bgy += b.oy; bgz += b.oz;
                         gdx += m.cu * b.rx + m.m10 * b.ry + m.m20 * b.rz;
                         gdy += m.m11 * b.ry + m.m21 * b.rz - m.su * b.rx;
@@ -1776,7 +2034,9 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
         const int64_t idx = (int64_t)h * a.P + p;
-        if (first) {
+        if (!lane_live) {
+            // (a padding lane of the blocking instantiation: nothing to store)
+        } else if (first) {
             grad_origins[idx] = go;
             grad_normals[idx] = gn;
         } else {                                      // this thread owns the point in every pass: plain add
@@ -1794,18 +2054,19 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
 #endif
   }
     if (win.npass < 1 && tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));   // (never: npass >= 1)
-    if constexpr (BLOCKING) {      // rectangle gradients of this workgroup -> the primitive tables
-        for (int c = tid; c < n_prims * 12; c += blockDim.x) {
-            const float v = (float)s_tab.grad[c];
-            if (v == 0.0f) continue;
-            const int64_t id = s_tab.id[c / 12];
-            const int part = (c % 12) / 3, comp = c % 3;
-            float* dst = part == 0 ? g_corners + 16 * id + comp                 // corner 0
-                       : part == 1 ? g_spans + 8 * id + comp                    // span u
-                       : part == 2 ? g_spans + 8 * id + 4 + comp                // span v
-                                   : g_pnormals + 4 * id + comp;
-            atomicAdd(dst, v);
+    if constexpr (BLOCKING) {
+        // The waves' rectangle gradients, added in WAVE ORDER (s_tab.grad[k * 12 + j]: lane 2k holds j = 0..5, lane 2k + 1
+        // j = 6..11, i.e. entry lane * 6 + c), then this item's slab [Cmax,12] of the caller's scratch: reduce_prim_grads_kernel
+        // adds the items' slabs in item order.  No atomics: the rectangle gradients are bit-reproducible.
+        for (int w = 0; w < nwaves; ++w) {
+            if (wave == w && lane < 2 * n_prims) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) s_tab.grad[lane * 6 + c] += (double)prim_sums.v[c];
+            }
+            __syncthreads();
         }
+        float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
+        for (int c = tid; c < n_prims * 12; c += blockDim.x) slab[c] = (float)s_tab.grad[c];
     }
 }
 
@@ -2099,8 +2360,7 @@ template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN 
 __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThreads : (LEAN ? kLeanBwdThreads : 1024))) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
                                                              float4* __restrict__ grad_normals,
-                                                             float* __restrict__ g_corners, float* __restrict__ g_spans,
-                                                             float* __restrict__ g_pnormals,
+                                                             float* __restrict__ prim_slabs,
                                                              unsigned int* __restrict__ work_counter)
 {
     __shared__ int s_next;
@@ -2117,8 +2377,8 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
                 item = hk * per + item % per;
             }
         }
-        trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
-                                                               g_pnormals, decode_work_item(a, item), nullptr, &s_next);
+        trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, prim_slabs,
+                                                               decode_work_item(a, item), nullptr, &s_next);
         return;
     }
     const bool reverse = a.reverse_bwd != 0;
@@ -2127,8 +2387,8 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
             trace_bwd_item_lean<INTERLEAVED, ATOMIC_OUT>(a, grad_flux, grad_origins, grad_normals, decode_work_item(a, item, reverse),
                                                          work_counter, &s_next);
         else
-            trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, g_corners, g_spans,
-                                                                   g_pnormals, decode_work_item(a, item, reverse), work_counter, &s_next);
+            trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, prim_slabs,
+                                                                   decode_work_item(a, item, reverse), work_counter, &s_next);
         __syncthreads();
         item = __builtin_amdgcn_readfirstlane(s_next);       // wave-uniform by construction: say so (the item's fields then live in SGPRs)
         __syncthreads();
@@ -2149,6 +2409,47 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float4* __rest
         sn.x += b.x; sn.y += b.y; sn.z += b.z; sn.w += b.w;
     }
     out_o[i] = so; out_n[i] = sn;
+}
+
+// Rectangle gradients: the items' slabs -> the three gradient tables, every element written (zeros where nothing flows: a
+// rectangle nobody's rays met, corners 1-3, the w components).  One workgroup per rectangle k; thread t looks at the
+// heliostats h = t, t + 256, ... (their candidate lists, <= Cmax entries each), adds the slabs of h's items in item order,
+// and the 256 partial sums are added in thread order by a fixed tree: bit-reproducible.  A heliostat whose list is empty
+// (the lean launch of a split call traced it) or overflowed beyond Cmax (truncated; reported) contributes its first
+// min(count, Cmax) candidates like the kernels that filled the slabs.
+__global__ __launch_bounds__(256) void reduce_prim_grads_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ cand,
+                                                                const int32_t* __restrict__ cand_count, int H, int Cmax,
+                                                                int items_per_heliostat, float* __restrict__ g_corners,
+                                                                float* __restrict__ g_spans, float* __restrict__ g_pnormals)
+{
+    __shared__ float s_part[256][13];              // (+1: no bank conflicts in the tree)
+    const int k = blockIdx.x, tid = threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = 0.0f;
+    for (int h = tid; h < H; h += 256) {
+        const int nc = min(cand_count[h], Cmax);
+        for (int c = 0; c < nc; ++c) {
+            if (cand[(int64_t)h * Cmax + c] != k) continue;
+            for (int it = 0; it < items_per_heliostat; ++it) {
+                const float* __restrict__ v = slabs + (((int64_t)h * items_per_heliostat + it) * Cmax + c) * 12;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) acc[j] += v[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s_part[tid][j] = acc[j];
+    __syncthreads();
+    for (int half = 128; half > 0; half >>= 1) {
+        if (tid < half)
+#pragma unroll
+            for (int j = 0; j < 12; ++j) s_part[tid][j] += s_part[tid + half][j];
+        __syncthreads();
+    }
+    if (tid < 16) g_corners[16 * (int64_t)k + tid] = tid < 3 ? s_part[0][tid] : 0.0f;                       // corner 0
+    if (tid < 8) g_spans[8 * (int64_t)k + tid] = (tid & 3) < 3 ? s_part[0][3 + 3 * (tid >> 2) + (tid & 3)] : 0.0f;   // span u, span v
+    if (tid < 4) g_pnormals[4 * (int64_t)k + tid] = tid < 3 ? s_part[0][9 + tid] : 0.0f;
 }
 
 // pixel accumulators -> fp32 bitmap (one rounding per pixel), and the accumulators are left zero for the next call.
@@ -2550,14 +2851,14 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                 hipStream_t lean_stream = stream;
                 if (ss != nullptr && ss->start()) { side.s = ss; lean_stream = ss->side; }
                 if (il_l) {
-                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true, false, false, true>),
+                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<true, false, false, 1>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                    hipLaunchKernelGGL((trace_fwd_lds_kernel<true, false, false, true>), dim3((unsigned)blocks_l), dim3(threads_l),
+                    hipLaunchKernelGGL((trace_fwd_lds_kernel<true, false, false, 1>), dim3((unsigned)blocks_l), dim3(threads_l),
                                        lds_l, lean_stream, launch);
                 } else {
-                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false, false, false, true>),
+                    ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<false, false, false, 1>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                    hipLaunchKernelGGL((trace_fwd_lds_kernel<false, false, false, true>), dim3((unsigned)blocks_l), dim3(threads_l),
+                    hipLaunchKernelGGL((trace_fwd_lds_kernel<false, false, false, 1>), dim3((unsigned)blocks_l), dim3(threads_l),
                                        lds_l, lean_stream, launch);
                 }
                 return ART_OK;
@@ -2579,10 +2880,30 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanFwdThreads;
         }
         window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
+        // Field-scale prediction (per-target bitmaps, a handful of samples per point, whole heliostats per item): items are
+        // GROUPS of consecutive heliostats that share a window and its flush (trace_fwd_item_field).  Group size by the round
+        // model of window_geometry: rounds x (rays per item + ~1.5e4 ray-equivalents per window build / clear / flush +
+        // ~1.5e3 per heliostat for its share of the window phase and its counters).
+        bool field_groups = false;
+        if (lean && T > 0 && Tc == 0 && mode == 1 && a.R < 8 && a.n_pblocks == 1 && a.n_rchunks == 1 && a.H > 1) {
+            int K = env_int("ARTIST_HIP_FIELD_GROUP", -1);                   // -1: chosen here; 0 / 1: off
+            if (K < 0) {
+                double best = 0.0;
+                K = 1;
+                for (int k = 1; k <= 32 && k <= a.H; ++k) {
+                    const int64_t groups = (a.H + k - 1) / k;
+                    const int64_t rounds = (groups + resident_workgroups() - 1) / resident_workgroups();
+                    const double cost = ((double)rounds + 0.5) * ((double)k * ((double)a.P * a.R + 1.5e3) + 1.5e4);
+                    if (k == 1 || cost < 0.97 * best) { best = cost; K = k; }
+                }
+            }
+            if (K > 1) { a.h_group = std::min(K, a.H); a.n_groups = (a.H + a.h_group - 1) / a.h_group; field_groups = true; }
+        }
         if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
-            fprintf(stderr, "art_trace_fwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
-                    a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean);
-        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
+            fprintf(stderr, "art_trace_fwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d group %d\n",
+                    a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean,
+                    a.h_group);
+        const int64_t items = (int64_t)(field_groups ? a.n_groups : a.H) * a.n_pblocks * a.n_rchunks;
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
 #ifdef ART_FWD_SINGLE_ITEM
@@ -2604,15 +2925,17 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         } while (0)
 #define ART_LAUNCH_FWD_TYPE(CY)                                                                                  \
         do {                                                                                                     \
-            if (il && blocking) ART_LAUNCH_FWD(true, CY, true, false);                                           \
-            else if (il) ART_LAUNCH_FWD(true, CY, false, false);                                                 \
-            else if (blocking) ART_LAUNCH_FWD(false, CY, true, false);                                           \
-            else ART_LAUNCH_FWD(false, CY, false, false);                                                        \
+            if (il && blocking) ART_LAUNCH_FWD(true, CY, true, 0);                                               \
+            else if (il) ART_LAUNCH_FWD(true, CY, false, 0);                                                     \
+            else if (blocking) ART_LAUNCH_FWD(false, CY, true, 0);                                               \
+            else ART_LAUNCH_FWD(false, CY, false, 0);                                                            \
         } while (0)
         const bool il = interleaved_layout(a);
         if (T > 0 && !planar_done) {
-            if (lean && il) ART_LAUNCH_FWD(true, false, false, true);
-            else if (lean) ART_LAUNCH_FWD(false, false, false, true);
+            if (lean && field_groups && il) ART_LAUNCH_FWD(true, false, false, 2);
+            else if (lean && field_groups) ART_LAUNCH_FWD(false, false, false, 2);
+            else if (lean && il) ART_LAUNCH_FWD(true, false, false, 1);
+            else if (lean) ART_LAUNCH_FWD(false, false, false, 1);
             else ART_LAUNCH_FWD_TYPE(false);
         }
         if (planar_done) a.split = 3;                // the cylinder launch of a mixed tower: cylinder heliostats first
@@ -2695,9 +3018,6 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         a.prim_corners = prim_corners; a.prim_spans = prim_spans; a.prim_normals = prim_normals;
         a.cand = cand; a.cand_count = cand_count; a.Cmax = (int)Cmax;
         set_cone(a, max_scatter_angle);
-        ART_HIP(hipMemsetAsync(grad_prim_corners, 0, sizeof(float) * 16 * N, stream));
-        ART_HIP(hipMemsetAsync(grad_prim_spans, 0, sizeof(float) * 8 * N, stream));
-        ART_HIP(hipMemsetAsync(grad_prim_normals, 0, sizeof(float) * 4 * N, stream));
     }
     float4* go = reinterpret_cast<float4*>(grad_origins);
     float4* gn = reinterpret_cast<float4*>(grad_normals);
@@ -2734,6 +3054,17 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             fprintf(stderr, "art_trace_bwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
                     a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean);
         const bool atomic_out = a.n_rchunks > 1;      // (round 1's name: today the chunks write slabs, nothing is atomic)
+        // Blocking: every item of the blocking launch leaves its rectangle gradients in a slab [Cmax,12] of the scratch buffer
+        // (behind the chunk slabs); reduce_prim_grads_kernel adds them in item order.
+        float* prim_slabs = nullptr;
+        if (blocking) {
+            const int64_t chunk_floats = atomic_out ? (int64_t)a.n_rchunks * H * P * 8 : 0;
+            const int64_t slab_floats = (int64_t)a.H * a.n_pblocks * a.n_rchunks * a.Cmax * 12;
+            if (grad_scratch == nullptr || (reinterpret_cast<uintptr_t>(grad_scratch) % 16) != 0 ||
+                grad_scratch_floats < chunk_floats + slab_floats)
+                return ART_EINVAL;                    // (art_trace_bwd_scratch_floats says how much)
+            prim_slabs = grad_scratch + chunk_floats;
+        }
         SideJoin side = {nullptr};                    // (joins `stream` when this scope is left, errors included)
         std::function<int()> launch_lean;
         // Blocking on: the heliostats with an empty candidate list take the lean kernel in a launch of their own (see
@@ -2777,14 +3108,12 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                         ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<true, false, false, false, true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
                         hipLaunchKernelGGL((trace_bwd_lds_kernel<true, false, false, false, true>), dim3((unsigned)blocks_l),
-                                           dim3(threads_l), lds_l, lean_stream, al, grad_flux, go, gn, grad_prim_corners,
-                                           grad_prim_spans, grad_prim_normals, wc);
+                                           dim3(threads_l), lds_l, lean_stream, al, grad_flux, go, gn, prim_slabs, wc);
                     } else {
                         ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<false, false, false, false, true>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
                         hipLaunchKernelGGL((trace_bwd_lds_kernel<false, false, false, false, true>), dim3((unsigned)blocks_l),
-                                           dim3(threads_l), lds_l, lean_stream, al, grad_flux, go, gn, grad_prim_corners,
-                                           grad_prim_spans, grad_prim_normals, wc);
+                                           dim3(threads_l), lds_l, lean_stream, al, grad_flux, go, gn, prim_slabs, wc);
                     }
                     return ART_OK;
                 };
@@ -2809,8 +3138,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             work_counter += CY ? 6 : 5;                       /* backward: planar / cylinder launch */          \
             hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL, LN>), dim3((unsigned)blocks),               \
                                dim3(std::min(cfg.block, CY ? kCylBwdThreads : (BL ? kBlockingBwdThreads : 1024))), lds, stream, a, grad_flux, \
-                               go, gn,                                                                           \
-                               grad_prim_corners, grad_prim_spans, grad_prim_normals, work_counter);             \
+                               go, gn, prim_slabs, work_counter);                                                \
         } while (0)
 #define ART_LAUNCH_BWD_BL(CY, BL, LN)                                                                            \
         do {                                                                                                     \
@@ -2842,6 +3170,12 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
 #undef ART_LAUNCH_BWD
         ART_HIP(hipGetLastError());
         if (launch_lean) { const int rc = launch_lean(); if (rc != ART_OK) return rc; }
+        if (blocking) {
+            if (side.s) { side.s->end(); side.s = nullptr; }        // (the lean launch wrote no slabs, but `stream` must own what follows)
+            hipLaunchKernelGGL(reduce_prim_grads_kernel, dim3((unsigned)N), dim3(256), 0, stream, prim_slabs, a.cand, a.cand_count, a.H,
+                               a.Cmax, a.n_pblocks * a.n_rchunks, grad_prim_corners, grad_prim_spans, grad_prim_normals);
+            ART_HIP(hipGetLastError());
+        }
         if (atomic_out) {
             const int64_t n = H * P;
             hipLaunchKernelGGL(reduce_chunks_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, go, gn, a.n_rchunks, n,
@@ -2860,24 +3194,26 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     return ART_OK;
 }
 
-extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points)
+extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t Cmax)
 {
-    if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26)) return 0;
+    if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || Cmax < 0 || Cmax > kMaxCand) return 0;
     TraceArgs a = {};
     a.H = (int)H; a.R = (int)R; a.P = (int)P;
     FwdConfig cfg = fwd_config();
     if (cfg.variant != 0) return 0;
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return 0;
     a.facet_points = (int)P; a.blocks_per_facet = 1;
-    window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+    window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);      // the generic kernels' geometry (cylinders, blocking)
     int64_t chunks = a.n_rchunks;
+    // blocking: one [Cmax,12] slab of rectangle gradients per item of the blocking launch
+    const int64_t prim_floats = Cmax > 0 ? (int64_t)H * a.n_pblocks * a.n_rchunks * Cmax * 12 : 0;
     cfg.block = kLeanBwdThreads;                   // the lean kernel's geometry (art_trace_bwd picks one of the two)
     cfg.exact_pblock = true;
     cfg.facet_points = (int)facet_points;
     if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
     window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
     chunks = std::max<int64_t>(chunks, a.n_rchunks);
-    return chunks > 1 ? chunks * H * P * 8 : 0;
+    return (chunks > 1 ? chunks * H * P * 8 : 0) + prim_floats;
 }
 
 extern "C" int art_per_target_sum(const float* bitmaps, const int32_t* target_idx, int64_t H, int64_t T,

@@ -280,7 +280,7 @@ class TraceRays(torch.autograd.Function):
         g_pc = g_ps = g_pn = None
         if block_tabs:
             g_pc, g_ps, g_pn = (torch.empty_like(t) for t in block_tabs[:3])
-        n_scratch = int(_lib.lib().art_trace_bwd_scratch_floats(H, R, P, points_per_facet))
+        n_scratch = int(_lib.lib().art_trace_bwd_scratch_floats(H, R, P, points_per_facet, Cmax if block_tabs else 0))
         scratch = torch.empty((n_scratch,), dtype=torch.float32, device=dev) if n_scratch else None
         with torch.cuda.device(dev):
             rc = _lib.lib().art_trace_bwd(

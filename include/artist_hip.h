@@ -138,7 +138,7 @@ int art_async_status(void *stream, int clear);
  *   grad_origins, grad_normals   outputs [H,P,4] (w components 0 / as autograd gives them)
  *   grad_scratch, grad_scratch_floats   see art_trace_bwd_scratch_floats
  *   grad_prim_corners [N,4,4], grad_prim_spans [N,2,4], grad_prim_normals [N,4]   (blocking only; fully
- *                 written) DIRECT gradients of the soft mask w.r.t. the rectangle tables - corner 0, both spans,
+ *                 written, in a fixed summation order) DIRECT gradients of the soft mask w.r.t. the rectangle tables - corner 0, both spans,
  *                 the normal; the caller chains them through whatever built the tables (blocking.py:170-207)
  * ------------------------------------------------------------------------------------------- */
 int art_trace_bwd(const float *origins, const float *normals, const float *incident,
@@ -154,11 +154,14 @@ int art_trace_bwd(const float *origins, const float *normals, const float *incid
                   float *grad_prim_spans, float *grad_prim_normals, float *grad_scratch, int64_t grad_scratch_floats,
                   void *stream);
 
-/* Scratch of art_trace_bwd in floats (0 for fields that fill the chip without cutting a point's samples into chunks).
- * With a 16-byte aligned buffer of at least this size the chunks' partial gradients are written to slabs and added in
- * chunk order - bit-reproducible gradients; with NULL (or less) the samples of a point stay in one work item, which is
- * reproducible too but leaves most of the chip idle on a field of a few heliostats. */
-int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points);
+/* Scratch of art_trace_bwd in floats.  Without blocking (Cmax = 0): 0 for fields that fill the chip without cutting a
+ * point's samples into chunks; with a 16-byte aligned buffer of at least this size the chunks' partial gradients are
+ * written to slabs and added in chunk order - bit-reproducible gradients; with NULL (or less) the samples of a point stay
+ * in one work item, which is reproducible too but leaves most of the chip idle on a field of a few heliostats.
+ * With blocking (Cmax = the capacity passed to art_blocking_filter) the buffer is REQUIRED: every work item leaves its
+ * rectangle gradients in a [Cmax,12] slab and a last kernel adds the slabs in item order - the rectangle gradients are
+ * bit-reproducible as well (no float atomics anywhere in the trace kernels). */
+int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t Cmax);
 
 /* ---------------------------------------------------------------------------------------------
  * art_blocking_filter - lbvh_filter_blocking_planes (artist/raytracing/blocking.py:832-995, with the tree of

@@ -75,11 +75,12 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
         _lib.lib()
 
 
-def test_no_float_atomics_in_the_planar_trace_kernels(tmp_path):
-    """Determinism by construction: the device code of libartist_hip.so holds no `global_atomic_add_f32`
-    in any trace kernel that serves planar receivers without blocking - flux goes through 64-bit integer accumulators,
-    gradients through plain stores and chunk slabs.  (The blocking instantiations still flush the rectangle gradients with
-    one float atomic per workgroup and component; the cylinder instantiations share the planar code paths.)"""
+def test_no_float_atomics_in_any_trace_kernel(tmp_path):
+    """Determinism by construction: the device code of libartist_hip.so holds no float atomic - neither
+    `global_atomic_add_f32` nor an LDS `ds_add_f32` / `ds_add_f64` (`ds_add_rtn_*` likewise) - in ANY trace kernel, planar
+    or cylindrical, blocking on or off: flux goes through 64-bit integer accumulators, gradients through plain stores and
+    chunk slabs, and the rectangle gradients of the blocking backward through wave reductions and item slabs (round 2
+    still flushed those with float atomics)."""
     import shutil
     import subprocess
     llvm = pathlib.Path("/opt/rocm/lib/llvm/bin")
@@ -108,12 +109,8 @@ def test_no_float_atomics_in_the_planar_trace_kernels(tmp_path):
             if m:
                 current = m.group(1)
                 seen_trace |= "trace_fwd_lds_kernel" in current
-            elif "global_atomic_add_f32" in line and current:
+            elif current and re.search(r"global_atomic_(add|pk_add)_f(32|64)|ds_(add|pk_add)(_rtn)?_f(32|64)", line):
                 per_kernel[current] = per_kernel.get(current, 0) + 1
     assert seen_trace, "trace kernels not found in the device code"
-    # template arguments: trace_fwd_lds_kernel<IL, CYL, BLOCKING, LEAN>, trace_bwd_lds_kernel<IL, SLABS, CYL, BLOCKING, LEAN>
-    def blocking(name):
-        m = re.search(r"trace_fwd_lds_kernelILb\dELb\dELb(\d)", name) or re.search(r"trace_bwd_lds_kernelILb\dELb\dELb\dELb(\d)", name)
-        return bool(m) and m.group(1) == "1"
-    offenders = {k: v for k, v in per_kernel.items() if "trace_" in k and not blocking(k)}
+    offenders = {k: v for k, v in per_kernel.items() if "trace_" in k or "reduce_prim" in k or "reduce_chunks" in k}
     assert not offenders, offenders

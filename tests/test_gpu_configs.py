@@ -202,3 +202,68 @@ def test_reconstruction_epoch_forward_and_control_point_gradients(H, R, n_cp, la
     flux_rt, *_ = rt.trace_rays(inc, mask, tix)
     del rt
     check_invariants(scenario, group, mask, tix, inc, flux_rt, fused, 1, label)
+
+
+def test_field_groups_change_speed_only(monkeypatch):
+    """Field-scale prediction (per-target bitmaps, a few samples per point) groups consecutive heliostats into one work
+    item that shares a window and its flush (trace_fwd_item_field).  The grouping is a launch geometry like any other: the
+    bitmaps and the ray counters are the same BITS with groups of any size, without groups, and as the segment sum's
+    inputs - on a field with two targets in runs of irregular length, a run that crosses group borders, two heliostats
+    that miss everything and one with a stale target index (skipped, reported)."""
+    from artist_amd import ops
+    from artist_amd.scene import build_synthetic_scenario
+    H, R = 700, 2
+    scenario, _ = build_synthetic_scenario(H, n_rays=R, n_cp=(6, 6), n_eval=16, device=DEV,
+                                           target_centers=((0.0, 0.0, 55.0, 1.0), (3.0, 0.0, 48.0, 1.0)),
+                                           target_normals=((0.0, 1.0, 0.0, 0.0), (0.0, 1.0, 0.0, 0.0)), target_dims=((8.0, 8.0), (6.0, 7.0)))
+    group = scenario.heliostat_field.heliostat_groups[0]
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    group.activate_heliostats(mask)
+    gen = torch.Generator().manual_seed(5)
+    tix = torch.zeros(H, dtype=torch.long)
+    k = 0
+    while k < H:                                                   # runs of 1 .. 40 heliostats per target
+        run = int(torch.randint(1, 41, (1,), generator=gen))
+        tix[k:k + run] = int(torch.randint(0, 2, (1,), generator=gen))
+        k += run
+    tix = tix.to(DEV)
+    inc = torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=DEV).repeat(H, 1)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask)
+    points, normals = group.active_surface_points.clone(), group.active_surface_normals.clone()
+    up = torch.tensor([0.0, 0.0, 1.0, 0.0], device=DEV)            # two mirrors lying flat: the sun's rays go on northwards,
+    normals[17] = up                                               # away from the tower - no ray reaches a target
+    normals[400] = up
+    P = points.shape[1]
+    both = torch.randn((H, R, P, 2), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) * 2.09e-3
+    planar = scenario.solar_tower.target_areas[0]
+    args = (points, normals, inc, both[..., 0], both[..., 1], tix, planar.centers, planar.normals, planar.dimensions, 1.0, 0.0, 0.935,
+            (256, 256))
+
+    def run(env, target_idx=tix):
+        with monkeypatch.context() as m:
+            for key, value in env.items():
+                m.setenv(key, value)
+            flux, fac = ops.trace_rays(*args[:5], target_idx, *args[6:], per_target=True)
+            return n(flux), n(fac)
+
+    plain_flux, plain_fac = run({"ARTIST_HIP_FIELD_GROUP": "0"})
+    assert plain_flux.sum() > 0 and plain_fac[0, 17] == 0 and plain_fac[0, 400] == 0 and (plain_fac[0] > 0.5).sum() > H - 10
+    for env in ({}, {"ARTIST_HIP_FIELD_GROUP": "2"}, {"ARTIST_HIP_FIELD_GROUP": "7"}, {"ARTIST_HIP_FIELD_GROUP": "32"},
+                {"ARTIST_HIP_FIELD_GROUP": "13", "ARTIST_HIP_FWD_TILE_KB": "16"}):
+        flux, fac = run(env)
+        np.testing.assert_array_equal(flux, plain_flux, err_msg=str(env))
+        np.testing.assert_array_equal(fac, plain_fac, err_msg=str(env))
+    # ... and the per-heliostat bitmaps' segment sum agrees up to its fp32 additions
+    per_h, _ = ops.trace_rays(*args)
+    summed = n(ops.per_target_sum(per_h, tix, 2))
+    assert rel_l2(plain_flux, summed) < 1e-6
+    # a stale target index inside a group: that heliostat is skipped and reported, the others are untouched
+    bad = tix.clone()
+    bad[333] = 9
+    flux_bad, fac_bad = run({"ARTIST_HIP_FIELD_GROUP": "8"}, bad)
+    with pytest.raises(IndexError):
+        ops.check_async_errors(DEV)
+    one, fac_one = ops.trace_rays(*(a_[333:334] if isinstance(a_, torch.Tensor) and a_.shape[:1] == (H,) else a_ for a_ in args),
+                                  per_target=True)
+    assert fac_bad[0, 333] == 0 and np.array_equal(np.delete(fac_bad, 333, axis=1), np.delete(plain_fac, 333, axis=1))
+    assert rel_l2(flux_bad + n(one), plain_flux) < 1e-6

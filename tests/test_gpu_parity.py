@@ -1456,6 +1456,9 @@ def test_random_scenes_split_calls(seed, H, P, R, variant, monkeypatch):
     grads = oracle.trace_bwd(*oracle_args, f32(w), 0.7, 0.05, 0.9, **okw)
     go, gn = grads[0], grads[1]
     tol = 2e-5 if variant == "blocking_on_planes" else 2e-3
+    assert np.isfinite(go).all() and np.isfinite(gn).all(), "the oracle's gradients are not finite"
+    assert bool(torch.isfinite(o.grad).all()) and bool(torch.isfinite(nn_.grad).all()), \
+        ("non-finite HIP gradients in heliostats", np.nonzero(~np.isfinite(n(o.grad)).all(axis=(1, 2)))[0], n(tix))
     assert rel_l2(n(o.grad)[planar], go[planar]) < 2e-5, rel_l2(n(o.grad)[planar], go[planar])
     assert rel_l2(n(nn_.grad)[planar], gn[planar]) < 2e-5, rel_l2(n(nn_.grad)[planar], gn[planar])
     assert rel_l2(n(o.grad), go) < tol and rel_l2(n(nn_.grad), gn) < tol
@@ -1804,6 +1807,23 @@ def test_flux_is_bit_reproducible(golden, name):
     runs = [n(trace_rays(**inp)[0]) for _ in range(3)]
     np.testing.assert_array_equal(runs[0], runs[1])
     np.testing.assert_array_equal(runs[0], runs[2])
+    # ... and so do the gradients - with blocking on also those of the rectangle tables, which round 2 still added up with
+    # float atomics (wave reductions on the DPP network, wave order, item slabs added in item order: DESIGN.md 4.2b)
+    def grads():
+        leaves = [inp["origins"].clone().requires_grad_(True), inp["normals"].clone().requires_grad_(True)]
+        kw = dict(inp, origins=leaves[0], normals=leaves[1])
+        if name in BLOCKING_CASES:
+            blk = {k: (v.clone().requires_grad_(True) if k in ("corners", "spans", "normals") else v) for k, v in inp["blocking"].items()}
+            kw["blocking"] = blk
+            leaves += [blk["corners"], blk["spans"], blk["normals"]]
+        flux = trace_rays(**kw)[0]
+        return [n(g) for g in torch.autograd.grad(flux, leaves, t(d["loss_weights"]))]
+    g0, g1, g2 = grads(), grads(), grads()
+    for a_, b_, c_ in zip(g0, g1, g2):
+        np.testing.assert_array_equal(a_, b_)
+        np.testing.assert_array_equal(a_, c_)
+    if name in BLOCKING_CASES:
+        assert np.abs(g0[2]).sum() > 0 and np.abs(g0[4]).sum() > 0           # the rectangles do receive gradients
 
 
 def test_kinematics_reconstruction_loop_converges():
