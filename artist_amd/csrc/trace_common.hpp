@@ -58,6 +58,7 @@ struct TraceArgs {
     int multipass_ratio;      // footprints above ratio x capacity are swept in several passes
     int h_group, n_groups;    // forward, mode 1, few samples per point: an item is a group of h_group consecutive heliostats
                               // (trace_fwd_item_field); 1: one heliostat per item row
+    int tail_h, tail_bpf, tail_pblock, tail_npb;   // the queue's finer-grained end: see work_item_count / set_queue_tail
     int win_sample;           // window phase on one evenly spaced point per thread (1) or on every point of the block (0)
     // Forward accumulation (windowed kernels): every bitmap pixel has a 64-bit FIXED-POINT accumulator in `accum`
     // ([n_maps,Hh,W], all zero on entry).  Window flushes, cell carries and stray rays add integers to it - integer
@@ -172,6 +173,7 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
     a.facet_points = (int)P; a.blocks_per_facet = 1; a.pack_edge = 0; a.split = 0;
     a.accum = nullptr; a.ex_g = 0; a.scale_g = 1.0f; a.status = nullptr;
     a.win_sample = 0; a.h_group = 1; a.n_groups = 0;
+    a.tail_h = 0; a.tail_bpf = 1; a.tail_pblock = 0; a.tail_npb = 0;
     return true;
 }
 

@@ -456,7 +456,7 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
 //   * the eight XCDs share one queue (the hardware deals every eighth workgroup to an XCD, whatever their length),
 //     (Dealing the last items as two halves of their sample range, so that the kernel ends within half an item, measured
 //     neutral at 1000 and 125 heliostats in round 1 and needed float atomics in the backward kernel: removed.)
-struct WorkItem { int h, pblock, rchunk, r0, r1; };
+struct WorkItem { int h, pblock, rchunk, r0, r1; bool tail; };     // tail: an item of the queue's finer-grained end (see TraceArgs::tail_h)
 // Blocking on, but a heliostat none of whose rays can meet a rectangle (an empty candidate list - with the reference's tree
 // that is almost every heliostat) is traced by the LEAN kernels: the call then makes two launches that share the field,
 // a.split = 1 (lean: the unblocked heliostats) and 2 (blocking instantiation: the others).  Workgroup-uniform.
@@ -469,14 +469,21 @@ __device__ __forceinline__ bool other_launch_owns(const TraceArgs& a, int h)
 // Points [p0, p1) of point block `pblock`: blocks never straddle two facets (a.facet_points consecutive points - the
 // caller's facet size, a whole multiple of it when blocks are larger than a facet, or P when no facet structure is
 // known) - two facets' images are two blobs and one window serves them badly.
-__device__ __forceinline__ void block_range(const TraceArgs& a, int pblock, int& p0, int& p1)
+__device__ __forceinline__ void block_range(const TraceArgs& a, int pblock, int& p0, int& p1, bool tail = false)
 {
-    const int f = pblock / a.blocks_per_facet, i = pblock - f * a.blocks_per_facet;
-    p0 = f * a.facet_points + i * a.p_block;
-    p1 = min(p0 + a.p_block, min((f + 1) * a.facet_points, a.P));
+    const int bpf = tail ? a.tail_bpf : a.blocks_per_facet, pb = tail ? a.tail_pblock : a.p_block;
+    const int f = pblock / bpf, i = pblock - f * bpf;
+    p0 = f * a.facet_points + i * pb;
+    p1 = min(p0 + pb, min((f + 1) * a.facet_points, a.P));
 }
 // (a.h_group > 1: an item is a GROUP of consecutive heliostats - trace_fwd_item_field - and the queue holds a.n_groups rows)
-__device__ __forceinline__ int work_item_count(const TraceArgs& a) { return (a.h_group > 1 ? a.n_groups : a.H) * a.n_pblocks * a.n_rchunks; }
+// (a.tail_h > 0: the last a.tail_h heliostats of the queue are cut into a.tail_npb point blocks each instead of a.n_pblocks -
+//  the queue ends with smaller items, so that the CUs finish closer together; n_rchunks == 1 then)
+__device__ __forceinline__ int work_item_count(const TraceArgs& a)
+{
+    if (a.tail_h > 0) return (a.H - a.tail_h) * a.n_pblocks + a.tail_h * a.tail_npb;
+    return (a.h_group > 1 ? a.n_groups : a.H) * a.n_pblocks * a.n_rchunks;
+}
 // Longest items first: an item's cost grows with the distance between heliostat and target (wider image, more rays
 // beyond the window: 83 -> 115 us from the nearest to the farthest tenth of the metric field), and a queue that ends
 // with the long items ends with idle CUs.  Fields are usually listed row by row, so the cheap test is which END of the
@@ -498,6 +505,18 @@ __device__ __forceinline__ bool farther_end_is_last(const TraceArgs& a)
 
 __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int item, bool reverse = false)
 {
+    if (a.tail_h > 0) {
+        // queue order: the heliostats in list order (or, `reverse`, from the last to the first), whole samples per item; the
+        // queue's last a.tail_h heliostats in finer blocks
+        const int head_items = (a.H - a.tail_h) * a.n_pblocks;
+        WorkItem w;
+        int hq;
+        if (item < head_items) { hq = item / a.n_pblocks; w.pblock = item - hq * a.n_pblocks; w.tail = false; }
+        else { const int j = item - head_items; const int k = j / a.tail_npb; hq = a.H - a.tail_h + k; w.pblock = j - k * a.tail_npb; w.tail = true; }
+        w.h = reverse ? a.H - 1 - hq : hq;
+        w.rchunk = 0; w.r0 = 0; w.r1 = a.R;
+        return w;
+    }
     if (reverse) item = work_item_count(a) - 1 - item;
     const int base = item;
     WorkItem w;
@@ -507,6 +526,7 @@ __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int ite
     w.rchunk = rchunk;
     w.r0 = rchunk * a.r_chunk;
     w.r1 = min(w.r0 + a.r_chunk, a.R);
+    w.tail = false;
     return w;
 }
 
@@ -974,7 +994,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     unsigned long long* __restrict__ acc = a.accum + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;   // this bitmap's accumulators
     const float4 inc = a.incident[h];
     int p0, p1;
-    block_range(a, pblock, p0, p1);
+    block_range(a, pblock, p0, p1, item.tail);
     const int r0 = item.r0;
     const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
@@ -1019,8 +1039,8 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     // an empty window (no chief ray of the block reaches the target) holds no ray: every valid ray is then a stray
     const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
     // largest byte address a ray of this pass can produce for its LOW row; rays outside the window are clamped into
-    // [cell 0, that] and add zero there
-    const float addr_hi_f = lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2));
+    // [cell 0, that] and add zero there (an empty window: onto cell 0 - the tile is cleared, so that is a legal place too)
+    const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2)) : lds_base;
     unsigned n_valid = 0;
     if (!first) {
         const int npx = win.tw * pth;
@@ -1099,10 +1119,16 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
 #ifdef ART_ABLATE_NO_LDS_ATOMICS   // diagnostic build: keep the operands alive, skip the LDS traffic
             asm volatile("" ::"v"(up), "v"(lo), "v"(pq1), "v"(pq2), "v"(pq3), "v"(pq4));
 #else
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(ART_EXP_SETPRIO);
+#endif
             po1 = __hip_atomic_fetch_add(up, pq1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             po2 = __hip_atomic_fetch_add(up + 1, pq2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             po3 = __hip_atomic_fetch_add(lo + 1, pq3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             po4 = __hip_atomic_fetch_add(lo, pq4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
 #ifndef ART_ABLATE_NO_STRAYS       // diagnostic build drops the stray rays (wrong bitmap) to price them
             // Valid rays outside this pass's window: strays of the union window (or, when the footprint is swept in
@@ -1290,7 +1316,7 @@ __device__ __forceinline__ void trace_fwd_item_field(const TraceArgs& a, unsigne
         const unsigned twm2_bits = f32_bits((float)(win.tw - 2)), thm2_bits = f32_bits((float)(win.th - 2));
         const unsigned tw4 = 4u * (unsigned)win.tw;
         const unsigned long long win_ok = (win.tw >= 2 && win.th >= 2) ? ~0ull : 0ull;
-        const float addr_hi_f = lds_base + (float)(4 * (win.tw * (win.th - 2) + win.tw - 2));
+        const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (win.th - 2) + win.tw - 2)) : lds_base;
         // ---- phase 2: trace every heliostat of the run (the ray body of trace_fwd_item_lean) ---------------------------------
         unsigned long long m_parked = 0ull;
         float pk_be = 0.0f, pk_bu = 0.0f, pk_ah = 0.0f;
@@ -1716,7 +1742,7 @@ __device__ __forceinline__ void zero_block_gradients(const TraceArgs& a, const W
                                                      float4* __restrict__ grad_normals)
 {
     int p0, p1;
-    block_range(a, item.pblock, p0, p1);
+    block_range(a, item.pblock, p0, p1, item.tail);
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int p = p0 + (int)threadIdx.x; p < p1; p += (int)blockDim.x) {
         grad_origins[(int64_t)item.h * a.P + p] = z;
@@ -2110,7 +2136,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
     const float4 inc = a.incident[h];
     int p0, p1;
-    block_range(a, pblock, p0, p1);
+    block_range(a, pblock, p0, p1, item.tail);
     const int r0 = item.r0;
     const int r1 = item.r1;
     const float4* __restrict__ org = a.origins + (int64_t)h * a.P;
@@ -2139,7 +2165,6 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const float lds_base = (float)(unsigned)(size_t)(lds_f32*)gtile;
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
     const unsigned twm2_bits = f32_bits((float)(win.tw - 2)), uthm2_bits = f32_bits((float)(win.th - 2));
-    const unsigned tw4 = 4u * (unsigned)win.tw;
   for (int pass = 0; pass < win.npass; ++pass) {
     const int pu0 = win.u0 + pass * (win.ths - 1);
     const int pth = min(win.ths, win.u0 + win.th - pu0);
@@ -2175,13 +2200,21 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             for (int c = lane; c < win.tw; c += 64) t0[c] = g0[c];
         }
     }
+    // an empty window (no chief ray of the block reaches the target; or a degenerate one of a single row / column) holds no
+    // ray: every valid ray is then a stray.  Its masked rays still READ two cells - clamped onto cells 0 and 1, see addr_hi_f -
+    // and multiply them by zero weights, so those cells must hold finite values: nothing was staged there, and whatever
+    // the CU's previous workgroup left in its LDS may look like a NaN (0 x NaN = NaN in every gradient of the block: the
+    // rare, box-dependent failure of tests/test_gpu_parity.py::test_random_scenes_split_calls[8-12-77-17-*] in round 3).
+    const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
+#ifndef ART_NO_EMPTY_WINDOW_FIX     // (diagnostic build: shows that tests/test_gpu_boundary.py::test_results_do_not_depend_on_what_the_lds_held_before fails without it)
+    if (win_ok == 0ull && tid < 2) gtile[tid] = 0.0f;
+#endif
     __syncthreads();
 
     const float pu0f = (float)pu0;
     const unsigned thm2_bits = f32_bits((float)(pth - 2));
-    // an empty window (no chief ray of the block reaches the target) holds no ray: every valid ray is then a stray
-    const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
-    const float addr_hi_f = lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2));
+    const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2)) : lds_base;
+    const unsigned tw4 = win_ok != 0ull ? 4u * (unsigned)win.tw : 0u;      // (degenerate window: both rows of a read are cells 0, 1)
     for (int j = tid; j < n_pts; j += blockDim.x) {
         const int p = p0 + (packed ? (int)perm[j] : j);
         const float4 o = org[p];
@@ -2220,7 +2253,13 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             const unsigned addr_lo = (unsigned)af;
             const lds_f32* lo = (const lds_f32*)(size_t)addr_lo;
             const lds_f32* up = (const lds_f32*)(size_t)(addr_lo + tw4);
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(ART_EXP_SETPRIO);
+#endif
             float g1 = up[0], g2 = up[1], g3 = lo[1], g4 = lo[0];
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             unsigned long long m_use = m_in;
 #ifndef ART_ABLATE_NO_STRAYS
             if (__builtin_expect((m_valid & ~m_in) != 0ull, 0)) {
@@ -2709,6 +2748,42 @@ static void window_geometry(TraceArgs& a, const FwdConfig& cfg, int p_block_targ
     if (cost(half) < 0.97 * cost(a)) a = half;
 }
 
+// work_item_count() on the host
+static int64_t host_item_count(const TraceArgs& a)
+{
+    if (a.tail_h > 0) return (int64_t)(a.H - a.tail_h) * a.n_pblocks + (int64_t)a.tail_h * a.tail_npb;
+    return (int64_t)(a.h_group > 1 ? a.n_groups : a.H) * a.n_pblocks * a.n_rchunks;
+}
+
+// The queue's finer-grained end (lean kernels, whole samples per item): the heliostats of the LAST round of resident
+// workgroups are cut into twice as many point blocks.  With ~2 items per CU (one of eight ranks' share of the metric field:
+// 500 items of ~200 us on 256 CUs) the queue otherwise ends with half an item of idle time per CU on average; splitting by
+// POINTS keeps every point's samples in one item, so bitmaps and gradients are the same bits with or without it
+// (ARTIST_HIP_TAIL=0 switches it off; ARTIST_HIP_TAIL=2 forces it for the backward kernel as well: tests).  Costs one more
+// window build / clear / flush per extra item.
+static void set_queue_tail(TraceArgs& a, int min_points)
+{
+    a.tail_h = 0; a.tail_bpf = a.blocks_per_facet; a.tail_pblock = a.p_block; a.tail_npb = a.n_pblocks;
+    const int mode = env_int("ARTIST_HIP_TAIL", 1);
+    if (mode == 0 || a.n_rchunks != 1 || a.h_group > 1 || a.n_pblocks < 1) return;
+    const bool forward = min_points >= 512;
+    if (mode == 2) min_points = 64;                                   // (tests: also in the backward kernel, any field size)
+    const int64_t items = (int64_t)a.H * a.n_pblocks;
+    // Measured (same box, forward / backward ms, tail off -> on): 1000 heliostats 3.23 -> 3.17 / 3.43 -> 3.43, 250 heliostats
+    // 0.848 -> 0.828 / 0.873 -> 0.885, 125 heliostats 0.506 -> 0.516 / 0.516 -> 0.585: every extra item pays a window build,
+    // a clear / staging pass and a flush (more in the backward kernel: 155 KB of gradient window + the edge-point
+    // partition), which eats what the shorter tail gives unless the queue has at least three rounds - and in the backward
+    // kernel even then.  So: forward only (min_points == 512 is the forward's call), three rounds or more.
+    if (mode != 2 && (items < 3 * (int64_t)resident_workgroups() || !forward)) return;
+    if (items < 2) return;
+    const int bpf = 2 * a.blocks_per_facet;
+    const int pb = (a.facet_points + bpf - 1) / bpf;
+    if (pb < min_points || (a.facet_points + pb - 1) / pb != bpf) return;
+    a.tail_h = (int)std::min<int64_t>(a.H, (resident_workgroups() + a.n_pblocks - 1) / a.n_pblocks);
+    a.tail_bpf = bpf; a.tail_pblock = pb;
+    a.tail_npb = (a.P + a.facet_points - 1) / a.facet_points * bpf;
+}
+
 // Geometry for one point-block size.  p_block: a multiple of the block size close to
 // P / ceil(P / 2048) so that point blocks are balanced; samples are chunked only as far as needed to
 // fill the chip (each chunk pays a window build + flush).
@@ -2837,7 +2912,8 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             cl.exact_pblock = true;
             if (!cl.p_block_fixed) cl.p_block = cl.facet_points > 0 ? kLeanFwdPoints : kLeanFwdThreads;
             window_geometry(al, cl, cl.p_block, cl.p_block_fixed);
-            const int64_t items_l = (int64_t)al.H * al.n_pblocks * al.n_rchunks;
+            set_queue_tail(al, 512);
+            const int64_t items_l = host_item_count(al);
             if (items_l > 2147483647LL - 65536) return ART_EINVAL;
             const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
             const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(unsigned);
@@ -2899,11 +2975,12 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             }
             if (K > 1) { a.h_group = std::min(K, a.H); a.n_groups = (a.H + a.h_group - 1) / a.h_group; field_groups = true; }
         }
+        if (lean && T > 0 && Tc == 0) set_queue_tail(a, 512);
         if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
-            fprintf(stderr, "art_trace_fwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d group %d\n",
+            fprintf(stderr, "art_trace_fwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d group %d tail %d x %d\n",
                     a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean,
-                    a.h_group);
-        const int64_t items = (int64_t)(field_groups ? a.n_groups : a.H) * a.n_pblocks * a.n_rchunks;
+                    a.h_group, a.tail_h, a.tail_npb);
+        const int64_t items = host_item_count(a);
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
 #ifdef ART_FWD_SINGLE_ITEM
@@ -3090,7 +3167,8 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             }
             window_geometry(al, cl, cl.p_block_bwd, cl.p_block_bwd_fixed);
             if (al.n_rchunks == 1) {
-                const int64_t items_l = (int64_t)al.H * al.n_pblocks;
+                set_queue_tail(al, 384);
+                const int64_t items_l = host_item_count(al);
                 if (items_l > 2147483647LL - 65536) return ART_EINVAL;
                 const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
                 const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(float) + perm_l;
@@ -3120,7 +3198,8 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                 if (mixed_split) planar_done = true; else a.split = 2;
             }
         }
-        const int64_t items = (int64_t)a.H * a.n_pblocks * a.n_rchunks;
+        if (lean && a.n_rchunks == 1) set_queue_tail(a, 384);
+        const int64_t items = host_item_count(a);
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float) + perm_bytes;

@@ -166,3 +166,67 @@ def test_many_queued_launches_share_their_counters_safely(golden):
     np.testing.assert_array_equal(n(last), n(first))
     np.testing.assert_array_equal(n(g[0]), n(g_first[0]))
     np.testing.assert_array_equal(n(g[1]), n(g_first[1]))
+
+
+def _poison_lds(pattern=0x7FC00000):
+    """Fill every CU's LDS with a NaN bit pattern (tests/lds_poison.hip, built by ``__graft_entry__.build``)."""
+    import ctypes
+    import pathlib
+    so = pathlib.Path(__file__).resolve().parent / "bin" / "liblds_poison.so"
+    if not so.exists():
+        pytest.skip("tests/bin/liblds_poison.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = ctypes.CDLL(str(so))
+    lib.lds_poison.argtypes = [ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+    sink = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert lib.lds_poison(pattern, torch.cuda.current_stream(DEV).cuda_stream, sink.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert int(sink) == 0
+
+
+@pytest.mark.parametrize("blocking", [False, True])
+def test_results_do_not_depend_on_what_the_lds_held_before(blocking):
+    """LDS is not cleared between workgroups.  Heliostats that miss their target completely have an EMPTY window: their
+    rays are all masked, and the lean backward kernel used to multiply whatever the unstaged cells held by zero weights -
+    NaN whenever the CU's previous workgroup had left something that looks like one (round 3: a rare, box-dependent
+    failure of test_random_scenes_split_calls).  With every CU's LDS filled with NaN patterns (and with all-ones) before
+    each call, flux, factors and gradients must be the bits of the unpoisoned run - with blocking off (lean kernels) and
+    on (split call: lean launch for the heliostats without candidate rectangles, among them the ones that miss)."""
+    from artist_amd import trace_rays
+    from test_gpu_parity import _random_feature_scene
+    sc = _random_feature_scene(8, 12, 77, 17)                    # heliostats 4, 9, 10, 11 reflect past both planes
+    tix = (sc["target_idx"] % 2).to(DEV)
+    dv = lambda x: x.to(DEV).contiguous()  # noqa: E731
+    both = dv(sc["both"])
+    kw = dict(ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=(96, 64))
+    if blocking:
+        kw["blocking"] = dict({k: dv(v) for k, v in sc["prims"].items()}, lbvh_compat=False)
+    w = torch.rand((12, 64, 96), generator=torch.Generator().manual_seed(8)).to(DEV)
+
+    def run(pattern, env_blocks):
+        import os
+        old = os.environ.get("ARTIST_HIP_FWD_BLOCKS")
+        if env_blocks:
+            os.environ["ARTIST_HIP_FWD_BLOCKS"] = env_blocks      # "1": samples stay in one chunk, the backward call splits too
+        try:
+            o, nn_ = dv(sc["origins"]).requires_grad_(True), dv(sc["normals"]).requires_grad_(True)
+            if pattern is not None:
+                _poison_lds(pattern)
+            out = trace_rays(o, nn_, dv(sc["incident"]), both[..., 0], both[..., 1], tix, dv(sc["planes"]["centers"]),
+                             dv(sc["planes"]["normals"]), dv(sc["planes"]["dims"]), **kw)
+            if pattern is not None:
+                _poison_lds(pattern)
+            (out[0] * w).sum().backward()
+            return n(out[0]), n(out[1]), n(o.grad), n(nn_.grad)
+        finally:
+            if old is None:
+                os.environ.pop("ARTIST_HIP_FWD_BLOCKS", None)
+            else:
+                os.environ["ARTIST_HIP_FWD_BLOCKS"] = old
+
+    for env_blocks in ("1", None):
+        clean = run(None, env_blocks)
+        assert float(clean[1][1, 9]) == 0 and np.isfinite(clean[2]).all() and np.abs(clean[2][9]).sum() == 0
+        for pattern in (0x7FC00000, 0xFFFFFFFF, 0x7F800001):
+            dirty = run(pattern, env_blocks)
+            for a_, b_ in zip(clean, dirty):
+                np.testing.assert_array_equal(a_, b_, err_msg=f"pattern {pattern:#x}, blocks {env_blocks}")

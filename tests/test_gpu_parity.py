@@ -1457,8 +1457,11 @@ def test_random_scenes_split_calls(seed, H, P, R, variant, monkeypatch):
     go, gn = grads[0], grads[1]
     tol = 2e-5 if variant == "blocking_on_planes" else 2e-3
     assert np.isfinite(go).all() and np.isfinite(gn).all(), "the oracle's gradients are not finite"
-    assert bool(torch.isfinite(o.grad).all()) and bool(torch.isfinite(nn_.grad).all()), \
-        ("non-finite HIP gradients in heliostats", np.nonzero(~np.isfinite(n(o.grad)).all(axis=(1, 2)))[0], n(tix))
+    if not (bool(torch.isfinite(o.grad).all()) and bool(torch.isfinite(nn_.grad).all())):
+        bad_o, bad_n = ~np.isfinite(n(o.grad)).all(axis=2), ~np.isfinite(n(nn_.grad)).all(axis=2)
+        raise AssertionError(("non-finite HIP gradients (heliostat, point) origins / normals", np.argwhere(bad_o).tolist()[:40],
+                              np.argwhere(bad_n).tolist()[:40], "counts", int(bad_o.sum()), int(bad_n.sum()), "unblocked fraction",
+                              n(fac[2]).tolist(), "values", n(o.grad)[bad_o][:4].tolist()))
     assert rel_l2(n(o.grad)[planar], go[planar]) < 2e-5, rel_l2(n(o.grad)[planar], go[planar])
     assert rel_l2(n(nn_.grad)[planar], gn[planar]) < 2e-5, rel_l2(n(nn_.grad)[planar], gn[planar])
     assert rel_l2(n(o.grad), go) < tol and rel_l2(n(nn_.grad), gn) < tol
@@ -1751,13 +1754,17 @@ def test_scenario_file_to_flux(golden, name):
 
 @pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_PERSISTENT="0"), dict(ARTIST_HIP_LEAN="0"), dict(ARTIST_HIP_FWD_PBLOCK="512", ARTIST_HIP_BWD_PBLOCK="640"),
                                    dict(ARTIST_HIP_FWD_BLOCKS="4096"), dict(ARTIST_HIP_BWD_PACK="0"), dict(ARTIST_HIP_BWD_PACK="200"),
-                                   dict(ARTIST_HIP_FWD_TILE_KB="24", ARTIST_HIP_BWD_PACK="64")])
+                                   dict(ARTIST_HIP_FWD_TILE_KB="24", ARTIST_HIP_BWD_PACK="64"), dict(ARTIST_HIP_TAIL="2"),
+                                   dict(ARTIST_HIP_TAIL="2", ARTIST_HIP_FWD_PBLOCK="256", ARTIST_HIP_BWD_PBLOCK="320"),
+                                   dict(ARTIST_HIP_WINDOW_SAMPLE="0")])
 def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     """The windowed kernels hand out (heliostat, point block, sample chunk) items through a work queue: persistent
     workgroups (default) or one workgroup per item, the lean or the generic ray body, other point-block sizes, samples cut
     into more chunks, the backward kernel's edge points packed or not (and with a margin that makes every point an edge point,
-    and with a small window).  However the items are dealt, the bitmaps are the same BITS (integer pixel accumulators); the
-    gradients are the same bits as long as a point's samples are summed in the same order (everything but the chunking)."""
+    and with a small window), the queue's end cut into finer point blocks (ARTIST_HIP_TAIL=2: in both kernels, any field
+    size), the window phase on every point instead of a sample.  However the items are dealt, the bitmaps are the same BITS
+    (integer pixel accumulators); the gradients are the same bits as long as a point's samples are summed in the same order
+    (everything but the chunking)."""
     from artist_amd import trace_rays
     d = golden("mid_256")
 
