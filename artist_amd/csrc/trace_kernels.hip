@@ -1289,7 +1289,9 @@ __device__ __forceinline__ void trace_fwd_item_field(const TraceArgs& a, unsigne
         }
         {
             WindowStats w;
-            const int ps = a.P > (int)blockDim.x ? window_sample_point(0, a.P) : tid;
+            // (a quarter of the threads look: 256 evenly spaced points per heliostat are plenty for the union of a run's
+            //  images, and every sampled point is 40 B of extra HBM traffic on a path that is bound by exactly that)
+            const int ps = (tid & 3) != 0 ? a.P : (a.P > (int)blockDim.x ? window_sample_point(0, a.P) : tid);
             for (int hh = hs; hh < he; ++hh) {
                 if (ps < a.P) {
                     float u, e;

@@ -15,6 +15,10 @@ step     : one surface-reconstruction epoch over the whole field
 N GPUs   : heliostats are sharded over ranks exactly like RestrictedDistributedSampler
            (heliostat i -> rank i mod N); total work is fixed  => "scaling": "strong".
 
+Every rank draws ITS rows of the field-wide seed-7 sample, so an N-rank run traces exactly the rays of the 1-rank run; the line
+carries a checksum of the reduced flux ("sharding_check") and, at N > 1, rank 0 re-traces the whole field alone and the run fails
+when the reduced flux differs from it by more than 2e-6.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -34,7 +38,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_PEAK_FILE = ROOT / "profiles" / "r02_hbm_peak.json"       # tools/hbm_peak.hip on this pool's MI355X (float4 copy / read / write)
-HBM_TRAFFIC_FILE = ROOT / "profiles" / "r02_hbm_traffic.json"  # rocprofv3 --pmc passes of this command (tools/pmc_hbm.sh)
+HBM_TRAFFIC_FILE = ROOT / "profiles" / "r03_hbm_traffic.json"  # rocprofv3 --pmc passes of this command (tools/pmc_hbm.sh)
 
 
 def parse():
@@ -429,7 +433,7 @@ def main():
                          # what binds the kernel (neither of the contract's two roofs): replayed analysis, DESIGN.md 4.0 / 4.1
                          "limiter_note": "not HBM: about two thirds of the kernel are vector issue of the ray arithmetic (reference operation order, "
                                          "no FMA contraction), the rest LDS-atomic, stray-ray and stream stalls - ablation table in DESIGN.md "
-                                         "section 4.4, issue rates in 4.0 (profiles/r02_issue_bench.json, r02_ablation.txt); stated from "
+                                         "section 4.4, issue rates and the LDS conflict split in 4.0 (profiles/r02_issue_bench.json, r02_ablation.txt, r03_pmc_lds_conflicts.txt); stated from "
                                          "profiles/, not measured by this run"},
             "check": check,
             "sharding_check": sharding,

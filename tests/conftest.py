@@ -65,3 +65,25 @@ def sun_distortions(n_heliostats, n_rays, n_points, covariance=4.3681e-06, mean=
         torch.tensor([[covariance, 0], [0, covariance]], dtype=torch.float))
     du, de = mvn.sample((n_heliostats, n_rays, n_points)).permute(3, 0, 1, 2)
     return du, de
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_lds(request):
+    """Every GPU test starts with each CU's LDS full of NaN bit patterns (tests/lds_poison.hip): LDS is not cleared between
+    workgroups, and a kernel that reads a cell it never wrote only fails when the leftover looks like a NaN - with this the
+    leftover always does at the start of a test (round 3 found a latent read of that kind: DESIGN.md section 3)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import ctypes
+    so = ROOT / "tests" / "bin" / "liblds_poison.so"
+    try:
+        import torch
+        if so.exists() and torch.cuda.is_available():
+            lib = ctypes.CDLL(str(so))
+            lib.lds_poison.argtypes = [ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
+            sink = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+            lib.lds_poison(0x7FC00000, torch.cuda.current_stream().cuda_stream, sink.data_ptr())
+    except OSError:
+        pass
+    yield

@@ -7,14 +7,14 @@ timeout -k 10 300 python tools/config_bench.py 2>/dev/null | grep "^{" > gpurun_
 timeout -k 10 300 python bench.py --heliostats 100 --rays 180 --n-cp 6 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final_bench_config4.json
 timeout -k 10 300 python bench.py --heliostats 125 --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final_bench_h125.json
 ARTIST_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/final_bench_2rank_gloo.log 2> gpurun_out/final_bench_2rank_gloo.err || echo "2-rank rehearsal failed"
+ARTIST_AMD_COLLECTIVES_AT_WORLD_1=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final_bench_rccl_world1.log 2>&1 || echo "rccl world-1 rehearsal failed"
 timeout -k 10 300 python tools/blocking_bench.py 2>/dev/null | tail -1 > gpurun_out/final_blocking_bench.json
 timeout -k 10 300 python tools/flux_bench.py 2>/dev/null | tail -1 > gpurun_out/final_flux_bench.json
 timeout -k 10 300 python tools/cylinder_bench.py 2>/dev/null | tail -1 > gpurun_out/final_cylinder_bench.json
-if ls tools/bin/libabl_base.so > /dev/null 2>&1; then
-  timeout -k 10 300 python tools/ab_libs.py --rounds 4 --reps 3 shipped=tools/bin/libabl_base.so no_lds_atomics=tools/bin/libabl_noatomics.so no_strays=tools/bin/libabl_nostrays.so no_loads=tools/bin/libabl_noloads.so no_flush=tools/bin/libabl_noflush.so alu_only=tools/bin/libabl_aluonly.so 2>&1 | tail -6 > gpurun_out/final_ablation.txt || true
-fi
 bash tools/kstats.sh final > gpurun_out/final_kstats.txt 2>&1 || true
 bash tools/kstats.sh final125 --heliostats 125 > gpurun_out/final_kstats_h125.txt 2>&1 || true
 bash tools/prof_pass.sh final > /dev/null 2>&1 || true
 bash tools/pmc_hbm.sh final > /dev/null 2>&1 || true
+bash tools/pmc_lds.sh finallds > /dev/null 2>&1 || true
+python tools/pmc_summary.py final > gpurun_out/final_pmc_summary.txt 2>&1 || true
 echo done
