@@ -230,3 +230,73 @@ def test_results_do_not_depend_on_what_the_lds_held_before(blocking):
             dirty = run(pattern, env_blocks)
             for a_, b_ in zip(clean, dirty):
                 np.testing.assert_array_equal(a_, b_, err_msg=f"pattern {pattern:#x}, blocks {env_blocks}")
+
+
+def test_every_entry_point_is_independent_of_lds_leftovers(monkeypatch):
+    """The same check for the whole boundary: every asynchronous entry point of the library is wrapped so that each of its
+    calls starts with all CUs' LDS full of NaN patterns, and an epoch that touches all of them - NURBS evaluation with fused
+    alignment, a mixed planar / cylindrical tower with blocking on (filter, split launches, soft mask), per-target sums,
+    centre of mass, crop + pixel loss, crop + KL, and every backward pass - must give the bits of the unwrapped epoch."""
+    from artist_amd import HeliostatRayTracer, NURBSSurfaces, _lib, get_center_of_mass
+    from artist_amd.flux import FluxCropKLLoss, FluxCropPixelLoss
+    from artist_amd.scene import SolarTower, TowerTargetAreasCylindrical, build_synthetic_scenario
+    H = 10
+    handle = _lib.lib()
+
+    def epoch():
+        torch.manual_seed(0)
+        scenario, uv = build_synthetic_scenario(H, 12, n_cp=(6, 6), n_eval=14, device=DEV)
+        planar = scenario.solar_tower.target_areas[0]
+        cyl = TowerTargetAreasCylindrical(
+            names=["cyl"], centers=torch.tensor([[0.0, -12.0, 55.0, 1.0]], device=DEV),
+            normals=torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=DEV), axes=torch.tensor([[0.0, 0.0, 1.0, 0.0]], device=DEV),
+            radii=torch.tensor([12.0], device=DEV), heights=torch.tensor([30.0], device=DEV), opening_angles=torch.tensor([2.0], device=DEV))
+        scenario.solar_tower = SolarTower([planar, cyl], device=DEV)
+        group = scenario.heliostat_field.heliostat_groups[0]
+        mask = torch.ones(H, dtype=torch.int32, device=DEV)
+        tix = torch.tensor([0, 1, 0, 0, 1, 0, 0, 0, 1, 0], device=DEV)
+        inc = torch.tensor([0.0, 1.0, 0.0, 0.0], device=DEV).expand(H, 4).contiguous()       # a low sun in the south ...
+        group.positions[:4] = torch.tensor([[0.0, 140.0, 0.0, 1.0], [0.0, 137.0, 0.0, 1.0], [1.2, 134.0, 0.0, 1.0],
+                                            [0.4, 131.0, 0.0, 1.0]], device=DEV)             # ... and a column of mirrors in each other's beams
+        group.activate_heliostats(mask, DEV)
+        group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask, DEV)
+        from artist_amd import scene
+        orientation = scene.ideal_orientations(group.active_positions, scenario.solar_tower.get_centers_of_target_areas(tix), inc)
+        cp = group.active_nurbs_control_points.clone().requires_grad_(True)
+        pts, nrm = NURBSSurfaces(group.nurbs_degrees, cp, device=DEV).calculate_surface_points_and_normals(
+            uv, group.active_canting, group.active_facet_translations, orientations=orientation)
+        group.active_surface_points, group.active_surface_normals = pts.reshape(H, -1, 4), nrm.reshape(H, -1, 4)
+        rt = HeliostatRayTracer(scenario, group, blocking_active=True, bitmap_resolution=torch.tensor([64, 64]))
+        rt.lbvh_compat = False
+        flux, intercept, on_target, unblocked = rt.trace_rays(inc, mask, tix)
+        per_target = rt.get_bitmaps_per_target(flux.detach(), tix)
+        dims = torch.tensor([[8.0, 8.0]], device=DEV).expand(H, 2).contiguous()
+        truth = torch.rand((H, 64, 64), generator=torch.Generator().manual_seed(1)).to(DEV) + 0.1
+        loss = FluxCropPixelLoss.apply(flux, dims, truth, 6.0, 6.0).sum() + FluxCropKLLoss.apply(flux, dims, truth, 6.0, 6.0).sum() \
+            + get_center_of_mass(flux).sum() * 1e-3
+        loss.backward()
+        torch.cuda.synchronize()
+        return [n(x) for x in (pts, flux, intercept, on_target, unblocked, per_target, loss, cp.grad)]
+
+    clean = epoch()
+    assert np.isfinite(clean[7]).all() and np.abs(clean[7]).sum() > 0 and (clean[4] < 1).any()
+    calls = []
+    for name in _lib.SIGNATURES:
+        if name in ("art_abi_version", "art_last_hip_error", "art_strerror", "art_async_status", "art_blocking_workspace_bytes",
+                    "art_trace_bwd_scratch_floats"):
+            continue
+        real = getattr(handle, name)
+
+        def wrapped(*args, _real=real, _name=name):
+            _poison_lds(0x7FC00000)
+            calls.append(_name)
+            return _real(*args)
+
+        monkeypatch.setattr(handle, name, wrapped)
+    dirty = epoch()
+    monkeypatch.undo()
+    assert {"art_nurbs_fwd", "art_nurbs_bwd", "art_trace_fwd", "art_trace_bwd", "art_blocking_filter", "art_per_target_sum",
+            "art_flux_crop_pixel_loss_fwd", "art_flux_crop_pixel_loss_bwd", "art_flux_crop_kl_loss_fwd", "art_flux_crop_kl_loss_bwd",
+            "art_flux_center_of_mass", "art_flux_center_of_mass_bwd", "art_reflect"} <= set(calls), sorted(set(calls))
+    for a_, b_ in zip(clean, dirty):
+        np.testing.assert_array_equal(a_, b_)
