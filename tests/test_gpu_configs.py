@@ -156,14 +156,18 @@ def _oracle_epoch(dtype, cp, uv, canting, transl, orientation, inc, du, de, tix,
     flux, fac = oracle.trace_fwd(*args)
     go, gn = oracle.trace_bwd(*args, c(weights))
     g_cp = oracle.nurbs_bwd(c(cp), c(uv), [3, 3], (go @ ori).reshape(pts.shape), (gn @ ori).reshape(nrm.shape), c(canting))
-    return flux, fac, g_cp
+    # ... and END TO END: the oracle's trace on the oracle's OWN aligned surfaces (nothing taken from the HIP run)
+    flux_e2e, _ = oracle.trace_fwd(ap, an, *args[2:])
+    return flux, fac, g_cp, flux_e2e
 
 
 @pytest.mark.parametrize("H,R,n_cp,label", [(100, 180, 6, "config 4"), (1000, 100, 10, "metric config")])
 def test_reconstruction_epoch_forward_and_control_point_gradients(H, R, n_cp, label):
     """Config 4 (100 heliostats x 180 rays, 6x6 degree-3 control nets) and the metric config (1000 x 100, 10x10): one
     surface-reconstruction epoch forward + backward on the whole field; a sample of heliostats against the oracle's
-    epoch (flux < 1e-5, counters exact, control-point gradients within the oracle's own fp32-vs-fp64 distance)."""
+    epoch (flux < 1e-5 with the trace stage fed the same aligned surfaces, counters exact, control-point gradients within the
+    oracle's own fp32-vs-fp64 distance) AND end to end - control points to flux with every stage the oracle's own - within the
+    distance between the oracle's fp32 and fp64 chains (printed)."""
     from artist_amd import scene
     scenario, group, mask, tix, inc, uv = build_field(H, R, n_cp=n_cp)
     planar = scenario.solar_tower.target_areas[0]
@@ -192,6 +196,13 @@ def test_reconstruction_epoch_forward_and_control_point_gradients(H, R, n_cp, la
               f"vs fp64 {rel_l2(n(g_cp[h]), o64[2][k]):.2e}, oracle fp32-vs-fp64 {yard:.2e}")
         assert got < max(2.0 * yard, 2e-4), (label, h, got, yard)
         assert rel_l2(n(g_cp[h]), o64[2][k]) < max(3.0 * yard, 2e-4), (label, h)
+        # end to end (control points -> flux, every stage the oracle's own): one ULP of a normal moves every ray of its point by
+        # ~4e-4 px, so the yardstick is how far the oracle's fp32 chain is from its fp64 chain
+        e2e, e2e_yard = rel_l2(n(flux[h]), o32[3][k]), rel_l2(o32[3][k], o64[3][k])
+        print(f"{label}: heliostat {h}: END TO END flux vs the oracle's own chain {e2e:.2e} (oracle fp32-vs-fp64 chain: {e2e_yard:.2e}; "
+              f"vs the fp64 chain {rel_l2(n(flux[h]), o64[3][k]):.2e})")
+        assert e2e < max(3.0 * e2e_yard, 1e-4), (label, h, e2e, e2e_yard)
+        assert rel_l2(n(flux[h]), o64[3][k]) < max(3.0 * e2e_yard, 1e-4), (label, h)
     np.testing.assert_array_equal(n(factors[0][sel]), o32[1][0])
     np.testing.assert_array_equal(n(factors[1][sel]), o32[1][1])
     # invariants on the whole field (the tracer mirror reads the aligned surfaces from the group)
