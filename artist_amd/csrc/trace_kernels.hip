@@ -971,7 +971,12 @@ __device__ __forceinline__ void pack_edge_points(const TraceArgs& a, const Plane
                                // with twelve waves of 0.7 us ray steps the stream's latency is covered anyway, and a stray's
                                // vmcnt(0) has less to wait for
 #endif
-template <bool INTERLEAVED>
+// BLOCKING: the same item with the soft blocking mask (blocking.py:212-354) of the heliostat's candidate rectangles in every
+// ray - the launch of a split call that owns the heliostats WITH candidates.  What changes against the plain lean item: the
+// rectangle tables in LDS, a bitmask per point of the rectangles its scatter cone can touch, `keep` = 1 - blocked in the ray's
+// intensity, and three ray counters instead of one (a valid ray can now carry no light: I > 0 needs keep > 0; the blocking
+// factor counts ALL rays with blocked < 1e-3, heliostat_ray_tracer.py:501-503).
+template <bool INTERLEAVED, bool BLOCKING = false>
 __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
                                                     const int bid, const WorkItem item, unsigned int* __restrict__ work_counter,
                                                     int* s_next)
@@ -980,6 +985,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     __shared__ float s_red[13][16];
     __shared__ Window s_win;
     __shared__ unsigned s_cnt[3];
+    __shared__ PrimTable<BLOCKING> s_tab;
     const int pblock = item.pblock;
     const int h = item.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -1014,6 +1020,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         for (int i = tid; i < a.tile_cap / 4; i += blockDim.x) t4[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) tile[a.tile_cap + tid] = 0u;
     }
+    const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
     const float Wf = (float)a.W, Hf = (float)a.Hh;
@@ -1042,6 +1049,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     // [cell 0, that] and add zero there (an empty window: onto cell 0 - the tile is cleared, so that is a legal place too)
     const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2)) : lds_base;
     unsigned n_valid = 0;
+    [[maybe_unused]] unsigned n_int = 0, n_free = 0;      // (blocking) rays with I > 0 / with blocked < 1e-3
     if (!first) {
         const int npx = win.tw * pth;
         for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
@@ -1050,7 +1058,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
 
     // ---- phase 2: trace ------------------------------------------------------------------------
     unsigned long long m_parked = 0ull;               // lanes holding a parked stray ray
-    float pk_be = 0.0f, pk_bu = 0.0f, pk_ah = 0.0f;   // its bitmap coordinates (geometry.py:186-197) and direction cosine
+    float pk_be = 0.0f, pk_bu = 0.0f, pk_ah = 0.0f;   // its bitmap coordinates (geometry.py:186-197) and direction cosine (x keep)
     auto unpark = [&]() {                             // the parked rays' four weights -> their pixels' accumulators
         if ((m_parked >> lane) & 1ull) {
             const float tbe = truncf(pk_be), tbu = truncf(pk_bu);                              // heliostat_ray_tracer.py:674-675
@@ -1074,6 +1082,15 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         float4 d; float s;
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
+        [[maybe_unused]] unsigned pmask = 0u, wmask = 0u;       // rectangles this point's / this wave's rays can touch
+        if constexpr (BLOCKING) {
+            if (n_prims > 0) {
+                const float il = rsqrtf(fmaxf(d.x * d.x + d.y * d.y + d.z * d.z, 1e-30f));
+                pmask = cone_mask(s_tab.prim, s_tab.aux, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin,
+                                  a.slab_cull != 0);
+                wmask = wave_or_mask(pmask, n_prims);
+            }
+        }
         auto carries = [&]() {                       // cold: a cell of the previous ray wrapped (see resolve_carries)
             PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
             resolve_carries(ps, acc, a.W, a.Hh, win.shift);
@@ -1107,7 +1124,22 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
             const unsigned addr_lo = (unsigned)af;
             const unsigned addr_up = addr_lo + tw4;                            // flat row iu + 1
-            const float Is = select_or_zero(m_in, fabsf(ah) * kS);
+            float ahk = ah;                                                    // the direction cosine, attenuated by the blocking mask
+            if constexpr (BLOCKING) {
+                // soft mask over this heliostat's rectangles, for every ray - also those that miss the target
+                // (blocking.py:212-354; heliostat_ray_tracer.py:462-480); keep is exactly 0 once the transmittance drops below
+                // 2^-25, as in the reference
+                float blocked = 0.0f, keep = 1.0f;
+                if (wmask != 0u) {
+                    unsigned near;
+                    blocked = 1.0f - soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
+                    keep = 1.0f - blocked;
+                }
+                n_free += __popcll(ballot64(blocked < 1e-3f) & live);
+                n_int += __popcll(m_valid & ballot64(keep > 0.0f));
+                ahk = ah * keep;
+            }
+            const float Is = select_or_zero(m_in, fabsf(ahk) * kS);
             const float wa = chu * Is, wb = clu * Is;
             // the previous ray's adds have landed; a carry needs a cell that was already above 2^31 (q < 2^22)
             if (__builtin_expect(wave_any(((po1 | po2 | po3 | po4) >> 31) != 0u), 0)) carries();
@@ -1143,7 +1175,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 else if (win.npass > 1)                         // banded sweep: only what no band holds
                     m_out &= ~(win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(tbu - u0f) <= uthm2_bits));
                 if (m_out & m_parked) unpark();
-                pk_be = select_mask(m_out, be, pk_be); pk_bu = select_mask(m_out, bu, pk_bu); pk_ah = select_mask(m_out, ah, pk_ah);
+                pk_be = select_mask(m_out, be, pk_be); pk_bu = select_mask(m_out, bu, pk_bu); pk_ah = select_mask(m_out, ahk, pk_ah);
                 m_parked |= m_out;
             }
 #endif
@@ -1221,7 +1253,10 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         resolve_carries(ps, acc, a.W, a.Hh, win.shift);
     }
     if (m_parked != 0ull) unpark();
-    if (first && lane == 0) { atomicAdd(&s_cnt[0], n_valid); atomicAdd(&s_cnt[1], n_valid); }
+    if (first && lane == 0) {
+        if constexpr (BLOCKING) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_valid); atomicAdd(&s_cnt[2], n_free); }
+        else { atomicAdd(&s_cnt[0], n_valid); atomicAdd(&s_cnt[1], n_valid); }
+    }
     __syncthreads();
     unsigned next_item = 0u;
     if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
@@ -1242,7 +1277,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();
   }
-    if (tid < 2 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
+    if (tid < (BLOCKING ? 3 : 2) && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1449,19 +1484,23 @@ constexpr bool kCylPersistentBwd = false;       // (measured neutral: 18.57 vs 1
 #define ART_LEAN_FWD_THREADS 1024
 #endif
 constexpr int kLeanFwdThreads = ART_LEAN_FWD_THREADS;
+#ifndef ART_LEAN_BLOCK_FWD_THREADS
+#define ART_LEAN_BLOCK_FWD_THREADS 768
+#endif
+constexpr int kLeanBlockFwdThreads = ART_LEAN_BLOCK_FWD_THREADS;   // the lean body + the soft mask: 168 registers instead of 128
 constexpr int kCylFwdThreads = 1024;             // (768: within the noise of the box, 512: 17 % slower)
 // LEAN: 0 the generic item, 1 trace_fwd_item_lean, 2 trace_fwd_item_field (groups of heliostats, see there)
 template <bool INTERLEAVED, bool CYL, bool BLOCKING, int LEAN = 0>
-__global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
+__global__ __launch_bounds__(LEAN ? (BLOCKING ? kLeanBlockFwdThreads : kLeanFwdThreads) : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
-    static_assert(!LEAN || (!CYL && !BLOCKING), "the lean ray body is the planar, non-blocking one");
+    static_assert(!LEAN || (!CYL && (LEAN == 1 || !BLOCKING)), "the lean ray bodies are planar; the field item knows no blocking");
     __shared__ int s_next, s_reverse;
 #ifdef ART_FWD_SINGLE_ITEM   // diagnostic build: one workgroup per item, no loop (A/B against the persistent form)
     constexpr bool single_item = true;
 #else
     // The cylinder and blocking instantiations keep more values alive per ray; inside the persistent loop they spill
     // enough to lose 5-9 % (tools/blocking_bench.py, same-box A/B), so they take one item per workgroup.
-    constexpr bool single_item = CYL || (BLOCKING && !kBlockingPersistentFwd);
+    constexpr bool single_item = CYL || (BLOCKING && LEAN == 0 && !kBlockingPersistentFwd);
 #endif
     if constexpr (single_item) {
         int item = (int)blockIdx.x;
@@ -1509,8 +1548,8 @@ __global__ __launch_bounds__(LEAN ? kLeanFwdThreads : (CYL ? kCylFwdThreads : 10
         if constexpr (LEAN == 2)
             trace_fwd_item_field<INTERLEAVED>(L.a, L.counts, s_reverse != 0 ? work_item_count(L.a) - 1 - item : item, L.work_counter, &s_next);
         else if constexpr (LEAN == 1)
-            trace_fwd_item_lean<INTERLEAVED>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0), L.work_counter,
-                                             &s_next);
+            trace_fwd_item_lean<INTERLEAVED, BLOCKING>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0),
+                                                       L.work_counter, &s_next);
         else
             trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0),
                                                        L.work_counter, &s_next);
@@ -2109,15 +2148,21 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
 // --------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) float lds_f32;
 
-template <bool INTERLEAVED, bool ATOMIC_OUT>
+// BLOCKING: the same item with the soft blocking mask recomputed per ray, its factor `keep` in the intensity, and the mask's
+// adjoint (block_adjoint: ray side into this thread's sums, rectangle side into the wave's owner-lane registers, see there) -
+// the launch of a split call that owns the heliostats WITH candidate rectangles.  A wave then walks whole trips (a lane beyond
+// the block's end repeats the last point, masked) and the item ends like trace_bwd_item: wave order, slab.
+template <bool INTERLEAVED, bool ATOMIC_OUT, bool BLOCKING = false>
 __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const float* __restrict__ grad_flux,
                                                     float4* __restrict__ grad_origins, float4* __restrict__ grad_normals,
-                                                    const WorkItem item, unsigned int* __restrict__ work_counter, int* s_next)
+                                                    const WorkItem item, unsigned int* __restrict__ work_counter, int* s_next,
+                                                    float* __restrict__ prim_slabs = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) float gtile[];
     __shared__ float s_red[13][16];
     __shared__ Window s_win;
     __shared__ int s_edge[kPackTrips * 16 + 1];      // edge points per (trip, wave), then their exclusive scan; [last] = total
+    __shared__ PrimTable<BLOCKING> s_tab;
 
     const int pblock = item.pblock;
     const int h = item.h;
@@ -2129,7 +2174,13 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const int t = a.target_idx[h];
     const bool bad_target = !target_in_range(a, t);
     if (bad_target || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {
-        if (bad_target) zero_block_gradients(a, item, grad_origins, grad_normals);
+        if (bad_target) {
+            zero_block_gradients(a, item, grad_origins, grad_normals);
+            if constexpr (BLOCKING) {                // ... and no rectangle gradients from this item either
+                float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
+                for (int c = tid; c < a.Cmax * 12; c += blockDim.x) slab[c] = 0.0f;
+            }
+        }
         if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
@@ -2145,9 +2196,11 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
+    const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
     unsigned next_item = 0u;
+    [[maybe_unused]] PrimSums prim_sums = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};   // (blocking) this wave's rectangle gradients
     const float kI = (a.mag * a.k_ext) * a.k_refl;
     const float sx = pl.wm1 / pl.w, sz = pl.hm1 / pl.h;
     const float Wf = (float)a.W, Hf = (float)a.Hh;
@@ -2217,7 +2270,10 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const unsigned thm2_bits = f32_bits((float)(pth - 2));
     const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2)) : lds_base;
     const unsigned tw4 = win_ok != 0ull ? 4u * (unsigned)win.tw : 0u;      // (degenerate window: both rows of a read are cells 0, 1)
-    for (int j = tid; j < n_pts; j += blockDim.x) {
+    // (blocking: a WAVE walks a trip as long as its first lane has a point; lanes beyond the end repeat the last slot, masked)
+    for (int jt = tid; (BLOCKING ? jt - lane : jt) < n_pts; jt += blockDim.x) {
+        const bool lane_live = jt < n_pts;
+        const int j = lane_live ? jt : n_pts - 1;
         const int p = p0 + (packed ? (int)perm[j] : j);
         const float4 o = org[p];
         const float4 n = nrm[p];
@@ -2225,6 +2281,16 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         reflect(inc, n, d, s);
         const float numer = plane_numer(pl, o);
         float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // gox / goz / goy: sums of g_hx / g_hz / g_numer
+        [[maybe_unused]] float bgx = 0.f, bgy = 0.f, bgz = 0.f;                   // dL/do through the blocking mask (world)
+        [[maybe_unused]] unsigned pmask = 0u, wmask = 0u;                         // rectangles this point's / this wave's rays can touch
+        if constexpr (BLOCKING) {
+            if (n_prims > 0) {
+                const float il = rsqrtf(fmaxf(d.x * d.x + d.y * d.y + d.z * d.z, 1e-30f));
+                pmask = cone_mask(s_tab.prim, s_tab.aux, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin,
+                                  a.slab_cull != 0);
+                wmask = wave_or_mask(pmask, n_prims);
+            }
+        }
         auto trace_one = [&](const float u, const float e, const unsigned long long live) {
             // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
             // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
@@ -2285,8 +2351,17 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
 #endif
             {
 #pragma clang fp contract(fast)
-                const float kIm = select_or_zero(m_use, kI);
-                const float I = -(kIm * ah);                                  // mag (-a) k_ext k_refl (one rounding: gradient side)
+                float kIm = select_or_zero(m_use, kI);
+                [[maybe_unused]] float trans = 1.0f, g_keep_scale = 0.0f;
+                [[maybe_unused]] unsigned near = 0u;
+                if constexpr (BLOCKING) {
+                    if (wmask != 0u) {
+                        trans = soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
+                        g_keep_scale = kIm * (-ah);                           // dI / d(keep) = mag (-a) k_ext k_refl for a ray in use
+                        kIm *= 1.0f - (1.0f - trans);                         // keep, with the reference's rounding (blocked = 1 - trans)
+                    }
+                }
+                const float I = -(kIm * ah);                                  // mag (-a) keep k_ext k_refl (one rounding: gradient side)
                 const float A = chu * g1 + clu * g4, B = chu * g2 + clu * g3;
                 const float gI = cle * A + che * B;
                 const float g_be = (B - A) * I;
@@ -2304,6 +2379,21 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
                 gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
                 gdz += m.ce * grz - m.se * gry;
+                if constexpr (BLOCKING) {
+                    // the mask's adjoint: only rays inside some rectangle's soft edge that still carry light have a gradient
+                    // through it (dL/d(keep) = dL/dI x dI/d(keep); keep = trans up to its rounding)
+                    const float g_keep = gI * g_keep_scale;
+                    const bool adj = lane_live && near != 0u && g_keep != 0.0f && trans > 1e-30f;
+                    if (wave_any(adj)) {
+                        const AdjointOut ao = block_adjoint((LdsPrims)s_tab.prim, prim_sums, wmask, adj ? near : 0u, o.x, o.y, o.z, rx, ry,
+                                                            rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+                        prim_sums = ao.sums;
+                        bgx += ao.ray.ox; bgy += ao.ray.oy; bgz += ao.ray.oz;
+                        gdx += m.cu * ao.ray.rx + m.m10 * ao.ray.ry + m.m20 * ao.ray.rz;
+                        gdy += m.m11 * ao.ray.ry + m.m21 * ao.ray.rz - m.su * ao.ray.rx;
+                        gdz += m.ce * ao.ray.rz - m.se * ao.ray.ry;
+                    }
+                }
             }
             // The sums are pinned here: volatile statements keep their order, so this ray's gradient arithmetic cannot
             // sink below the next ring step's head (it did, and everything that was alive across it went to scratch).
@@ -2364,11 +2454,14 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
         // hit = o + t r, t = (c - o).m / (r.m): dL/do = (g_hx, 0, g_hz) - m * sum g_numer
         const float sn = goy;
-        const float4 go = make_float4(gox - sn * pl.mx, -(sn * pl.my), goz - sn * pl.mz, 0.0f);
+        float4 go = make_float4(gox - sn * pl.mx, -(sn * pl.my), goz - sn * pl.mz, 0.0f);
+        if constexpr (BLOCKING) { go.x += bgx; go.y += bgy; go.z += bgz; }
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
         const int64_t idx = (int64_t)h * a.P + p;
-        if (first) {
+        if (!lane_live) {
+            // (a padding lane of the blocking instantiation: nothing to store)
+        } else if (first) {
             grad_origins[idx] = go;
             grad_normals[idx] = gn;
         } else {
@@ -2380,6 +2473,17 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();
   }
+    if constexpr (BLOCKING) {          // the waves' rectangle gradients in wave order, then this item's slab (see trace_bwd_item)
+        for (int w = 0; w < nwaves; ++w) {
+            if (wave == w && lane < 2 * n_prims) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) s_tab.grad[lane * 6 + c] += (double)prim_sums.v[c];
+            }
+            __syncthreads();
+        }
+        float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
+        for (int c = tid; c < n_prims * 12; c += blockDim.x) slab[c] = (float)s_tab.grad[c];
+    }
 }
 
 // Persistent workgroups over the work-item queue, like the forward kernel.
@@ -2397,6 +2501,8 @@ constexpr int kLeanBwdPoints = 2560;
 //  ray than the plain body, and three waves per SIMD with a few spills beat two without - same-box, tools/cylinder_bench.py:
 //  512 -> 768 threads 18.6 -> 17.0 ms forward + backward, 1024 threads 17.9; tools/blocking_bench.py exact mode 30.5 -> 29.0)
 constexpr int kCylBwdThreads = 768, kBlockingBwdThreads = 768;
+// static LDS the rectangle tables add to the lean backward kernel (PrimTable<true>: rectangles, cull data, fp64 gradient sums)
+constexpr int kLeanBlockBwdStatic = (int)sizeof(PrimTable<true>);
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
 __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThreads : (LEAN ? kLeanBwdThreads : 1024))) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
@@ -2407,7 +2513,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
     __shared__ int s_next;
     const int n_items = work_item_count(a);
     int item = blockIdx.x;
-    if constexpr ((CYL && !kCylPersistentBwd) || (!CYL && BLOCKING && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
+    if constexpr ((CYL && !kCylPersistentBwd) || (!CYL && BLOCKING && !LEAN && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
         if (item >= n_items) return;
         if constexpr (CYL && !BLOCKING) {
             if (a.split == 3) {                      // the heliostats that aim at a cylinder first (see art_trace_fwd)
@@ -2425,8 +2531,8 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThre
     const bool reverse = a.reverse_bwd != 0;
     while (item < n_items) {
         if constexpr (LEAN)
-            trace_bwd_item_lean<INTERLEAVED, ATOMIC_OUT>(a, grad_flux, grad_origins, grad_normals, decode_work_item(a, item, reverse),
-                                                         work_counter, &s_next);
+            trace_bwd_item_lean<INTERLEAVED, ATOMIC_OUT, BLOCKING>(a, grad_flux, grad_origins, grad_normals,
+                                                                   decode_work_item(a, item, reverse), work_counter, &s_next, prim_slabs);
         else
             trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, prim_slabs,
                                                                    decode_work_item(a, item, reverse), work_counter, &s_next);
@@ -2957,6 +3063,17 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             cfg.exact_pblock = true;
             if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanFwdThreads;
         }
+        // Blocking on, planar receivers: the heliostats WITH candidate rectangles take the lean ray body with the soft mask
+        // (trace_fwd_item_lean<.., BLOCKING>; 768-thread persistent workgroups) instead of the generic item.
+        const bool lean_block = blocking && lean_ok && T > 0 && Tc == 0 && env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
+        if (lean_block) {
+            cfg.block = kLeanBlockFwdThreads;
+            cfg.exact_pblock = true;
+            if (env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {       // (facet-sized items: slower with the generic body, faster here)
+                cfg.facet_points = (int)facet_points;
+                if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanBlockFwdThreads;
+            }
+        }
         window_geometry(a, cfg, cfg.p_block, cfg.p_block_fixed);
         // Field-scale prediction (per-target bitmaps, a handful of samples per point, whole heliostats per item): items are
         // GROUPS of consecutive heliostats that share a window and its flush (trace_fwd_item_field).  Group size by the round
@@ -2995,7 +3112,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // exits at once (the type is only known on the device)
 #define ART_LAUNCH_FWD(IL, CY, BL, LN)                                                                           \
         do {                                                                                                     \
-            const int64_t blocks = (CY || (BL && !kBlockingPersistentFwd)) ? items : persistent_blocks;                \
+            const int64_t blocks = (CY || (BL && LN == 0 && !kBlockingPersistentFwd)) ? items : persistent_blocks;     \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL, LN>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             const FwdLaunch launch = {a, flux, counts, work_counters[CY ? 1 : 0]};                               \
@@ -3015,6 +3132,8 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             else if (lean && field_groups) ART_LAUNCH_FWD(false, false, false, 2);
             else if (lean && il) ART_LAUNCH_FWD(true, false, false, 1);
             else if (lean) ART_LAUNCH_FWD(false, false, false, 1);
+            else if (lean_block && il) ART_LAUNCH_FWD(true, false, true, 1);
+            else if (lean_block) ART_LAUNCH_FWD(false, false, true, 1);
             else ART_LAUNCH_FWD_TYPE(false);
         }
         if (planar_done) a.split = 3;                // the cylinder launch of a mixed tower: cylinder heliostats first
@@ -3107,17 +3226,23 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     if (cfg.variant == 0) {
         // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, one block per facet
         const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0;
+        // ... and with blocking on, the heliostats WITH candidate rectangles take the same body with the soft mask and its
+        // adjoint (trace_bwd_item_lean<.., BLOCKING>) instead of the generic item
+        const bool lean_block = blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0 &&
+                                env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
         size_t perm_bytes = 0;
-        if (lean) {
+        if (lean || lean_block) {
             cfg.block = kLeanBwdThreads;
             cfg.exact_pblock = true;
-            cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
-            if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
+            if (lean || env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {
+                cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
+                if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
+            }
             // edge points packed into the block's last waves (trace_bwd_item_lean): the permutation lives behind the window
             a.pack_edge = std::min(std::max(env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
             if (a.pack_edge != 0) {
                 perm_bytes = 2 * kPackPoints;
-                cfg.tile_cap = std::min<int>(cfg.tile_cap, (int)((160 * 1024 - 1408 - perm_bytes - 8) / 4) / 64 * 64);
+                cfg.tile_cap = std::min<int>(cfg.tile_cap, (int)((160 * 1024 - 1408 - (lean_block ? kLeanBlockBwdStatic : 0) - perm_bytes - 8) / 4) / 64 * 64);
             }
         }
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
@@ -3211,7 +3336,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         }
 #define ART_LAUNCH_BWD(IL, AT, CY, BL, LN)                                                                       \
         do {                                                                                                     \
-            const int64_t blocks = ((CY && !kCylPersistentBwd) || (!CY && BL && !kBlockingPersistentBwd)) ? items : persistent_blocks; \
+            const int64_t blocks = ((CY && !kCylPersistentBwd) || (!CY && BL && !LN && !kBlockingPersistentBwd)) ? items : persistent_blocks; \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL, LN>),\
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = stream_work_counters(stream);                                               \
@@ -3233,6 +3358,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             if (blocking) ART_LAUNCH_BWD_BL(CY, true, false); else ART_LAUNCH_BWD_BL(CY, false, false);          \
         } while (0)
         if (T > 0 && Tc == 0 && lean) ART_LAUNCH_BWD_BL(false, false, true);
+        else if (lean_block) ART_LAUNCH_BWD_BL(false, true, true);
         else
         if (T > 0 && !planar_done) ART_LAUNCH_BWD_TYPE(false);
         if (planar_done) a.split = 3;
