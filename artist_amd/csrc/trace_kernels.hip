@@ -1008,6 +1008,15 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
     // ---- phase 1: window (as in the generic item) ------------------------------------------------
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+    ART_TIMELINE(1);
+#ifdef ART_DEBUG_TIMELINE
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();       // shader clock
+#endif
     if (tid < 3) s_cnt[tid] = 0;
     const int pf = (a.win_sample != 0 && p1 - p0 > (int)blockDim.x) ? window_sample_point(p0, p1) : p0 + tid;
     FirstPoint fp = {{0.0f, 0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f, 0.0f}, 0.0f, 0.0f};
@@ -1023,6 +1032,13 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
+    ART_TIMELINE(2);
+#ifdef ART_DEBUG_TIMELINE      // (lean items: slots 3, 4 hold the item's stray rays | un-park events, and its window (tw, th, npass))
+    __shared__ unsigned s_dbg[2];
+    if (tid < 2) s_dbg[tid] = 0u;
+    unsigned dbg_strays = 0u, dbg_unparks = 0u;
+    if (tid == 0 && bid < kTimelineSlots) g_timeline[8 * bid + 4] = ((unsigned long long)win.npass << 40) | ((unsigned long long)win.tw << 20) | (unsigned)win.th;
+#endif
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     // (Packing the edge points into the block's last waves, which takes 8 % off the backward kernel, was measured here too:
     //  3.25 -> 3.32 ... 3.43 ms for margins of 1/4 ... 3/4 of the scatter pad - a stray costs this kernel its atomics, which
@@ -1047,7 +1063,14 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
     // largest byte address a ray of this pass can produce for its LOW row; rays outside the window are clamped into
     // [cell 0, that] and add zero there (an empty window: onto cell 0 - the tile is cleared, so that is a legal place too)
-    const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2)) : lds_base;
+    [[maybe_unused]] const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (pth - 2) + win.tw - 2)) : lds_base;
+    // A ray outside the window (a stray, or one that misses the target) still issues its four adds - of zero.  Clamped onto the
+    // window's first / last cell (round 2) every such lane of a wave hit the SAME four cells, and atomics on one address are
+    // served lane after lane; each lane now adds its zeros to cells of its own (2 lane, 2 lane + 1 and the two above them:
+    // inside every window's allocation, which is never smaller than 1024 cells).  Worth ~1 % where a tenth of the rays miss
+    // (the far heliostats of the metric field; same-box A/B 0.546 -> 0.541 ms at 125 heliostats, 3.315 -> 3.294 at 1000).
+    [[maybe_unused]] const float own_cell_f = lds_base + (float)(8 * lane);
+    const unsigned tw4p = win_ok != 0ull ? tw4 : 0u;           // (a degenerate window may be one long row: its masked rays stay in cells 0 .. 127)
     unsigned n_valid = 0;
     [[maybe_unused]] unsigned n_int = 0, n_free = 0;      // (blocking) rays with I > 0 / with blocked < 1e-3
     if (!first) {
@@ -1068,12 +1091,21 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 const float wa = chu * Is, wb = clu * Is;                                      // the same integers reach the bitmap
                 unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;   // flat row iu + 1, flipped
                 unsigned long long* row_lo = row_hi + a.W;
+#ifdef ART_ABLATE_NO_STRAY_ATOMICS     // diagnostic build (wrong bitmap): everything but the four atomics
+                unsigned long long q1 = cell_to_accum(cle * wa), q2 = cell_to_accum(che * wa), q3 = cell_to_accum(che * wb), q4 = cell_to_accum(cle * wb);
+                asm volatile("" ::"v"(row_hi), "v"(row_lo), "v"(q1), "v"(q2), "v"(q3), "v"(q4));
+#else
                 atomicAdd(row_hi, cell_to_accum(cle * wa)); atomicAdd(row_hi + 1, cell_to_accum(che * wa));
                 atomicAdd(row_lo + 1, cell_to_accum(che * wb)); atomicAdd(row_lo, cell_to_accum(cle * wb));
+#endif
             }
         }
         m_parked = 0ull;
     };
+    // (Round 3 measured an alternative to un-parking whenever a lane that holds a parked ray strays again - every ~3 strays,
+    //  the strays come from the same few lanes: the parked ray MOVED to a lane of the wave that held none (v_readlane + a
+    //  select), so that a wave un-parked once per ~64 strays.  590 -> 30 un-park events per item of a far heliostat, and the
+    //  item took 147 instead of 135 us: the un-park events were never the cost - tools/timeline.sh)
     unsigned po1 = 0u, po2 = 0u, po3 = 0u, po4 = 0u, pq1 = 0u, pq2 = 0u, pq3 = 0u, pq4 = 0u;   // the previous ray's adds
     float ptbe = 0.0f, ptbu = 0.0f;
     for (int p = p0 + tid; p < p1; p += blockDim.x) {
@@ -1121,9 +1153,13 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
             const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
             n_valid += __popcll(m_valid);
+#ifdef ART_CLAMP_MASKED_RAYS          // A/B build: round 2's address rule (masked rays clamped onto the window's first / last cell)
             const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
+#else
+            const float af = select_mask(m_in, fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), own_cell_f);
+#endif
             const unsigned addr_lo = (unsigned)af;
-            const unsigned addr_up = addr_lo + tw4;                            // flat row iu + 1
+            const unsigned addr_up = addr_lo + tw4p;                           // flat row iu + 1
             float ahk = ah;                                                    // the direction cosine, attenuated by the blocking mask
             if constexpr (BLOCKING) {
                 // soft mask over this heliostat's rectangles, for every ray - also those that miss the target
@@ -1174,6 +1210,9 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 if (!first) m_out = 0ull;
                 else if (win.npass > 1)                         // banded sweep: only what no band holds
                     m_out &= ~(win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(tbu - u0f) <= uthm2_bits));
+#ifdef ART_DEBUG_TIMELINE
+                if (lane == 0) { dbg_strays += __popcll(m_out); dbg_unparks += (m_out & m_parked) ? 1u : 0u; }
+#endif
                 if (m_out & m_parked) unpark();
                 pk_be = select_mask(m_out, be, pk_be); pk_bu = select_mask(m_out, bu, pk_bu); pk_ah = select_mask(m_out, ahk, pk_ah);
                 m_parked |= m_out;
@@ -1260,6 +1299,9 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     __syncthreads();
     unsigned next_item = 0u;
     if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
+#ifdef ART_DEBUG_TIMELINE       // (lean items: slot 7 = start of the flush)
+    if (first) ART_TIMELINE(7);
+#endif
 
     // ---- phase 3: flush ------------------------------------------------------------------------
     for (int row = wave; row < pth; row += nwaves) {
@@ -1277,6 +1319,14 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();
   }
+    ART_TIMELINE(6);       // (diagnostic build: the flush is not stamped apart from the trace here)
+#ifdef ART_DEBUG_TIMELINE
+    if (lane == 0) { atomicAdd(&s_dbg[0], dbg_strays); atomicAdd(&s_dbg[1], dbg_unparks); }
+    __syncthreads();
+    if (tid == 0 && bid < kTimelineSlots) {
+        g_timeline[8 * bid + 3] = ((unsigned long long)s_dbg[1] << 32) | s_dbg[0];
+    }
+#endif
     if (tid < (BLOCKING ? 3 : 2) && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
@@ -1351,9 +1401,10 @@ __device__ __forceinline__ void trace_fwd_item_field(const TraceArgs& a, unsigne
         const float lds_base = (float)(unsigned)(size_t)(lds_u32*)tile;
         const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
         const unsigned twm2_bits = f32_bits((float)(win.tw - 2)), thm2_bits = f32_bits((float)(win.th - 2));
-        const unsigned tw4 = 4u * (unsigned)win.tw;
         const unsigned long long win_ok = (win.tw >= 2 && win.th >= 2) ? ~0ull : 0ull;
-        const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (win.th - 2) + win.tw - 2)) : lds_base;
+        const unsigned tw4 = win_ok != 0ull ? 4u * (unsigned)win.tw : 0u;
+        [[maybe_unused]] const float addr_hi_f = win_ok != 0ull ? lds_base + (float)(4 * (win.tw * (win.th - 2) + win.tw - 2)) : lds_base;
+        [[maybe_unused]] const float own_cell_f = lds_base + (float)(8 * lane);      // masked rays add their zeros here (see trace_fwd_item_lean)
         // ---- phase 2: trace every heliostat of the run (the ray body of trace_fwd_item_lean) ---------------------------------
         unsigned long long m_parked = 0ull;
         float pk_be = 0.0f, pk_bu = 0.0f, pk_ah = 0.0f;
@@ -1414,7 +1465,11 @@ __device__ __forceinline__ void trace_fwd_item_field(const TraceArgs& a, unsigne
                     const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
                     const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
                     n_valid += __popcll(m_valid);
+#ifdef ART_CLAMP_MASKED_RAYS
                     const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
+#else
+                    const float af = select_mask(m_in, fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), own_cell_f);
+#endif
                     const unsigned addr_lo = (unsigned)af;
                     const unsigned addr_up = addr_lo + tw4;
                     const float Is = select_or_zero(m_in, fabsf(ah) * kS);
@@ -2196,9 +2251,17 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
+#ifdef ART_DEBUG_TIMELINE
+    const int bid = item.h * a.n_pblocks * a.n_rchunks + item.pblock * a.n_rchunks + item.r0 / max(a.r_chunk, 1);
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+    ART_TIMELINE(1);
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
+    ART_TIMELINE(2);
     unsigned next_item = 0u;
     [[maybe_unused]] PrimSums prim_sums = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};   // (blocking) this wave's rectangle gradients
     const float kI = (a.mag * a.k_ext) * a.k_refl;
@@ -2265,6 +2328,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     if (win_ok == 0ull && tid < 2) gtile[tid] = 0.0f;
 #endif
     __syncthreads();
+    if (first) { ART_TIMELINE(3); ART_TIMELINE(4); }      // (diagnostic build: window + edge partition | staging | trace)
 
     const float pu0f = (float)pu0;
     const unsigned thm2_bits = f32_bits((float)(pth - 2));
@@ -2473,6 +2537,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();
   }
+    ART_TIMELINE(5); ART_TIMELINE(6);
     if constexpr (BLOCKING) {          // the waves' rectangle gradients in wave order, then this item's slab (see trace_bwd_item)
         for (int w = 0; w < nwaves; ++w) {
             if (wave == w && lane < 2 * n_prims) {

@@ -44,7 +44,23 @@ def stats(name, pat, depth):
     if span is None:
         print(name, "ring loop not found")
         return
-    ins = [l.split()[0] for l in lines[span[0]:span[1]] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+    body = [l for l in lines[span[0]:span[1]] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+    ins = [l.split()[0] for l in body]
+    # "slow class" of DESIGN.md section 4.0: a VALU instruction with a scalar-register or literal operand, or one of the
+    # opcodes that take a second pass through the pipe whatever their operands
+    slow_ops = ("v_trunc", "v_cvt", "v_med3", "v_max", "v_min", "v_cmp", "v_mad_u32", "v_lshl_add", "v_or3", "v_pk_", "v_cndmask",
+                "v_rcp", "v_rsq", "v_sqrt", "v_readlane", "v_readfirstlane")
+    n_slow_op = n_slow_operand = 0
+    for l in body:
+        op = l.split()[0]
+        if not op.startswith("v_"):
+            continue
+        operands = l.split(";")[0].split(None, 1)[1] if len(l.split(";")[0].split(None, 1)) > 1 else ""
+        srcs = [x.strip() for x in operands.split(",")][1:]
+        if op.startswith(slow_ops):
+            n_slow_op += 1
+        elif any(re.match(r"^-?\|?(s\d+|s\[|vcc|exec|0x|-?\d+\.\d|[0-9a-fx]+$)", x) and not re.match(r"^-?[0-4]$|^-?(0\.5|1\.0|2\.0|4\.0)$|^0$", x) for x in srcs):
+            n_slow_operand += 1
     c = collections.Counter()
     for k in ins:
         if k.startswith("v_"):
@@ -71,8 +87,8 @@ def stats(name, pat, depth):
         for k, v in hist.most_common():
             print(f"    {k:28s} {v / depth:6.2f}")
     print(f"{name} (ring of {depth}): per ray " + ", ".join(f"{k} {v / depth:.1f}" for k, v in sorted(c.items())) +
-          f"; v_mov {sum(k.startswith('v_mov') for k in ins) / depth:.1f}, scratch in loop {sum(k.startswith('scratch') for k in ins)}; {meta}")
+          f"; slow-class opcodes {n_slow_op / depth:.1f}, scalar / literal operands {n_slow_operand / depth:.1f}; v_mov {sum(k.startswith('v_mov') for k in ins) / depth:.1f}, scratch in loop {sum(k.startswith('scratch') for k in ins)}; {meta}")
 
 
-stats("forward lean (interleaved)", "_ZN3art20trace_fwd_lds_kernelILb1ELb0ELb0ELb1EEEv", ring_depth("ART_RING_DEPTH"))
+stats("forward lean (interleaved)", "_ZN3art20trace_fwd_lds_kernelILb1ELb0ELb0ELi1EEEv", ring_depth("ART_RING_DEPTH"))
 stats("backward lean (interleaved)", "_ZN3art20trace_bwd_lds_kernelILb1ELb0ELb0ELb0ELb1EEEv", ring_depth("ART_RING_DEPTH_BWD"))

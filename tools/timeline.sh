@@ -14,6 +14,6 @@ exit 0
 fi
 H=${2:-1000}
 ARTIST_HIP_LIB=$PWD/artist_amd/libtimeline.so ART_TIMELINE_OUT=/tmp/timeline.bin ART_TIMELINE_OUT_BWD=/tmp/timeline_bwd.bin \
-  timeout -k 10 300 python bench.py --heliostats $H --steps 2 --warmup 1 --no-cpu-baseline > /dev/null
-echo "forward:"; python tools/timeline_report.py /tmp/timeline.bin
+  timeout -k 10 300 python bench.py --heliostats $H --steps 2 --warmup 1 --no-cpu-baseline --no-check > /dev/null
+echo "forward:"; if [ "${ARTIST_HIP_LEAN:-1}" = 1 ]; then python tools/timeline_lean_report.py /tmp/timeline.bin; else python tools/timeline_report.py /tmp/timeline.bin; fi
 echo "backward (phases: window, staging of dL/dflux, -, trace, -):"; python tools/timeline_report.py /tmp/timeline_bwd.bin

@@ -43,3 +43,15 @@ print(f"  shader clock over a workgroup (s_memtime / s_memrealtime): median {np.
 busy = total.sum() / 1e3
 span = (t[:, 5].max() - t[:, 0].min()) / 1e6
 print(f"  CU occupancy by stamped time: {busy / (span * len(np.unique(place))):.3f}")
+# item duration against its place in the queue (slot = item index): systematic differences would let the queue start with the long items
+idx = np.nonzero(np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8)[:, 1] > 0)[0]
+if len(idx) >= 20:
+    dec = np.array_split(np.argsort(idx), 10)
+    print("      item duration by decile of the queue position (us): " + " ".join(f"{total[d].mean():.0f}" for d in dec))
+    print(f"      item duration: mean {total.mean():.1f} us, std {total.std():.1f}, min {total.min():.1f}, max {total.max():.1f}")
+    print("      shader clock by decile (MHz): " + " ".join(f"{mhz[d].mean():.0f}" for d in dec))
+    start = (t[:, 0] - t[:, 0].min()) / 1e3
+    print("      item start by decile (us after the first): " + " ".join(f"{start[d].mean():.0f}" for d in dec))
+    trace_d = dur[:, 3] / 1e3
+    print("      trace phase by decile (us): " + " ".join(f"{trace_d[d].mean():.0f}" for d in dec))
+    print("      window phase by decile (us): " + " ".join(f"{(dur[:, 0] / 1e3)[d].mean():.1f}" for d in dec))
