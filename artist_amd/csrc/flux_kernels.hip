@@ -275,7 +275,22 @@ __device__ __forceinline__ void tap_range(float scale, float centre, int n, int 
 // of a row by its 64 pixels - they are computed once per tile into LDS - and the sum factorises into a horizontal
 // pass (4 global loads per output row and column, kept in LDS) and a vertical pass (4 LDS reads per pixel).  A bitmap
 // whose crop scale needs more than four taps per axis (scale < ~0.6) takes the per-pixel form.
-constexpr int kTileX = 64, kTileY = 32, kTaps = 4, kTileRows = 64;
+#ifndef ART_COM_UNROLL         // float4 loads in flight per thread in the centre-of-mass pass / rows in flight in the crop passes
+#define ART_COM_UNROLL 4
+#endif
+#ifndef ART_CROP_UNROLL
+#define ART_CROP_UNROLL 4
+#endif
+#ifndef ART_CROP_TILE_Y        // (build-time knobs of the A/B builds: tools/build_flux_variant.sh)
+#define ART_CROP_TILE_Y 32
+#endif
+#ifndef ART_CROP_TILE_ROWS
+#define ART_CROP_TILE_ROWS 64
+#endif
+#ifndef ART_CROP_ROW_UNROLL
+#define ART_CROP_ROW_UNROLL 4
+#endif
+constexpr int kTileX = 64, kTileY = ART_CROP_TILE_Y, kTaps = 4, kTileRows = ART_CROP_TILE_ROWS, kRowUnroll = ART_CROP_ROW_UNROLL;
 __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* __restrict__ dims, const float* __restrict__ com,
                                                                   const float* __restrict__ gcom,
                                                                   const float* __restrict__ grad_out, int Hh, int W,
@@ -326,16 +341,16 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     //  that the loads of several rows are in flight together: with a branch per tap every load was waited for in turn
     //  and a workgroup took 26 us for 6 000 loads)
     const int xr = in_x ? 1 : 0;
-    for (int r = threadIdx.x / kTileX; r <= ihi - ilo; r += 4 * (256 / kTileX)) {
-        float v[4];
+    for (int r = threadIdx.x / kTileX; r <= ihi - ilo; r += kRowUnroll * (256 / kTileX)) {
+        float v[kRowUnroll];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < kRowUnroll; ++q) {
             const int rr = min(r + q * (256 / kTileX), ihi - ilo);
             const float* __restrict__ row = g + (int64_t)(ilo + rr) * W;
             v[q] = ((row[c0 * xr] * wx0 + row[c1 * xr] * wx1) + row[c2 * xr] * wx2) + row[c3 * xr] * wx3;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < kRowUnroll; ++q) {
             const int rr = r + q * (256 / kTileX);
             if (rr <= ihi - ilo) s_t[rr][tx] = in_x ? v[q] : 0.0f;
         }
@@ -513,7 +528,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(
             int x4 = threadIdx.x % W4, y = threadIdx.x / W4;
             const int dx = blockDim.x % W4, dy = blockDim.x / W4;
             const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f);
-#pragma unroll 4
+#pragma unroll ART_COM_UNROLL
             for (int k = threadIdx.x; k < Hh * W4; k += blockDim.x) {
                 const float4 v = f4[k];
                 const int x = 4 * x4;
@@ -548,7 +563,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(
     if ((int)blockDim.x % W == 0) {                 // a thread owns one column (the per-thread summation order is unchanged)
         const int j = threadIdx.x % W, di = blockDim.x / W;
         const CropColumn col = crop_column(m, j);
-#pragma unroll 4      // four rows' taps in flight: the loop is a chain of L2 round trips otherwise
+#pragma unroll ART_CROP_UNROLL      // four rows' taps in flight: the loop is a chain of L2 round trips otherwise
         for (int i = threadIdx.x / W; i < Hh; i += di) {
             float v00, v01, v10, v11, ty;
             const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
@@ -597,7 +612,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_bwd_kernel(
     if ((int)blockDim.x % W == 0) {
         const int j = threadIdx.x % W, di = blockDim.x / W;
         const CropColumn col = crop_column(m, j);
-#pragma unroll 4
+#pragma unroll ART_CROP_UNROLL
         for (int i = threadIdx.x / W; i < Hh; i += di) {
             float v00, v01, v10, v11, ty;
             const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);

@@ -1799,6 +1799,46 @@ def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_BLOCK_LEAN="0"), dict(ARTIST_HIP_BLOCK_FACETS="0"), dict(ARTIST_HIP_BLOCKING_SPLIT="0"),
+                                   dict(ARTIST_HIP_BLOCK_LEAN="0", ARTIST_HIP_BLOCKING_SPLIT="0"), dict(ARTIST_HIP_FWD_BLOCKS="1"),
+                                   dict(ARTIST_HIP_FWD_BLOCKS="1", ARTIST_HIP_BLOCK_LEAN="0")])
+def test_blocking_bodies_agree(golden, monkeypatch, knobs):
+    """Blocking on planes runs the heliostats WITH candidate rectangles through the lean ray body with the soft mask (round 3;
+    ARTIST_HIP_BLOCK_LEAN=0: the generic item of round 2), in facet-sized items or not, next to a lean launch for the
+    heliostats without candidates or in one launch, with the samples in chunks or in one item (ARTIST_HIP_FWD_BLOCKS=1:
+    the launches of a split call).  Same rays, same mask: bitmaps within the two bodies' rounding of the four weights
+    (1e-6; the same bits where only the items change), ray counters equal, gradients - the rectangles' included - within 2e-6."""
+    from artist_amd import trace_rays
+    d = golden("mid_blocking")
+
+    def run():
+        inp = trace_inputs(d)
+        blk = blocking_inputs(d)
+        leaves = [inp["origins"].requires_grad_(True), inp["normals"].requires_grad_(True)]
+        blk = {k: (v.clone().requires_grad_(True) if k in ("corners", "spans", "normals") else v) for k, v in blk.items()}
+        leaves += [blk["corners"], blk["spans"], blk["normals"]]
+        flux, fac = trace_rays(**inp, blocking=blk)[:2]
+        grads = torch.autograd.grad(flux, leaves, t(d["loss_weights"]))
+        return [n(flux), n(fac)] + [n(g) for g in grads]
+
+    base = run()
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    other = run()
+    same_body = "ARTIST_HIP_BLOCK_LEAN" not in knobs
+    if same_body:
+        np.testing.assert_array_equal(other[0], base[0])
+    else:
+        assert rel_l2(other[0], base[0]) < 1e-6, rel_l2(other[0], base[0])
+    np.testing.assert_array_equal(other[1], base[1])
+    for got, ref in zip(other[2:], base[2:]):
+        assert np.isfinite(got).all()
+        assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
+    again = run()                                     # every variant repeats itself bit for bit
+    for x, y in zip(other, again):
+        np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("name", ["small_deg3", "mid_256", "mid_cyl", "mid_blocking"])
 def test_flux_is_bit_reproducible(golden, name):
     """SURVEY.md section 5 (race surface): the reference needs torch.use_deterministic_algorithms(True) for a stable
