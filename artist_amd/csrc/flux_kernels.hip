@@ -281,7 +281,7 @@ __device__ __forceinline__ void tap_range(float scale, float centre, int n, int 
 #ifndef ART_CROP_UNROLL
 #define ART_CROP_UNROLL 4
 #endif
-#ifndef ART_CROP_TILE_Y        // (build-time knobs of the A/B builds: tools/build_flux_variant.sh)
+#ifndef ART_CROP_TILE_Y        // (build-time knobs of the A/B builds: tools/build_obj_variant.sh)
 #define ART_CROP_TILE_Y 32
 #endif
 #ifndef ART_CROP_TILE_ROWS

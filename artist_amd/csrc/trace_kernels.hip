@@ -2279,6 +2279,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const bool packed = a.pack_edge != 0 && win.npass == 1 && n_pts <= kPackPoints && n_pts <= kPackTrips * (int)blockDim.x &&
                         win.tw >= 2 && win.th >= 2;
     if (packed) pack_edge_points(a, pl, inc, org, nrm, p0, n_pts, win, a.pack_edge, s_edge, perm);
+    ART_TIMELINE(5);         // (diagnostic build: end of the edge partition; slot 5 is read out of order by tools/timeline_report.py)
     const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
     const float lds_base = (float)(unsigned)(size_t)(lds_f32*)gtile;
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
@@ -2289,6 +2290,9 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const bool first = pass == 0;
     if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
     {   // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped: see trace_bwd_item
+        // (four rows per wave in flight: 6-8 us per item, tools/timeline.sh.  Eight rows measured 3.65 against 3.53 ms for the
+        //  kernel, twelve 4.4 - the batch's registers are allocated on top of the ray loop's; as a real call the batch faulted
+        //  on the dynamic-LDS table the compiler builds for callees, and was not pursued)
         struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;
         const int64_t dg = (int64_t)nwaves * a.W;
@@ -2537,7 +2541,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();
   }
-    ART_TIMELINE(5); ART_TIMELINE(6);
+    ART_TIMELINE(6);
     if constexpr (BLOCKING) {          // the waves' rectangle gradients in wave order, then this item's slab (see trace_bwd_item)
         for (int w = 0; w < nwaves; ++w) {
             if (wave == w && lane < 2 * n_prims) {

@@ -55,3 +55,7 @@ if len(idx) >= 20:
     trace_d = dur[:, 3] / 1e3
     print("      trace phase by decile (us): " + " ".join(f"{trace_d[d].mean():.0f}" for d in dec))
     print("      window phase by decile (us): " + " ".join(f"{(dur[:, 0] / 1e3)[d].mean():.1f}" for d in dec))
+    if (rec[:, 5] > rec[:, 2]).all() and (rec[:, 5] < rec[:, 3]).all():      # lean backward item: slot 5 = end of the edge partition
+        pk = (rec[:, 5].astype(np.int64) - rec[:, 2].astype(np.int64)) * 10 / 1e3
+        st = (rec[:, 3].astype(np.int64) - rec[:, 5].astype(np.int64)) * 10 / 1e3
+        print(f"      lean backward item: edge partition median {np.median(pk):.2f} us, staging of dL/dflux median {np.median(st):.2f} us")
