@@ -1325,6 +1325,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     __syncthreads();
     if (tid == 0 && bid < kTimelineSlots) {
         g_timeline[8 * bid + 3] = ((unsigned long long)s_dbg[1] << 32) | s_dbg[0];
+        g_timeline[8 * bid + 5] = __builtin_amdgcn_s_memtime() - clk0;             // shader clocks of the item
     }
 #endif
     if (tid < (BLOCKING ? 3 : 2) && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
@@ -2885,6 +2886,8 @@ static int resident_workgroups()
             cus <= 0)
             cus = 256;
         n = cus;
+        const int cap = env_int("ARTIST_HIP_WORKGROUPS", 0);      // (diagnostic: fewer persistent workgroups than CUs, tools/timeline.sh)
+        if (cap > 0 && cap < n) n = cap;
     }
     return n;
 }
