@@ -11,6 +11,9 @@
 // All of it is HBM-bound elementwise / reduction work on [B,Hh,W] fp32: one read and one write of the bitmaps.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <mutex>
+#include <vector>
 
 #include "launch_common.hpp"
 
@@ -642,6 +645,202 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The fused crop + PixelLoss pair for SMALL batches (one of eight ranks' share of a field: 125 bitmaps on 256 CUs).  One
+// workgroup per bitmap leaves half of the chip idle (42 + 84 us at 125 bitmaps, 40 + 71 at 64).  Here a bitmap's rows are cut
+// into kLossParts = 4 parts and up to four workgroups - as many as still have a CU each - share a bitmap:
+//   flux_com_parts_kernel          grid (P, B): the centre-of-mass sums of each part -> parts[b][v][0..2] (fp64)
+//   flux_crop_pixel_loss_parts_fwd grid (P, B): every workgroup adds the four parts in part order (the same centre in all of
+//                                  them), crops and compares its parts' rows, leaves (sum d^2, sum truth) per part
+//   ..._fwd_final                  one thread per bitmap: the parts in part order -> loss, the record for the backward pass
+//   flux_crop_pixel_loss_parts_bwd grid (P, B): the loss gradient's rows of the cropped gradient and, per part, the sums of the
+//                                  gradient of the centre;  ..._bwd_final: one thread per bitmap adds them.
+// (Kernel boundaries carry the parts from one step to the next.  A "last workgroup adds the parts" ticket was built first: its
+//  device-scope fences write back and invalidate the L2 of every XCD - 0.24 instead of 0.04 ms at 125 bitmaps.)
+// Sums are fixed functions of the data (per-thread order, block tree, parts in order): reproducible from run to run, and the
+// same for P = 1, 2, 4.  They differ from the one-workgroup kernels above in the LAST BITS of the fp64 sums (rows are
+// grouped by part), which is below fp32 output precision except for an occasional last-bit flip
+// (tests/test_gpu_parity.py::test_fused_crop_pixel_loss asserts 1e-6 for this path and identical bits for the other).
+// Scratch: the parts, per (device, stream), allocated by the library on first use (flux_parts_scratch).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLossParts = 4;
+constexpr int kMaxPartBitmaps = 512;
+struct PartScratch { double com[kMaxPartBitmaps][kLossParts][3]; double acc[kMaxPartBitmaps][kLossParts][2]; };
+
+__device__ __forceinline__ void part_rows(int Hh, int v, int& r0, int& r1)
+{
+    r0 = (int)(((int64_t)Hh * v) / kLossParts);
+    r1 = (int)(((int64_t)Hh * (v + 1)) / kLossParts);
+}
+
+__global__ __launch_bounds__(kReduceBlock) void flux_com_parts_kernel(const float* __restrict__ flux, int Hh, int W, int parts_per_wg,
+                                                                    PartScratch* __restrict__ ws)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.y;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    for (int v = blockIdx.x * parts_per_wg; v < (int)(blockIdx.x + 1) * parts_per_wg; ++v) {
+        int r0, r1;
+        part_rows(Hh, v, r0, r1);
+        double s = 0.0, xs = 0.0, ys = 0.0;
+        if ((W & 3) == 0) {
+            const int W4 = W >> 2;
+            const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f) + (int64_t)r0 * W4;
+            const int n = (r1 - r0) * W4;
+#pragma unroll 4
+            for (int k = threadIdx.x; k < n; k += blockDim.x) {
+                const float4 q = f4[k];
+                const int y = r0 + k / W4, x = 4 * (k % W4);
+                s += (double)((q.x + q.y) + (q.z + q.w));
+                xs += (double)((lin11(x, W) * q.x + lin11(x + 1, W) * q.y) + (lin11(x + 2, W) * q.z + lin11(x + 3, W) * q.w));
+                ys += (double)(lin11(y, Hh) * ((q.x + q.y) + (q.z + q.w)));
+            }
+        } else {
+            const int n = (r1 - r0) * W;
+            for (int k = threadIdx.x; k < n; k += blockDim.x) {
+                const float q = f[(int64_t)r0 * W + k];
+                const int y = r0 + k / W, x = k % W;
+                s += (double)q; xs += (double)(lin11(x, W) * q); ys += (double)(lin11(y, Hh) * q);
+            }
+        }
+        s = block_sum(s, s_red); xs = block_sum(xs, s_red); ys = block_sum(ys, s_red);
+        if (threadIdx.x == 0) { ws->com[b][v][0] = s; ws->com[b][v][1] = xs; ws->com[b][v][2] = ys; }
+    }
+}
+
+// the centre of bitmap b from the four parts (part order); every workgroup of the bitmap computes the same three numbers
+__device__ __forceinline__ void com_from_parts(const PartScratch* __restrict__ ws, int b, float& xc, float& yc, float& S)
+{
+    double s = 0.0, xs = 0.0, ys = 0.0;
+    for (int v = 0; v < kLossParts; ++v) { s += ws->com[b][v][0]; xs += ws->com[b][v][1]; ys += ws->com[b][v][2]; }
+    S = (float)s + 1e-8f;
+    xc = (float)(xs / (double)S); yc = (float)(ys / (double)S);
+}
+
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_parts_fwd_kernel(const float* __restrict__ flux,
+                                                                                     const float* __restrict__ dims,
+                                                                                     const float* __restrict__ truth, int Hh, int W,
+                                                                                     float crop_w, float crop_h, int parts_per_wg,
+                                                                                     PartScratch* ws)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.y;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
+    CropMap m;
+    float S;
+    com_from_parts(ws, b, m.xc, m.yc, S);
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.W = W; m.Hh = Hh;
+    for (int v = blockIdx.x * parts_per_wg; v < (int)(blockIdx.x + 1) * parts_per_wg; ++v) {
+        int r0, r1;
+        part_rows(Hh, v, r0, r1);
+        double se = 0.0, sg = 0.0;
+        if ((int)blockDim.x % W == 0) {                 // a thread owns one column
+            const int j = threadIdx.x % W, di = blockDim.x / W;
+            const CropColumn col = crop_column(m, j);
+#pragma unroll 4
+            for (int i = r0 + threadIdx.x / W; i < r1; i += di) {
+                float v00, v01, v10, v11, ty;
+                const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
+                const float t = g[i * W + j];
+                const float d = c - t;
+                se += (double)(d * d); sg += (double)t;
+            }
+        } else {
+            for (int k = r0 * W + threadIdx.x; k < r1 * W; k += blockDim.x) {
+                const int i = k / W, j = k - i * W;
+                float v00, v01, v10, v11, tx, ty;
+                const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
+                const float t = g[k];
+                const float d = c - t;
+                se += (double)(d * d); sg += (double)t;
+            }
+        }
+        se = block_sum(se, s_red); sg = block_sum(sg, s_red);
+        if (threadIdx.x == 0) { ws->acc[b][v][0] = se; ws->acc[b][v][1] = sg; }
+    }
+}
+
+// loss[b] and the record the backward pass reads, from the parts (part order): one thread per bitmap
+__global__ __launch_bounds__(256) void flux_crop_pixel_loss_parts_fwd_final_kernel(const PartScratch* __restrict__ ws, int B,
+                                                                                  float* __restrict__ loss, float* __restrict__ com4)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float xc, yc, S;
+    com_from_parts(ws, b, xc, yc, S);
+    double se = 0.0, sg = 0.0;
+    for (int v = 0; v < kLossParts; ++v) { se += ws->acc[b][v][0]; sg += ws->acc[b][v][1]; }
+    const float sgf = (float)sg;
+    loss[b] = (float)se / sgf;                              // loss.py:312-318
+    com4[4 * b] = xc; com4[4 * b + 1] = yc; com4[4 * b + 2] = S; com4[4 * b + 3] = sgf;
+}
+
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_parts_bwd_kernel(const float* __restrict__ flux,
+                                                                                     const float* __restrict__ dims,
+                                                                                     const float* __restrict__ truth,
+                                                                                     const float* __restrict__ com4,
+                                                                                     const float* __restrict__ grad_loss, int Hh, int W,
+                                                                                     float crop_w, float crop_h, int parts_per_wg,
+                                                                                     PartScratch* ws, float* __restrict__ grad_crop)
+{
+    __shared__ double s_red[16];
+    const int b = blockIdx.y;
+    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
+    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
+    float* __restrict__ gc = grad_crop + (int64_t)b * Hh * W;
+    CropMap m;
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.xc = com4[4 * b]; m.yc = com4[4 * b + 1]; m.W = W; m.Hh = Hh;
+    const float sgf = com4[4 * b + 3], gl = grad_loss[b];
+    for (int v = blockIdx.x * parts_per_wg; v < (int)(blockIdx.x + 1) * parts_per_wg; ++v) {
+        int r0, r1;
+        part_rows(Hh, v, r0, r1);
+        double gx = 0.0, gy = 0.0;
+        if ((int)blockDim.x % W == 0) {
+            const int j = threadIdx.x % W, di = blockDim.x / W;
+            const CropColumn col = crop_column(m, j);
+#pragma unroll 4
+            for (int i = r0 + threadIdx.x / W; i < r1; i += di) {
+                float v00, v01, v10, v11, ty;
+                const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
+                const int k = i * W + j;
+                const float go = gl * (2.0f * (c - g[k])) / sgf;
+                gc[k] = go;
+                gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
+                gy += (double)(go * ((v10 - v00) * (1.0f - col.tx) + (v11 - v01) * col.tx));
+            }
+        } else {
+            for (int k = r0 * W + threadIdx.x; k < r1 * W; k += blockDim.x) {
+                const int i = k / W, j = k - i * W;
+                float v00, v01, v10, v11, tx, ty;
+                const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
+                const float go = gl * (2.0f * (c - g[k])) / sgf;
+                gc[k] = go;
+                gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
+                gy += (double)(go * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
+            }
+        }
+        gx = block_sum(gx, s_red); gy = block_sum(gy, s_red);
+        if (threadIdx.x == 0) { ws->acc[b][v][0] = gx; ws->acc[b][v][1] = gy; }
+    }
+}
+
+// the gradient of the two centre coordinates from the parts (part order), and the centre in the layout the tiled kernel reads
+__global__ __launch_bounds__(256) void flux_crop_pixel_loss_parts_bwd_final_kernel(const PartScratch* __restrict__ ws,
+                                                                                  const float* __restrict__ com4, int B, int Hh, int W,
+                                                                                  float* __restrict__ com3, float* __restrict__ gcom)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double gx = 0.0, gy = 0.0;
+    for (int v = 0; v < kLossParts; ++v) { gx += ws->acc[b][v][0]; gy += ws->acc[b][v][1]; }
+    gcom[2 * b] = (float)(gx * (double)((float)(W - 1) / 2.0f));
+    gcom[2 * b + 1] = (float)(gy * (double)((float)(Hh - 1) / 2.0f));
+    com3[3 * b] = com4[4 * b]; com3[3 * b + 1] = com4[4 * b + 1]; com3[3 * b + 2] = com4[4 * b + 2];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // get_center_of_mass (artist/flux/bitmap.py:12-71): PIXEL coordinates (e, u) of each bitmap's centre of mass,
 // sum_j j f / (sum f + 1e-8) - what FocalSpotLoss (artist/optim/loss.py:124-250) and the kinematics reconstructor's
 // validation (kinematics_reconstructor.py:120) ask of the tracer's bitmaps.  com[b] = (e px, u px, sum + 1e-8).
@@ -837,6 +1036,44 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_kl_loss_bwd_kernel(con
 
 using namespace art;
 
+// Scratch of the part kernels: one PartScratch per (device, stream), allocated on first use and kept.  nullptr when the allocation fails: the callers fall back to one workgroup per bitmap.
+static PartScratch* flux_parts_scratch(hipStream_t stream)
+{
+    struct Entry { int dev; hipStream_t stream; PartScratch* ws; };
+    static std::vector<Entry> table;
+    static std::mutex lock;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> guard(lock);
+    for (const Entry& e : table)
+        if (e.dev == dev && e.stream == stream) return e.ws;
+    PartScratch* ws = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&ws), sizeof(PartScratch)) != hipSuccess) return nullptr;
+    if (hipMemset(ws, 0, sizeof(PartScratch)) != hipSuccess) { (void)hipFree(ws); return nullptr; }
+    table.push_back({dev, stream, ws});
+    return ws;
+}
+
+// Workgroups per bitmap of the fused crop + loss pair: as many of 4 / 2 / 1 as still leave every workgroup a CU of its own
+// (the passes are bound by what ONE CU's texture path delivers: two workgroups on a CU gain nothing and the extra launches
+// cost ~4 us each).  Measured, forward / backward in us (tools/flux_bench.py; 1, 2, 4 workgroups per bitmap): 64 bitmaps
+// 40 / 71, 35 / 57, 22 / 45; 125 bitmaps 42 / 84, 37 / 73, 37 / 74; 180 bitmaps 43 / 98, 63 / 112, 52 / 100; 250 bitmaps
+// 45 / 114, 64 / 128, 66 / 130.  ARTIST_HIP_LOSS_PARTS = 1 / 2 / 4 forces a value (1: the one-workgroup kernels).
+static int loss_workgroups_per_bitmap(int64_t B, int64_t Hh)
+{
+    const char* env = getenv("ARTIST_HIP_LOSS_PARTS");
+    const int forced = env ? atoi(env) : 0;
+    if (B > kMaxPartBitmaps || Hh < kLossParts) return 1;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    int cus = 256;
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+    }
+    return 4 * B <= cus ? 4 : (2 * B <= cus ? 2 : 1);
+}
+
 static bool crop_args_ok(const void* a, const void* b, const void* c, const void* d, int64_t B, int64_t Hh, int64_t W)
 {
     return a && b && c && d && B >= 0 && Hh >= 1 && W >= 1 && Hh <= 65535 && Hh * W <= (int64_t)1 << 30 && B <= 65535;
@@ -895,6 +1132,16 @@ extern "C" int art_flux_crop_pixel_loss_fwd(const float* flux, const float* targ
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!crop_args_ok(flux, target_dims, ground_truth, loss, B, Hh, W) || !centers4) return ART_EINVAL;
     if (B == 0) return ART_OK;
+    const int P = loss_workgroups_per_bitmap(B, Hh);
+    PartScratch* ws = P > 1 ? flux_parts_scratch(stream) : nullptr;
+    if (ws != nullptr) {
+        hipLaunchKernelGGL(flux_com_parts_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux, (int)Hh, (int)W,
+                           kLossParts / P, ws);
+        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_fwd_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux,
+                           target_dims, ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, kLossParts / P, ws);
+        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_fwd_final_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, ws, (int)B,
+                           loss, centers4);
+    } else
     hipLaunchKernelGGL(flux_crop_pixel_loss_fwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
                        ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, loss, centers4);
     ART_HIP(hipGetLastError());
@@ -912,6 +1159,15 @@ extern "C" int art_flux_crop_pixel_loss_bwd(const float* flux, const float* targ
     float* grad_crop = workspace;                      // [B,Hh,W]
     float* com3 = workspace + B * Hh * W;              // [B,3]
     float* gcom = com3 + 3 * B;                        // [B,2]
+    const int P = loss_workgroups_per_bitmap(B, Hh);
+    PartScratch* ws = P > 1 ? flux_parts_scratch(stream) : nullptr;
+    if (ws != nullptr) {
+        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_bwd_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux,
+                           target_dims, ground_truth, centers4, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height,
+                           kLossParts / P, ws, grad_crop);
+        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_bwd_final_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, ws,
+                           centers4, (int)B, (int)Hh, (int)W, com3, gcom);
+    } else
     hipLaunchKernelGGL(flux_crop_pixel_loss_bwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
                        ground_truth, centers4, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height, grad_crop, com3,
                        gcom);
