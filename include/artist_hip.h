@@ -18,7 +18,10 @@
  *     trace entry points refuse on all of them until somebody clears it), per (GPU, stream) eight 4-byte work
  *     counters in device memory (zero whenever no launch is using them: the launch's last fetch resets them, so
  *     there is no bound on the number of queued launches), per (host thread, GPU) one side stream + two events
- *     for the second launch of a split call (blocking on / mixed towers); nothing else survives a call;
+ *     for the second launch of a split call (blocking on / mixed towers), per (GPU, stream) 40 KB of device memory
+ *     for the part sums of art_flux_crop_pixel_loss_fwd/_bwd on small batches (allocated by the first such call
+ *     on a stream - which must therefore not be made while the stream is being captured into a graph; the values
+ *     are rewritten by every call that reads them); nothing else survives a call;
  *   - return 0 on success, a negative ART_E* code otherwise (never throws across the ABI);
  *     art_strerror() maps a code to text;
  *   - outputs are fully written by the callee (zero-filled first where they are accumulators).
@@ -292,7 +295,9 @@ int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B,
  * bitmaps, crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246) followed by PixelLoss
  * (artist/optim/loss.py:251-318; surface_reconstructor.py:575-590, 664-676), as ONE pass per direction: the cropped
  * bitmaps never reach HBM.  Results are bit-identical to art_flux_crop_fwd + art_flux_loss(kind 0) and to their
- * backward calls.
+ * backward calls when a bitmap has a workgroup of its own (B > half the GPU's CUs).  Smaller batches give a bitmap
+ * two or four workgroups (its rows in four parts whose fp64 sums are added in part order): the same numbers up to
+ * the last bits of those sums (< 1e-6 relative in the results), reproducible from run to run.
  *   flux [B,Hh,W], target_dims [B,2], ground_truth [B,Hh,W] (the measured, already cropped flux)
  *   loss [B] out; centers4 [B,4] out (centre of mass x, y, bitmap sum + 1e-8, sum of the measured flux): pass it
  *   back to the backward call.
