@@ -433,8 +433,9 @@ def main():
                          # what binds the kernel (neither of the contract's two roofs): replayed analysis, DESIGN.md 4.0 / 4.1
                          "limiter_note": "not HBM: about two thirds of the kernel are vector issue of the ray arithmetic (reference operation order, "
                                          "no FMA contraction), the rest LDS-atomic, stray-ray and stream stalls - ablation table in DESIGN.md "
-                                         "section 4.4, issue rates and the LDS conflict split in 4.0 (profiles/r02_issue_bench.json, r02_ablation.txt, r03_pmc_lds_conflicts.txt); stated from "
-                                         "profiles/, not measured by this run"},
+                                         "section 4.4, issue rates and the LDS conflict split in 4.0 (profiles/r02_issue_bench.json, r02_ablation.txt, r03_pmc_lds_conflicts.txt); "
+                                         "with all 256 CUs busy the shader clock settles at ~2.0 GHz (2.4 GHz with an eighth of them: an item costs the same cycles at "
+                                         "every load, profiles/r03_clock_vs_load.txt, DESIGN.md 4.2.1); stated from profiles/, not measured by this run"},
             "check": check,
             "sharding_check": sharding,
         }
