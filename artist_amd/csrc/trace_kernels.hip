@@ -976,7 +976,7 @@ __device__ __forceinline__ void pack_edge_points(const TraceArgs& a, const Plane
 // rectangle tables in LDS, a bitmask per point of the rectangles its scatter cone can touch, `keep` = 1 - blocked in the ray's
 // intensity, and three ray counters instead of one (a valid ray can now carry no light: I > 0 needs keep > 0; the blocking
 // factor counts ALL rays with blocked < 1e-3, heliostat_ray_tracer.py:501-503).
-template <bool INTERLEAVED, bool BLOCKING = false>
+template <bool INTERLEAVED, bool BLOCKING = false, bool CYL = false>
 __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* __restrict__ flux, unsigned int* __restrict__ counts,
                                                     const int bid, const WorkItem item, unsigned int* __restrict__ work_counter,
                                                     int* s_next)
@@ -991,12 +991,15 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
 
     const int t = a.target_idx[h];
-    if (!target_in_range(a, t) || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // a bad index, another launch's heliostat (cylinder, blocked) or an empty item
+    static_assert(!(BLOCKING && CYL), "the lean body serves blocking on planes or cylinders without blocking");
+    if (!target_in_range(a, t) || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {   // a bad index, another launch's heliostat (other receiver type, blocked) or an empty item
         if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
-    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
-    const Cyl cy = {};
+    Plane pl = {}; Cyl cy = {};
+    if constexpr (CYL) cy = load_cyl(a.cyl_centers, a.cyl_normals, a.cyl_axes, a.cyl_radii, a.cyl_heights, a.cyl_opening, t - a.T, a.W, a.Hh,
+                                     a.mag, a.k_ext, a.k_refl);
+    else pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     unsigned long long* __restrict__ acc = a.accum + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;   // this bitmap's accumulators
     const float4 inc = a.incident[h];
     int p0, p1;
@@ -1030,7 +1033,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         if (tid < 2) tile[a.tile_cap + tid] = 0u;
     }
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
-    compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
+    compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
     ART_TIMELINE(2);
 #ifdef ART_DEBUG_TIMELINE      // (lean items: slots 3, 4 hold the item's stray rays | un-park events, and its window (tw, th, npass))
@@ -1043,10 +1046,11 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     // (Packing the edge points into the block's last waves, which takes 8 % off the backward kernel, was measured here too:
     //  3.25 -> 3.32 ... 3.43 ms for margins of 1/4 ... 3/4 of the scatter pad - a stray costs this kernel its atomics, which
     //  packing does not remove, and the partition is paid by every item.)
-    const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
+    [[maybe_unused]] const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
     // |I| S = |r.m| * kS for a front-facing ray:  I = ((mag (-a)) k_ext) k_refl  (heliostat_ray_tracer.py:482-487, geometry.py:139)
+    // (cylinders: the parked / splatted number is the ray's intensity I itself, in the generic item's product order, and kS = S)
     const float kI = (pl.mag * pl.k_ext) * pl.k_refl;
-    const float kS = kI * win.scale;
+    const float kS = CYL ? win.scale : kI * win.scale;
     const float lds_base = (float)(unsigned)(size_t)(lds_u32*)tile;         // byte address of cell 0 (a link-time constant)
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw);
     const unsigned twm2_bits = f32_bits((float)(win.tw - 2));               // low pixel column le in [0, tw - 2]
@@ -1072,7 +1076,8 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     [[maybe_unused]] const float own_cell_f = lds_base + (float)(8 * lane);
     const unsigned tw4p = win_ok != 0ull ? tw4 : 0u;           // (a degenerate window may be one long row: its masked rays stay in cells 0 .. 127)
     unsigned n_valid = 0;
-    [[maybe_unused]] unsigned n_int = 0, n_free = 0;      // (blocking) rays with I > 0 / with blocked < 1e-3
+    [[maybe_unused]] unsigned n_int = 0, n_free = 0;      // (blocking, cylinders) rays with I > 0 / (blocking) with blocked < 1e-3
+    [[maybe_unused]] unsigned n_pos = 0;                  // (cylinders) rays with I_angle > 0
     if (!first) {
         const int npx = win.tw * pth;
         for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
@@ -1113,7 +1118,9 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         const float4 n = nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
-        const float numer = plane_numer(pl, o);
+        [[maybe_unused]] float numer = 0.0f;
+        [[maybe_unused]] CylPoint cp = {};
+        if constexpr (CYL) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
         [[maybe_unused]] unsigned pmask = 0u, wmask = 0u;       // rectangles this point's / this wave's rays can touch
         if constexpr (BLOCKING) {
             if (n_prims > 0) {
@@ -1138,21 +1145,33 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             if (__builtin_expect(wave_any(!(fabsf(u) + fabsf(e) <= kSmallAngle)), 0)) m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;           // geometry.py:116-118
-            const unsigned long long m_front = ballot64(ah < 0.0f) & live;
+            float ah, be, bu;
+            unsigned long long m_front, m_valid;
+            if constexpr (CYL) {
+                const CylHit ch = cyl_hit(cy, cp, rx, ry, rz);                 // geometry.py:287-445
+                be = ch.be; bu = ch.bu;
+                ah = (ch.I0 * a.k_ext) * a.k_refl;                             // the ray's intensity (heliostat_ray_tracer.py:482-487)
+                m_valid = ballot64(ch.ok) & live;
+                m_front = m_valid;
+                n_pos += __popcll(m_valid & ballot64(ch.I0 > 0.0f));           // :498-506: rays with I_angle > 0 ...
+                n_int += __popcll(m_valid & ballot64(ah > 0.0f));              // ... and with I > 0
+            } else {
+            ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;                       // geometry.py:116-118
+            m_front = ballot64(ah < 0.0f) & live;
             const float tt = div_noscale(numer, ah);                           // :130-131 (back-facing: masked below)
             const float hx = o.x + rx * tt, hz = o.z + rz * tt;                // :133-136
             const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;   // :148-169
-            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;    // :154-174
-            const float be = pl.wm1 - be0;                                     // :195-197
+            bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;    // :154-174
+            be = pl.wm1 - be0;                                                 // :195-197
+            // :178-184 on the bit patterns: 0 <= x <= hi  <=>  bits(x) <= bits(hi) unsigned (negative, NaN: larger)
+            m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
+            }
             const float tbe = truncf(be), tbu = truncf(bu);                    // heliostat_ray_tracer.py:674-675
             const float che = be - tbe, chu = bu - tbu;                        // :694-700 (exact)
             const float cle = 1.0f - che, clu = 1.0f - chu;                    // == (tbe + 1) - be: both exact
             const float lef = tbe - e0f, luf = tbu - pu0f;                     // window coordinates of the low pixel
-            // :178-184 on the bit patterns: 0 <= x <= hi  <=>  bits(x) <= bits(hi) unsigned (negative, NaN: larger)
-            const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
             const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
-            n_valid += __popcll(m_valid);
+            if constexpr (!CYL) n_valid += __popcll(m_valid);
 #ifdef ART_CLAMP_MASKED_RAYS          // A/B build: round 2's address rule (masked rays clamped onto the window's first / last cell)
             const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
 #else
@@ -1294,6 +1313,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     if (m_parked != 0ull) unpark();
     if (first && lane == 0) {
         if constexpr (BLOCKING) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_valid); atomicAdd(&s_cnt[2], n_free); }
+        else if constexpr (CYL) { atomicAdd(&s_cnt[0], n_int); atomicAdd(&s_cnt[1], n_pos); }
         else { atomicAdd(&s_cnt[0], n_valid); atomicAdd(&s_cnt[1], n_valid); }
     }
     __syncthreads();
@@ -1547,16 +1567,17 @@ constexpr int kLeanBlockFwdThreads = ART_LEAN_BLOCK_FWD_THREADS;   // the lean b
 constexpr int kCylFwdThreads = 1024;             // (768: within the noise of the box, 512: 17 % slower)
 // LEAN: 0 the generic item, 1 trace_fwd_item_lean, 2 trace_fwd_item_field (groups of heliostats, see there)
 template <bool INTERLEAVED, bool CYL, bool BLOCKING, int LEAN = 0>
-__global__ __launch_bounds__(LEAN ? (BLOCKING ? kLeanBlockFwdThreads : kLeanFwdThreads) : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
+__global__ __launch_bounds__(LEAN ? ((BLOCKING || CYL) ? kLeanBlockFwdThreads : kLeanFwdThreads) : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
-    static_assert(!LEAN || (!CYL && (LEAN == 1 || !BLOCKING)), "the lean ray bodies are planar; the field item knows no blocking");
+    static_assert(!LEAN || ((LEAN == 1 || (!BLOCKING && !CYL)) && !(BLOCKING && CYL)),
+                  "the lean body serves planes, planes with blocking, or cylinders; the field item is planar without blocking");
     __shared__ int s_next, s_reverse;
 #ifdef ART_FWD_SINGLE_ITEM   // diagnostic build: one workgroup per item, no loop (A/B against the persistent form)
     constexpr bool single_item = true;
 #else
     // The cylinder and blocking instantiations keep more values alive per ray; inside the persistent loop they spill
     // enough to lose 5-9 % (tools/blocking_bench.py, same-box A/B), so they take one item per workgroup.
-    constexpr bool single_item = CYL || (BLOCKING && LEAN == 0 && !kBlockingPersistentFwd);
+    constexpr bool single_item = (CYL && LEAN == 0) || (BLOCKING && LEAN == 0 && !kBlockingPersistentFwd);
 #endif
     if constexpr (single_item) {
         int item = (int)blockIdx.x;
@@ -1604,7 +1625,7 @@ __global__ __launch_bounds__(LEAN ? (BLOCKING ? kLeanBlockFwdThreads : kLeanFwdT
         if constexpr (LEAN == 2)
             trace_fwd_item_field<INTERLEAVED>(L.a, L.counts, s_reverse != 0 ? work_item_count(L.a) - 1 - item : item, L.work_counter, &s_next);
         else if constexpr (LEAN == 1)
-            trace_fwd_item_lean<INTERLEAVED, BLOCKING>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0),
+            trace_fwd_item_lean<INTERLEAVED, BLOCKING, CYL>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0),
                                                        L.work_counter, &s_next);
         else
             trace_fwd_item<INTERLEAVED, CYL, BLOCKING>(L.a, L.flux, L.counts, item, decode_work_item(L.a, item, s_reverse != 0),
@@ -3138,6 +3159,16 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // Blocking on, planar receivers: the heliostats WITH candidate rectangles take the lean ray body with the soft mask
         // (trace_fwd_item_lean<.., BLOCKING>; 768-thread persistent workgroups) instead of the generic item.
         const bool lean_block = blocking && lean_ok && T > 0 && Tc == 0 && env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
+        // Cylindrical receivers (no blocking): the lean item with the cylinder hit in place of the plane's (trace_fwd_item_lean<..,
+        // false, true>; 768-thread persistent workgroups, facet-sized items) instead of the generic one-item workgroups.  On a mixed
+        // tower this is the cylinder launch beside the planes' lean launch (a.split == 3: the receiver type decides who skips).
+        const bool lean_cyl = !blocking && lean_ok && Tc > 0 && env_int("ARTIST_HIP_CYL_LEAN", 1) != 0;
+        if (lean_cyl) {
+            cfg.block = kLeanBlockFwdThreads;
+            cfg.exact_pblock = true;
+            cfg.facet_points = (int)facet_points;
+            if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanBlockFwdThreads;
+        }
         if (lean_block) {
             cfg.block = kLeanBlockFwdThreads;
             cfg.exact_pblock = true;
@@ -3184,7 +3215,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // exits at once (the type is only known on the device)
 #define ART_LAUNCH_FWD(IL, CY, BL, LN)                                                                           \
         do {                                                                                                     \
-            const int64_t blocks = (CY || (BL && LN == 0 && !kBlockingPersistentFwd)) ? items : persistent_blocks;     \
+            const int64_t blocks = ((CY && LN == 0) || (BL && LN == 0 && !kBlockingPersistentFwd)) ? items : persistent_blocks;     \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_fwd_lds_kernel<IL, CY, BL, LN>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             const FwdLaunch launch = {a, flux, counts, work_counters[CY ? 1 : 0]};                               \
@@ -3209,7 +3240,9 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             else ART_LAUNCH_FWD_TYPE(false);
         }
         if (planar_done) a.split = 3;                // the cylinder launch of a mixed tower: cylinder heliostats first
-        if (Tc > 0) ART_LAUNCH_FWD_TYPE(true);
+        if (Tc > 0 && lean_cyl && il) ART_LAUNCH_FWD(true, true, false, 1);
+        else if (Tc > 0 && lean_cyl) ART_LAUNCH_FWD(false, true, false, 1);
+        else if (Tc > 0) ART_LAUNCH_FWD_TYPE(true);
 #undef ART_LAUNCH_FWD_TYPE
 #undef ART_LAUNCH_FWD
         ART_HIP(hipGetLastError());
