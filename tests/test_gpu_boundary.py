@@ -39,6 +39,48 @@ def test_two_streams_trace_concurrently(golden):
             np.testing.assert_array_equal(n(gn), n(ref_gn))
 
 
+def test_two_streams_share_no_part_sums():
+    """Small batches of the fused crop + pixel-loss pair give a bitmap several workgroups and pass their part sums through
+    library-owned scratch - one per (GPU, stream).  Two streams with DIFFERENT bitmaps, submitted interleaved: every loss and
+    gradient equals the one-stream result bit for bit."""
+    from artist_amd.flux import FluxCropPixelLoss
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    B, Hh, W = 24, 128, 128
+    ys, xs = torch.meshgrid(torch.arange(Hh, device=DEV, dtype=torch.float32), torch.arange(W, device=DEV, dtype=torch.float32), indexing="ij")
+
+    def case(shift):
+        cx = 40 + 40 * torch.rand(B, generator=gen, device=DEV) + shift
+        cy = 40 + 40 * torch.rand(B, generator=gen, device=DEV) - shift
+        flux = torch.exp(-((xs[None] - cx[:, None, None]) ** 2 + (ys[None] - cy[:, None, None]) ** 2) / (2 * 9.0 ** 2)).contiguous()
+        truth = torch.rand((B, Hh, W), generator=gen, device=DEV) + 0.1
+        dims = torch.full((B, 2), 8.0, device=DEV)
+        w = torch.rand(B, generator=gen, device=DEV)
+        return flux, truth, dims, w
+
+    def run(c):
+        flux, truth, dims, w = c
+        f = flux.clone().requires_grad_(True)
+        loss = FluxCropPixelLoss.apply(f, dims, truth, 6.0, 6.0)
+        (loss * w).sum().backward()
+        return loss.detach(), f.grad
+
+    cases = [case(0.0), case(7.0)]
+    refs = [run(c) for c in cases]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    got = [[], []]
+    for rep in range(8):
+        for k, s in enumerate(streams):
+            with torch.cuda.stream(s):
+                got[k].append(run(cases[k]))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for loss, grad in got[k]:
+            np.testing.assert_array_equal(n(loss), n(refs[k][0]))
+            np.testing.assert_array_equal(n(grad), n(refs[k][1]))
+    assert not np.array_equal(n(refs[0][0]), n(refs[1][0]))
+
+
 def test_status_word_is_per_device_and_any_stream_may_clear_it(golden):
     """The status word is one per GPU: a bad target index met by a kernel of stream A makes a trace call on stream B
     refuse, and a caller on stream B can clear it (``check_async_errors`` synchronises the device)."""
