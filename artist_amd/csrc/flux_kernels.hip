@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     __shared__ float s_wx[kTileX][kTaps], s_wy[kTileY][kTaps];
     __shared__ float s_t[kTileRows][kTileX];        // horizontal pass: T[i][x] = sum_q wx[x][q] g[i][j0(x) + q]
     __shared__ int s_wide, s_ilo, s_ihi;
+    __shared__ float s_gy[kTileY];                   // the row's share of the centre-of-mass term (one division per row, not per pixel)
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * kTileX, y0 = blockIdx.y * kTileY;
     const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
             (col ? s_wx[t] : s_wy[t])[q] = o <= hi_i ? tap(col ? m.ix(o) : m.iy(o), p) : 0.0f;
         }
         if (!col && hi_i >= lo_i) { atomicMin(&s_ilo, lo_i); atomicMax(&s_ihi, hi_i); }
+        if (!col) s_gy[t] = gcom[2 * b + 1] * (lin11(p, Hh) - m.yc) / com[3 * b + 2];
     }
     __syncthreads();
     const int ilo = s_ilo, ihi = s_ihi;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     __syncthreads();
     if (!in_x) return;
     const float S = com[3 * b + 2];
-    const float gx = gcom[2 * b] * (lin11(x, W) - m.xc) / S, gyc = gcom[2 * b + 1];
+    const float gx = gcom[2 * b] * (lin11(x, W) - m.xc) / S;
     for (int ty = threadIdx.x / kTileX; ty < kTileY; ty += 256 / kTileX) {
         const int y = y0 + ty;
         if (y >= Hh) break;
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
             const float wy = s_wy[ty][a];
             if (wy != 0.0f) acc += s_t[r0 + a][tx] * wy;      // uniform across the 64 lanes of a row
         }
-        acc += gx + gyc * (lin11(y, Hh) - m.yc) / S;
+        acc += gx + s_gy[ty];
         grad_flux[((int64_t)b * Hh + y) * W + x] = acc;
     }
 }
