@@ -524,12 +524,19 @@ struct SoftHit {
 
 // Plane hit (:315-324) and local coordinates (:328-345), reference operation order, in two steps so that a wave
 // whose rays all pass behind / too close to the rectangle's plane skips the second one.
+// (c0 - o).n of :315-324: a function of the POINT and the rectangle, not of the ray - the lean forward item computes it once per
+// point for the first two rectangles of the wave's mask and hands it to soft_transmittance (same expression, same bits)
+__device__ __forceinline__ float soft_plane_num(const Prim& q, float ox, float oy, float oz)
+{
+    return ((q.c0x - ox) * q.nx + (q.c0y - oy) * q.ny) + (q.c0z - oz) * q.nz;
+}
+
 __device__ __forceinline__ bool soft_plane(const Prim& q, float ox, float oy, float oz, float rx, float ry, float rz,
-                                           SoftHit& s)
+                                           SoftHit& s, bool have_num = false, float num_in = 0.0f)
 {
     s.den = (rx * q.nx + ry * q.ny) + rz * q.nz;
     s.den_safe = fabsf(s.den) < kBlockEps ? (s.den >= 0.0f ? kBlockEps : -kBlockEps) : s.den;
-    const float num = ((q.c0x - ox) * q.nx + (q.c0y - oy) * q.ny) + (q.c0z - oz) * q.nz;
+    const float num = have_num ? num_in : soft_plane_num(q, ox, oy, oz);
     // (the IEEE quotient without the generic sequence's range scaling: |den_safe| >= 1e-12 and |num| is a distance in
     //  metres, so neither operand nor quotient leaves the normal range - bit-identical, see div_noscale)
 #ifdef ART_OLD_SOFT_DIV
@@ -639,20 +646,28 @@ __device__ __forceinline__ unsigned cone_mask(const Prim* __restrict__ prims, co
 
 // exp(-alpha sum sigma) over the rectangles in `wave_mask` (wave-uniform union of the lanes' `mask`); `near` gets
 // the rectangles whose mask this ray actually entered with a gradient (not the rays deep inside one: sigma == 1).
+// (PRE: num0 / num1 = soft_plane_num of the first / second rectangle of wave_mask for this lane's point)
+template <bool PRE = false>
 __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, unsigned wave_mask, unsigned mask,
                                                     float ox, float oy, float oz, float rx, float ry, float rz,
-                                                    unsigned& near)
+                                                    unsigned& near, float num0 = 0.0f, float num1 = 0.0f)
 {
     float sum = 0.0f;
     near = 0u;
 #ifdef ART_ABLATE_BLOCK_STAGE0
     wave_mask = 0u;
 #endif
+    [[maybe_unused]] int it = 0;
     for (unsigned m = wave_mask; m != 0u; m &= m - 1u) {
         const int k = __builtin_ctz(m);
         const Prim q = prims[k];                       // wave-uniform LDS address: broadcast reads
         SoftHit s;
-        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s) && ((mask >> k) & 1u);
+        bool in_front;
+        if constexpr (PRE) {
+            in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s, it < 2, it == 0 ? num0 : num1) && ((mask >> k) & 1u);
+            ++it;
+        } else
+        in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s) && ((mask >> k) & 1u);
 #ifdef ART_ABLATE_BLOCK_STAGE1
         sum += in_front ? 1e-30f : 0.0f; continue;
 #endif

@@ -1130,6 +1130,14 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 wmask = wave_or_mask(pmask, n_prims);
             }
         }
+        [[maybe_unused]] float bnum0 = 0.0f, bnum1 = 0.0f;      // (c0 - o).n of the wave mask's first two rectangles: per point, not per ray
+        if constexpr (BLOCKING) {
+            if (wmask != 0u) {
+                bnum0 = soft_plane_num(s_tab.prim[__builtin_ctz(wmask)], o.x, o.y, o.z);
+                const unsigned rest = wmask & (wmask - 1u);
+                if (rest != 0u) bnum1 = soft_plane_num(s_tab.prim[__builtin_ctz(rest)], o.x, o.y, o.z);
+            }
+        }
         auto carries = [&]() {                       // cold: a cell of the previous ray wrapped (see resolve_carries)
             PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
             resolve_carries(ps, acc, a.W, a.Hh, win.shift);
@@ -1187,7 +1195,11 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 float blocked = 0.0f, keep = 1.0f;
                 if (wmask != 0u) {
                     unsigned near;
+#ifdef ART_BLOCK_NUM_PER_RAY       // A/B build
                     blocked = 1.0f - soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
+#else
+                    blocked = 1.0f - soft_transmittance<true>(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1);
+#endif
                     keep = 1.0f - blocked;
                 }
                 n_free += __popcll(ballot64(blocked < 1e-3f) & live);
@@ -2381,6 +2393,16 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 wmask = wave_or_mask(pmask, n_prims);
             }
         }
+#ifndef ART_BLOCK_NUM_PER_RAY       // the plane numerators of the mask once per point, as in the forward item (A/B build: per ray)
+        [[maybe_unused]] float bnum0 = 0.0f, bnum1 = 0.0f;
+        if constexpr (BLOCKING) {
+            if (wmask != 0u) {
+                bnum0 = soft_plane_num(s_tab.prim[__builtin_ctz(wmask)], o.x, o.y, o.z);
+                const unsigned rest = wmask & (wmask - 1u);
+                if (rest != 0u) bnum1 = soft_plane_num(s_tab.prim[__builtin_ctz(rest)], o.x, o.y, o.z);
+            }
+        }
+#endif
         auto trace_one = [&](const float u, const float e, const unsigned long long live) {
             // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
             // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
@@ -2446,7 +2468,11 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 [[maybe_unused]] unsigned near = 0u;
                 if constexpr (BLOCKING) {
                     if (wmask != 0u) {
+#ifndef ART_BLOCK_NUM_PER_RAY
+                        trans = soft_transmittance<true>(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1);
+#else
                         trans = soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
+#endif
                         g_keep_scale = kIm * (-ah);                           // dI / d(keep) = mag (-a) k_ext k_refl for a ray in use
                         kIm *= 1.0f - (1.0f - trans);                         // keep, with the reference's rounding (blocked = 1 - trans)
                     }
