@@ -342,6 +342,20 @@ struct CylHit {
     bool near, ok;           // root choice; hit && inside the sector
 };
 
+// sqrtf(x), correctly rounded, for 2^-96 <= x < inf (and x = 0): the compiler's own sequence - v_sqrt_f32, then the neighbours
+// below / above tested with one FMA each - without its scaling of tiny arguments and its fix-up of 0 / inf / NaN (15 -> 9
+// instructions).  The cylinder's discriminant carries + 1e-12 and the hit's distance from the axis is the radius.
+__device__ __forceinline__ float sqrt_noscale(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) - 1u);
+    const float su = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+    return s;
+}
+
 // atan2(y, x) for the receiver's azimuth (geometry.py:399): |smaller| / |larger| by div_noscale, atan(a) = a P(a^2) on [0, 1]
 // (degree 8 in a^2, fitted error 6e-9), then the octant.  Within 3.3 ULP of the exact value on 2e6 random pairs - what glibc's
 // float atan2 shows on the same pairs by the same measure (3.2) - in ~26 instructions instead of the library routine's ~60.
@@ -375,7 +389,11 @@ __device__ __forceinline__ CylHit cyl_hit(const Cyl& cy, const CylPoint& p, floa
     h.b = 2.0f * (p.ox * h.dx + p.oy * h.dy);                                    // :319
     const float disc = h.b * h.b - (4.0f * h.a) * p.c;                           // :322
     const bool mask = (disc >= 0.0f) && (fabsf(h.a) > 1e-8f);                    // :326
+#ifdef ART_CYL_IEEE_SQRT             // A/B build: the generic sequence
     h.sq = sqrtf(disc * (mask ? 1.0f : 0.0f) + 1e-12f);                          // :336
+#else
+    h.sq = sqrt_noscale(disc * (mask ? 1.0f : 0.0f) + 1e-12f);                   // :336
+#endif
     const float two_a = 2.0f * h.a;
     // (the quotients of this function are div_noscale: the IEEE quotient bit for bit while operands and quotient stay in the
     //  normal range - metres over metres here; a ray (almost) parallel to the axis, whose quotient may leave it, is masked by
@@ -399,7 +417,11 @@ __device__ __forceinline__ CylHit cyl_hit(const Cyl& cy, const CylPoint& p, floa
     h.t = t;
     h.x = p.ox + t * h.dx; h.y = p.oy + t * h.dy;                                // :374-381
     float z = p.oz + t * h.dz;
+#ifdef ART_CYL_IEEE_SQRT
     h.rho = sqrtf(h.x * h.x + h.y * h.y);                                        // :384-385
+#else
+    h.rho = sqrt_noscale(h.x * h.x + h.y * h.y);                                 // :384-385
+#endif
 #ifdef ART_CYL_IEEE_DIV              // A/B build: the generic division sequence
     h.nx = h.x / h.rho; h.ny = h.y / h.rho;
 #else
@@ -434,7 +456,8 @@ __device__ __forceinline__ void cyl_hit_bwd(const Cyl& cy, const CylPoint& p, co
     auto rcp_nr = [](float x) { const float y0 = __builtin_amdgcn_rcpf(x); return fmaf(fmaf(-x, y0, 1.0f), y0, y0); };
     const float g_ang = g_be * cy.wm1 * cy.inv_opening;
     const float g_z = g_bu * cy.hm1 * cy.inv_height;
-    const float irho2 = rcp_nr(h.x * h.x + h.y * h.y);
+    const float irho = rcp_nr(h.rho);
+    const float irho2 = irho * irho;
     float g_x = -g_ang * h.y * irho2, g_y = g_ang * h.x * irho2;
     float gdx = 0.0f, gdy = 0.0f;
     if (h.abi > 0.0f) {
@@ -442,7 +465,6 @@ __device__ __forceinline__ void cyl_hit_bwd(const Cyl& cy, const CylPoint& p, co
         gdx = -g_abi * h.nx; gdy = -g_abi * h.ny;
         const float gnx = -g_abi * h.dx, gny = -g_abi * h.dy;
         const float dotn = h.nx * gnx + h.ny * gny;
-        const float irho = rcp_nr(h.rho);
         g_x += (gnx - h.nx * dotn) * irho; g_y += (gny - h.ny * dotn) * irho;
     }
     gox = g_x; goy = g_y; goz = g_z;

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import (BLOCKING_CASES, CYL_CASES, KINEMATICS_CASES, REAL_CASES, STAGE_CASES, kinematics_case, rel_l2,
+from conftest import (BLOCKING_CASES, CYL_CASES, KINEMATICS_CASES, REAL_CASES, ROOT, STAGE_CASES, kinematics_case, rel_l2,
                       sun_distortions)
 
 pytestmark = pytest.mark.gpu
@@ -1822,6 +1822,24 @@ def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     again = run()                                     # and every variant repeats itself
     for x, y in zip(other, again):
         np.testing.assert_array_equal(x, y)
+
+
+def test_scale_free_square_root_is_the_ieee_square_root():
+    """The cylinder hit takes its two square roots (geometry.py:336, :384) with ray_math.hpp's sqrt_noscale - the compiler's
+    correctly rounded sequence without the scaling of arguments below 2^-96 and the fix-up of 0 / inf / NaN (15 -> 9 instructions).
+    EVERY float from 2^-96 up to the largest finite one - 1.9e9 values - and zero give the bits of sqrtf (tests/sqrt_check.hip)."""
+    import ctypes
+    so = ROOT / "tests" / "bin" / "libsqrt_check.so"
+    assert so.exists(), "tests/bin/libsqrt_check.so is built by __graft_entry__.build()"
+    lib = ctypes.CDLL(str(so))
+    lib.sqrt_check.argtypes = [ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]
+    bad = torch.zeros(1, dtype=torch.int64, device=DEV)
+    lo = 0x0F800000                      # 2^-96
+    hi = 0x7F800000                      # +inf (excluded)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert lib.sqrt_check(lo, hi - lo, bad.data_ptr(), stream) == 0
+    assert lib.sqrt_check(0, 1, bad.data_ptr(), stream) == 0          # 0.0
+    assert int(bad.item()) == 0, f"{int(bad.item())} arguments differ"
 
 
 @pytest.mark.parametrize("name", CYL_CASES)
