@@ -1802,21 +1802,22 @@ struct RayGrad { float ox, oy, oz, rx, ry, rz; };
 struct PrimSums { float v[6]; };                      // this lane's share of the wave's rectangle gradients
 struct AdjointOut { RayGrad ray; PrimSums sums; };
 typedef const __attribute__((address_space(3))) Prim* LdsPrims;
-// POINT_SLOT (the lean backward item, where this body is INLINED - its ring has two steps): the FIRST rectangle of the wave's mask -
-// usually the only one whose edge a wave's rays meet - is not handed over ray by ray: a lane adds its ray's twelve values to
-// `point` (its own registers, summed over the samples of its point) and the item reduces them across the wave once per point.
+// POINT_SLOT (the lean backward item, where this body is INLINED - its ring has two steps): the first TWO rectangles of the wave's
+// mask - usually the only ones whose edges a wave's rays meet - are not handed over ray by ray: a lane adds its ray's twelve values
+// to `point` / `point2` (its own registers, summed over the samples of its point) and the item reduces them across the wave once
+// per point.  The ray-by-ray hand-over cost 2.1 of exact mode's 18.2 ms (ablation build); same box: the call of round 3's first
+// half 18.2 ms, this body inlined 18.1, one slot 17.0, two 16.8.
 struct PointSums { float v[12]; };
 template <bool POINT_SLOT>
-__device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSums sums, PointSums& point, unsigned wave_mask, unsigned near,
+__device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSums sums, PointSums& point, PointSums& point2, unsigned wave_mask, unsigned near,
                                                          float ox, float oy, float oz, float rx, float ry, float rz, float g_sigma)
 {
     AdjointOut out = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sums};
     const int lane = threadIdx.x & 63;
-    [[maybe_unused]] bool first_rect = true;
+    [[maybe_unused]] int rect_no = 0;
     for (unsigned m = __builtin_amdgcn_readfirstlane(wave_mask); m != 0u; m &= m - 1u) {
         const int k = __builtin_ctz(m);
-        [[maybe_unused]] const bool slot = first_rect;
-        first_rect = false;
+        [[maybe_unused]] const int slot = rect_no++;
         const bool on = (near >> k) & 1u;
         if (!wave_any(on)) continue;
         typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1842,11 +1843,18 @@ __device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSum
                                 on ? g.su[2] : 0.f, on ? g.sv[0] : 0.f, on ? g.sv[1] : 0.f, on ? g.sv[2] : 0.f, on ? g.n[0] : 0.f,
                                 on ? g.n[1] : 0.f, on ? g.n[2] : 0.f};
         if constexpr (POINT_SLOT) {
-            if (slot) {              // (wave-uniform) this lane's own sums: reduced once per point by the caller
+            if (slot == 0) {         // (wave-uniform) this lane's own sums: reduced once per point by the caller
 #pragma unroll
                 for (int c = 0; c < 12; ++c) point.v[c] += part[c];
                 continue;
             }
+#ifndef ART_ADJOINT_ONE_SLOT        // (A/B build: only the first rectangle)
+            if (slot == 1) {
+#pragma unroll
+                for (int c = 0; c < 12; ++c) point2.v[c] += part[c];
+                continue;
+            }
+#endif
         }
         const bool lo = lane == 2 * k, hi = lane == 2 * k + 1;
         const unsigned long long m_on = __builtin_amdgcn_ballot_w64(on);
@@ -1882,8 +1890,8 @@ __device__ __attribute__((noinline)) AdjointOut block_adjoint(LdsPrims prims, Pr
                                                               float ox, float oy, float oz, float rx, float ry, float rz,
                                                               float g_sigma)
 {
-    PointSums unused = {};
-    return block_adjoint_body<false>(prims, sums, unused, wave_mask, near, ox, oy, oz, rx, ry, rz, g_sigma);
+    PointSums unused = {}, unused2 = {};
+    return block_adjoint_body<false>(prims, sums, unused, unused2, wave_mask, near, ox, oy, oz, rx, ry, rz, g_sigma);
 }
 
 // A heliostat that is skipped because its target index is outside the tables (ART_ETARGET, target_in_range) gets ZERO
@@ -2407,7 +2415,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // gox / goz / goy: sums of g_hx / g_hz / g_numer
         [[maybe_unused]] float bgx = 0.f, bgy = 0.f, bgz = 0.f;                   // dL/do through the blocking mask (world)
         [[maybe_unused]] unsigned pmask = 0u, wmask = 0u;                         // rectangles this point's / this wave's rays can touch
-        [[maybe_unused]] PointSums point_sums = {};                               // this lane's gradient of the wave mask's first rectangle (see block_adjoint_body)
+        [[maybe_unused]] PointSums point_sums = {}, point_sums2 = {};             // this lane's gradient of the wave mask's first (second) rectangle (see block_adjoint_body)
         [[maybe_unused]] bool point_touched = false;                              // (wave-uniform)
         if constexpr (BLOCKING) {
             if (n_prims > 0) {
@@ -2529,10 +2537,10 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                         const AdjointOut ao = block_adjoint((LdsPrims)s_tab.prim, prim_sums, wmask, adj ? near : 0u, o.x, o.y, o.z, rx, ry,
                                                             rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
 #elif defined(ART_ADJOINT_PER_RAY)
-                        const AdjointOut ao = block_adjoint_body<false>((LdsPrims)s_tab.prim, prim_sums, point_sums, wmask, adj ? near : 0u, o.x, o.y,
+                        const AdjointOut ao = block_adjoint_body<false>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
                                                                         o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
 #else
-                        const AdjointOut ao = block_adjoint_body<true>((LdsPrims)s_tab.prim, prim_sums, point_sums, wmask, adj ? near : 0u, o.x, o.y,
+                        const AdjointOut ao = block_adjoint_body<true>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
                                                                        o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
                         point_touched = true;
 #endif
@@ -2610,6 +2618,17 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                     const float a_lo = wave_reduce<kSum>(point_sums.v[c]), a_hi = wave_reduce<kSum>(point_sums.v[6 + c]);
                     prim_sums.v[c] += lane == 2 * k0 ? a_lo : (lane == 2 * k0 + 1 ? a_hi : 0.0f);
                 }
+#ifndef ART_ADJOINT_ONE_SLOT        // (A/B build: only the first rectangle)
+                const unsigned rest = wmask & (wmask - 1u);
+                if (rest != 0u) {
+                    const int k1 = __builtin_ctz(rest);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        const float a_lo = wave_reduce<kSum>(point_sums2.v[c]), a_hi = wave_reduce<kSum>(point_sums2.v[6 + c]);
+                        prim_sums.v[c] += lane == 2 * k1 ? a_lo : (lane == 2 * k1 + 1 ? a_hi : 0.0f);
+                    }
+                }
+#endif
             }
         }
         const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
