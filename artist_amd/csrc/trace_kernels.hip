@@ -1810,7 +1810,8 @@ typedef const __attribute__((address_space(3))) Prim* LdsPrims;
 struct PointSums { float v[12]; };
 template <bool POINT_SLOT>
 __device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSums sums, PointSums& point, PointSums& point2, unsigned wave_mask, unsigned near,
-                                                         float ox, float oy, float oz, float rx, float ry, float rz, float g_sigma)
+                                                         float ox, float oy, float oz, float rx, float ry, float rz, float g_sigma,
+                                                         float num0 = 0.0f, float num1 = 0.0f)
 {
     AdjointOut out = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sums};
     const int lane = threadIdx.x & 63;
@@ -1827,7 +1828,9 @@ __device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSum
         Prim q;
         __builtin_memcpy(&q, words, sizeof(Prim));
         SoftHit sh;
-        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, sh);
+        bool in_front;
+        if constexpr (POINT_SLOT) in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, sh, slot < 2, slot == 0 ? num0 : num1);   // (the caller's per-point numerators)
+        else in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, sh);
         soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, sh);
         SoftSig sg;
         (void)soft_sigma(sh, sg);
@@ -2540,8 +2543,13 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                         const AdjointOut ao = block_adjoint_body<false>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
                                                                         o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
 #else
+#ifndef ART_BLOCK_NUM_PER_RAY
                         const AdjointOut ao = block_adjoint_body<true>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
-                                                                       o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+                                                                       o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f, bnum0, bnum1);
+#else
+                        const AdjointOut ao = block_adjoint_body<false>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
+                                                                        o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+#endif
                         point_touched = true;
 #endif
                         prim_sums = ao.sums;
