@@ -1576,10 +1576,17 @@ constexpr int kLeanFwdThreads = ART_LEAN_FWD_THREADS;
 #define ART_LEAN_BLOCK_FWD_THREADS 768
 #endif
 constexpr int kLeanBlockFwdThreads = ART_LEAN_BLOCK_FWD_THREADS;   // the lean body + the soft mask: 168 registers instead of 128
+// the lean body + the cylinder hit: four waves per SIMD with 88 B of spills beat three without (same box, tools/cylinder_bench.py,
+// forward / forward + backward: 640 threads 6.86 / 14.2 ms, 768 5.61 / 12.6, 896 5.52 / 12.5, 1024 5.40 / 12.3; the blocking body:
+// 8.33, 7.26, 7.44, 7.18 ms forward - within the noise of the box from 768 on)
+#ifndef ART_LEAN_CYL_FWD_THREADS
+#define ART_LEAN_CYL_FWD_THREADS 1024
+#endif
+constexpr int kLeanCylFwdThreads = ART_LEAN_CYL_FWD_THREADS;
 constexpr int kCylFwdThreads = 1024;             // (768: within the noise of the box, 512: 17 % slower)
 // LEAN: 0 the generic item, 1 trace_fwd_item_lean, 2 trace_fwd_item_field (groups of heliostats, see there)
 template <bool INTERLEAVED, bool CYL, bool BLOCKING, int LEAN = 0>
-__global__ __launch_bounds__(LEAN ? ((BLOCKING || CYL) ? kLeanBlockFwdThreads : kLeanFwdThreads) : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
+__global__ __launch_bounds__(LEAN ? (BLOCKING ? kLeanBlockFwdThreads : (CYL ? kLeanCylFwdThreads : kLeanFwdThreads)) : (CYL ? kCylFwdThreads : 1024)) void trace_fwd_lds_kernel(FwdLaunch launch)
 {
     static_assert(!LEAN || ((LEAN == 1 || (!BLOCKING && !CYL)) && !(BLOCKING && CYL)),
                   "the lean body serves planes, planes with blocking, or cylinders; the field item is planar without blocking");
@@ -3262,10 +3269,10 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // tower this is the cylinder launch beside the planes' lean launch (a.split == 3: the receiver type decides who skips).
         const bool lean_cyl = !blocking && lean_ok && Tc > 0 && env_int("ARTIST_HIP_CYL_LEAN", 1) != 0;
         if (lean_cyl) {
-            cfg.block = kLeanBlockFwdThreads;
+            cfg.block = kLeanCylFwdThreads;
             cfg.exact_pblock = true;
             cfg.facet_points = (int)facet_points;
-            if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanBlockFwdThreads;
+            if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanCylFwdThreads;
         }
         if (lean_block) {
             cfg.block = kLeanBlockFwdThreads;
