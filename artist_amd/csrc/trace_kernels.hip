@@ -2696,7 +2696,10 @@ constexpr int kLeanBwdPoints = 2560;
 // (768-thread workgroups for the cylinder adjoint and the planar blocking instantiation: they keep ~60 more values alive per
 //  ray than the plain body, and three waves per SIMD with a few spills beat two without - same-box, tools/cylinder_bench.py:
 //  512 -> 768 threads 18.6 -> 17.0 ms forward + backward, 1024 threads 17.9; tools/blocking_bench.py exact mode 30.5 -> 29.0)
-constexpr int kCylBwdThreads = 768, kBlockingBwdThreads = 768;
+#ifndef ART_CYL_BWD_THREADS
+#define ART_CYL_BWD_THREADS 768
+#endif
+constexpr int kCylBwdThreads = ART_CYL_BWD_THREADS, kBlockingBwdThreads = 768;
 // static LDS the rectangle tables add to the lean backward kernel (PrimTable<true>: rectangles, cull data, fp64 gradient sums)
 constexpr int kLeanBlockBwdStatic = (int)sizeof(PrimTable<true>);
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
@@ -3455,6 +3458,8 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                 cfg.tile_cap = std::min<int>(cfg.tile_cap, (int)((160 * 1024 - 1408 - (lean_block ? kLeanBlockBwdStatic : 0) - perm_bytes - 8) / 4) / 64 * 64);
             }
         }
+        // (cylinders, the generic item: facet-sized balanced blocks measured slower - 12.7 vs 12.45 ms forward + backward,
+        //  tools/cylinder_bench.py - so they keep round 2's 2048-point blocks)
         window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
         // A small field is cut into sample chunks to fill the chip; the chunks of a point then write partial gradients
         // to [n_rchunks,H,P] slabs in the caller's scratch buffer and reduce_chunks_kernel adds them in chunk order
