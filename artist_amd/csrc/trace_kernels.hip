@@ -2700,10 +2700,14 @@ constexpr int kLeanBwdPoints = 2560;
 #define ART_CYL_BWD_THREADS 768
 #endif
 constexpr int kCylBwdThreads = ART_CYL_BWD_THREADS, kBlockingBwdThreads = 768;
+#ifndef ART_LEAN_BLOCK_BWD_THREADS
+#define ART_LEAN_BLOCK_BWD_THREADS 768
+#endif
+constexpr int kLeanBlockBwdThreads = ART_LEAN_BLOCK_BWD_THREADS;     // the lean backward item with the mask and its inlined adjoint
 // static LDS the rectangle tables add to the lean backward kernel (PrimTable<true>: rectangles, cull data, fp64 gradient sums)
 constexpr int kLeanBlockBwdStatic = (int)sizeof(PrimTable<true>);
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
-__global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? kBlockingBwdThreads : (LEAN ? kLeanBwdThreads : 1024))) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
+__global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? (LEAN ? kLeanBlockBwdThreads : kBlockingBwdThreads) : (LEAN ? kLeanBwdThreads : 1024))) void trace_bwd_lds_kernel(TraceArgs a, const float* __restrict__ grad_flux,
                                                              float4* __restrict__ grad_origins,
                                                              float4* __restrict__ grad_normals,
                                                              float* __restrict__ prim_slabs,
@@ -3445,7 +3449,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                                 env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
         size_t perm_bytes = 0;
         if (lean || lean_block) {
-            cfg.block = kLeanBwdThreads;
+            cfg.block = lean_block ? kLeanBlockBwdThreads : kLeanBwdThreads;
             cfg.exact_pblock = true;
             if (lean || env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {
                 cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
@@ -3558,7 +3562,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             if (work_counter == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }    \
             work_counter += CY ? 6 : 5;                       /* backward: planar / cylinder launch */          \
             hipLaunchKernelGGL((trace_bwd_lds_kernel<IL, AT, CY, BL, LN>), dim3((unsigned)blocks),               \
-                               dim3(std::min(cfg.block, CY ? kCylBwdThreads : (BL ? kBlockingBwdThreads : 1024))), lds, stream, a, grad_flux, \
+                               dim3(std::min(cfg.block, CY ? kCylBwdThreads : (BL ? (LN ? kLeanBlockBwdThreads : kBlockingBwdThreads) : 1024))), lds, stream, a, grad_flux, \
                                go, gn, prim_slabs, work_counter);                                                \
         } while (0)
 #define ART_LAUNCH_BWD_BL(CY, BL, LN)                                                                            \
