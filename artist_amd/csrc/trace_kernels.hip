@@ -2281,7 +2281,10 @@ typedef __attribute__((address_space(3))) float lds_f32;
 // adjoint (block_adjoint: ray side into this thread's sums, rectangle side into the wave's owner-lane registers, see there) -
 // the launch of a split call that owns the heliostats WITH candidate rectangles.  A wave then walks whole trips (a lane beyond
 // the block's end repeats the last point, masked) and the item ends like trace_bwd_item: wave order, slab.
-template <bool INTERLEAVED, bool ATOMIC_OUT, bool BLOCKING = false>
+// CYL: the same item with the cylinder hit (cyl_hit) in place of the plane's and its hand-derived adjoint (cyl_hit_bwd) - no edge
+// packing (the partition uses the planes' chief-ray hit) and no zero-weight trick (a masked ray's intermediates are not finite):
+// a lane in use takes a branch.
+template <bool INTERLEAVED, bool ATOMIC_OUT, bool BLOCKING = false, bool CYL = false>
 __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const float* __restrict__ grad_flux,
                                                     float4* __restrict__ grad_origins, float4* __restrict__ grad_normals,
                                                     const WorkItem item, unsigned int* __restrict__ work_counter, int* s_next,
@@ -2302,7 +2305,8 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     }
     const int t = a.target_idx[h];
     const bool bad_target = !target_in_range(a, t);
-    if (bad_target || t >= a.T || item.r1 <= item.r0 || other_launch_owns(a, h)) {
+    static_assert(!(BLOCKING && CYL), "the lean body serves blocking on planes or cylinders without blocking");
+    if (bad_target || (t >= a.T) != CYL || item.r1 <= item.r0 || other_launch_owns(a, h)) {
         if (bad_target) {
             zero_block_gradients(a, item, grad_origins, grad_normals);
             if constexpr (BLOCKING) {                // ... and no rectangle gradients from this item either
@@ -2313,8 +2317,10 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
         return;
     }
-    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
-    const Cyl cy = {};
+    Plane pl = {}; Cyl cy = {};
+    if constexpr (CYL) cy = load_cyl(a.cyl_centers, a.cyl_normals, a.cyl_axes, a.cyl_radii, a.cyl_heights, a.cyl_opening, t - a.T, a.W, a.Hh,
+                                     a.mag, a.k_ext, a.k_refl);
+    else pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
     const float* __restrict__ G = grad_flux + (int64_t)(a.mode == 0 ? h : t) * a.Hh * a.W;
     const float4 inc = a.incident[h];
     int p0, p1;
@@ -2333,7 +2339,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
 #endif
     ART_TIMELINE(1);
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
-    compute_window<INTERLEAVED, false>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
+    compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
     ART_TIMELINE(2);
     unsigned next_item = 0u;
@@ -2350,11 +2356,11 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     // stays coalesced: they skip a point here and there).  perm[j] = index within the block of the point in slot j.
     unsigned short* perm = reinterpret_cast<unsigned short*>(gtile + a.tile_cap + 2);
     const int n_pts = p1 - p0;
-    const bool packed = a.pack_edge != 0 && win.npass == 1 && n_pts <= kPackPoints && n_pts <= kPackTrips * (int)blockDim.x &&
+    const bool packed = !CYL && a.pack_edge != 0 && win.npass == 1 && n_pts <= kPackPoints && n_pts <= kPackTrips * (int)blockDim.x &&
                         win.tw >= 2 && win.th >= 2;
     if (packed) pack_edge_points(a, pl, inc, org, nrm, p0, n_pts, win, a.pack_edge, s_edge, perm);
     ART_TIMELINE(5);         // (diagnostic build: end of the edge partition; slot 5 is read out of order by tools/timeline_report.py)
-    const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
+    [[maybe_unused]] const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
     const float lds_base = (float)(unsigned)(size_t)(lds_f32*)gtile;
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
     const unsigned twm2_bits = f32_bits((float)(win.tw - 2)), uthm2_bits = f32_bits((float)(win.th - 2));
@@ -2421,8 +2427,10 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         const float4 n = nrm[p];
         float4 d; float s;
         reflect(inc, n, d, s);
-        const float numer = plane_numer(pl, o);
-        float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // gox / goz / goy: sums of g_hx / g_hz / g_numer
+        [[maybe_unused]] float numer = 0.0f;
+        [[maybe_unused]] CylPoint cp = {};
+        if constexpr (CYL) cp = cyl_point(cy, o); else numer = plane_numer(pl, o);
+        float gdx = 0.f, gdy = 0.f, gdz = 0.f, gox = 0.f, goy = 0.f, goz = 0.f;   // gox / goz / goy: sums of g_hx / g_hz / g_numer (cylinders: of dL/d(local origin))
         [[maybe_unused]] float bgx = 0.f, bgy = 0.f, bgz = 0.f;                   // dL/do through the blocking mask (world)
         [[maybe_unused]] unsigned pmask = 0u, wmask = 0u;                         // rectangles this point's / this wave's rays can touch
         [[maybe_unused]] PointSums point_sums = {}, point_sums2 = {};             // this lane's gradient of the wave mask's first (second) rectangle (see block_adjoint_body)
@@ -2455,21 +2463,31 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             if (__builtin_expect(wave_any(!(fabsf(u) + fabsf(e) <= kSmallAngle)), 0)) m = make_rot(e, u);
             float rx, ry, rz;
             scatter(m, d, rx, ry, rz);
-            const float ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
-            const unsigned long long m_front = ballot64(ah < 0.0f) & live;
-            float y;                                                         // ~ 1 / ah
+            [[maybe_unused]] float ah = 0.0f, y = 0.0f, tt = 0.0f;          // (planes) r.m, ~ 1 / (r.m), the path length
+            float be, bu;
+            unsigned long long m_front, m_valid;
+            [[maybe_unused]] CylHit ch = {};
+            if constexpr (CYL) {
+                ch = cyl_hit(cy, cp, rx, ry, rz);
+                be = ch.be; bu = ch.bu;
+                m_valid = ballot64(ch.ok) & live;
+                m_front = m_valid;
+            } else {
+            ah = (rx * pl.mx + ry * pl.my) + rz * pl.mz;
+            m_front = ballot64(ah < 0.0f) & live;
             // (the denominator is made safe, unlike in the forward: a masked ray's terms are multiplied by zero
             //  below and must therefore be finite)
-            const float tt = div_noscale_rcp(numer, select_mask(m_front, ah, 1.0f), y);
+            tt = div_noscale_rcp(numer, select_mask(m_front, ah, 1.0f), y);
             const float hx = o.x + rx * tt, hz = o.z + rz * tt;
             const float be0 = div_const((hx + pl.half_w) - pl.cx, pl.w, pl.inv_w) * pl.wm1;
-            const float bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;
-            const float be = pl.wm1 - be0;
+            bu = div_const((hz + pl.half_h) - pl.cz, pl.h, pl.inv_h) * pl.hm1;
+            be = pl.wm1 - be0;
+            m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
+            }
             const float tbe = truncf(be), tbu = truncf(bu);
             const float che = be - tbe, chu = bu - tbu;
             const float cle = 1.0f - che, clu = 1.0f - chu;
             const float lef = tbe - e0f, luf = tbu - pu0f;
-            const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
             const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
             const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
             const unsigned addr_lo = (unsigned)af;
@@ -2503,7 +2521,22 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 m_use |= ballot64(stray);
             }
 #endif
-            {
+            if constexpr (CYL) {
+                if ((m_use >> lane) & 1ull) {     // divergent: a masked ray's intermediates are not finite, so no zero-weight trick here
+#pragma clang fp contract(fast)
+                    const float I = (ch.I0 * a.k_ext) * a.k_refl;
+                    const float g_abs = cle * (chu * g1 + clu * g4) + che * (chu * g2 + clu * g3);     // dL/dI
+                    const float gI0 = g_abs * (a.k_ext * a.k_refl);                                      // dL/dI0
+                    const float g_be = (chu * (g2 - g1) + clu * (g3 - g4)) * I;
+                    const float g_bu = (cle * (g1 - g4) + che * (g2 - g3)) * I;
+                    float lx, ly, lz, grx, gry, grz;
+                    cyl_hit_bwd(cy, cp, ch, g_be, g_bu, gI0, lx, ly, lz, grx, gry, grz);
+                    gox += lx; goy += ly; goz += lz;
+                    gdx += m.cu * grx + m.m10 * gry + m.m20 * grz;
+                    gdy += m.m11 * gry + m.m21 * grz - m.su * grx;
+                    gdz += m.ce * grz - m.se * gry;
+                }
+            } else {
 #pragma clang fp contract(fast)
                 float kIm = select_or_zero(m_use, kI);
                 [[maybe_unused]] float trans = 1.0f, g_keep_scale = 0.0f;
@@ -2647,9 +2680,15 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             }
         }
         const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
-        // hit = o + t r, t = (c - o).m / (r.m): dL/do = (g_hx, 0, g_hz) - m * sum g_numer
-        const float sn = goy;
-        float4 go = make_float4(gox - sn * pl.mx, -(sn * pl.my), goz - sn * pl.mz, 0.0f);
+        float4 go;
+        if constexpr (CYL) {   // local origin = R (o - c)  ->  dL/do = R^T dL/dlocal
+            go = make_float4(gox * cy.r00 + goy * cy.r10 + goz * cy.r20, gox * cy.r01 + goy * cy.r11 + goz * cy.r21,
+                             gox * cy.r02 + goy * cy.r12 + goz * cy.r22, 0.0f);
+        } else {
+            // hit = o + t r, t = (c - o).m / (r.m): dL/do = (g_hx, 0, g_hz) - m * sum g_numer
+            const float sn = goy;
+            go = make_float4(gox - sn * pl.mx, -(sn * pl.my), goz - sn * pl.mz, 0.0f);
+        }
         if constexpr (BLOCKING) { go.x += bgx; go.y += bgy; go.z += bgz; }
         const float4 gn = make_float4(-2.0f * (gdn * inc.x + s * gdx), -2.0f * (gdn * inc.y + s * gdy),
                                       -2.0f * (gdn * inc.z + s * gdz), -2.0f * (gdn * inc.w));
@@ -2716,7 +2755,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? (LEAN ? kLeanBlo
     __shared__ int s_next;
     const int n_items = work_item_count(a);
     int item = blockIdx.x;
-    if constexpr ((CYL && !kCylPersistentBwd) || (!CYL && BLOCKING && !LEAN && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
+    if constexpr ((CYL && !LEAN && !kCylPersistentBwd) || (!CYL && BLOCKING && !LEAN && !kBlockingPersistentBwd)) {     // one item per workgroup, as in the forward kernel
         if (item >= n_items) return;
         if constexpr (CYL && !BLOCKING) {
             if (a.split == 3) {                      // the heliostats that aim at a cylinder first (see art_trace_fwd)
@@ -2734,7 +2773,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? (LEAN ? kLeanBlo
     const bool reverse = a.reverse_bwd != 0;
     while (item < n_items) {
         if constexpr (LEAN)
-            trace_bwd_item_lean<INTERLEAVED, ATOMIC_OUT, BLOCKING>(a, grad_flux, grad_origins, grad_normals,
+            trace_bwd_item_lean<INTERLEAVED, ATOMIC_OUT, BLOCKING, CYL>(a, grad_flux, grad_origins, grad_normals,
                                                                    decode_work_item(a, item, reverse), work_counter, &s_next, prim_slabs);
         else
             trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, prim_slabs,
@@ -3555,7 +3594,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         }
 #define ART_LAUNCH_BWD(IL, AT, CY, BL, LN)                                                                       \
         do {                                                                                                     \
-            const int64_t blocks = ((CY && !kCylPersistentBwd) || (!CY && BL && !LN && !kBlockingPersistentBwd)) ? items : persistent_blocks; \
+            const int64_t blocks = ((CY && !LN && !kCylPersistentBwd) || (!CY && BL && !LN && !kBlockingPersistentBwd)) ? items : persistent_blocks; \
             ART_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_bwd_lds_kernel<IL, AT, CY, BL, LN>),\
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
             unsigned* work_counter = stream_work_counters(stream);                                               \
@@ -3581,6 +3620,9 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         else
         if (T > 0 && !planar_done) ART_LAUNCH_BWD_TYPE(false);
         if (planar_done) a.split = 3;
+        // cylinders without blocking: the lean item with the cylinder hit (persistent 768-thread workgroups on the work queue)
+        if (Tc > 0 && !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && env_int("ARTIST_HIP_CYL_LEAN", 1) != 0) ART_LAUNCH_BWD_BL(true, false, true);
+        else
         if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
 #ifdef ART_DEBUG_TIMELINE
         if (const char* out = getenv("ART_TIMELINE_OUT_BWD")) {

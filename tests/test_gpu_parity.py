@@ -1846,18 +1846,22 @@ def test_scale_free_square_root_is_the_ieee_square_root():
 @pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_CYL_LEAN="0"), dict(ARTIST_HIP_CYL_LEAN="0", ARTIST_HIP_FWD_BLOCKS="1"), dict(ARTIST_HIP_FWD_BLOCKS="1"),
                                    dict(ARTIST_HIP_FWD_PBLOCK="200"), dict(ARTIST_HIP_PERSISTENT="0")])
 def test_cylinder_bodies_agree(golden, monkeypatch, name, knobs):
-    """Cylindrical receivers take the lean forward item with the cylinder hit in place of the plane's (round 3;
-    ARTIST_HIP_CYL_LEAN=0: the generic one-item workgroups of round 2), on cylinder-only and mixed towers, with the samples in
-    chunks or in one item, other point blocks, one workgroup per item.  Same rays and the same hit: ray counters equal, bitmaps
-    within the two bodies' rounding of the four weights (1e-6) and the same bits where only the items change."""
+    """Cylindrical receivers take the lean forward AND backward items with the cylinder hit in place of the plane's (round 3;
+    ARTIST_HIP_CYL_LEAN=0: the generic items of round 2), on cylinder-only and mixed towers, with the samples in chunks or in one
+    item, other point blocks, one workgroup per item.  Same rays and the same hit: ray counters equal, bitmaps within the two
+    bodies' rounding of the four weights (1e-6) and the same bits where only the items change, gradients within 2e-5, every
+    variant bit-reproducible."""
     from artist_amd import trace_rays
     d = golden(name)
 
     def run():
         inp = trace_inputs(d)
         inp["cyl"] = cyl_inputs(d)
+        inp["origins"].requires_grad_(True)
+        inp["normals"].requires_grad_(True)
         flux, fac = trace_rays(**inp)[:2]
-        return n(flux), n(fac)
+        (flux * t(d["loss_weights"])).sum().backward()
+        return n(flux), n(fac), n(inp["origins"].grad), n(inp["normals"].grad)
 
     base = run()
     for k, v in knobs.items():
@@ -1868,9 +1872,13 @@ def test_cylinder_bodies_agree(golden, monkeypatch, name, knobs):
     else:
         np.testing.assert_array_equal(other[0], base[0])
     np.testing.assert_array_equal(other[1], base[1])
+    # the backward kernels: the lean item (round 3) against the generic one, and other geometries of either - the same adjoint
+    # arithmetic, sums in other orders
+    assert np.isfinite(other[2]).all() and np.isfinite(other[3]).all()
+    assert rel_l2(other[2], base[2]) < 2e-5 and rel_l2(other[3], base[3]) < 2e-5, (rel_l2(other[2], base[2]), rel_l2(other[3], base[3]))
     again = run()
-    np.testing.assert_array_equal(again[0], other[0])
-    np.testing.assert_array_equal(again[1], other[1])
+    for x, y in zip(again, other):
+        np.testing.assert_array_equal(x, y)
 
 
 @pytest.mark.parametrize("knobs", [dict(ARTIST_HIP_BLOCK_LEAN="0"), dict(ARTIST_HIP_BLOCK_FACETS="0"), dict(ARTIST_HIP_BLOCKING_SPLIT="0"),
