@@ -430,12 +430,13 @@ __device__ __forceinline__ void timeline_mark(int slot, int k)
 #endif
 
 // (grad is DOUBLE: on gfx950 ds_add_f64 retires a wave instruction in ~25 cycles, ds_add_f32 in ~193 - tools/lds_atomic_bench.hip)
-template <bool BLOCKING> struct PrimTable { Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; double grad[kMaxCand * 12]; };
-template <> struct PrimTable<false> { Prim prim[1]; PrimAux aux[1]; int id[1]; double grad[1]; };
+// (GRAD = false: the forward items - no gradient sums, 3 KB less static LDS: room for 4 KB more window)
+template <bool BLOCKING, bool GRAD = true> struct PrimTable { Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; double grad[GRAD ? kMaxCand * 12 : 1]; };
+template <bool GRAD> struct PrimTable<false, GRAD> { Prim prim[1]; PrimAux aux[1]; int id[1]; double grad[1]; };
 
 // candidates of heliostat h -> LDS; returns their number (workgroup-uniform).  Ends with a barrier.
-template <bool BLOCKING>
-__device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<BLOCKING>& tab)
+template <bool BLOCKING, bool GRAD = true>
+__device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<BLOCKING, GRAD>& tab)
 {
     if constexpr (!BLOCKING) return 0;
     const int n = min(a.cand_count[h], a.Cmax);
@@ -445,7 +446,7 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
         tab.prim[c] = make_prim(a.prim_corners, a.prim_spans, a.prim_normals, k);
         tab.aux[c] = make_prim_aux(tab.prim[c]);
     }
-    for (int c = threadIdx.x; c < n * 12; c += blockDim.x) tab.grad[c] = 0.0;
+    if constexpr (GRAD) for (int c = threadIdx.x; c < n * 12; c += blockDim.x) tab.grad[c] = 0.0;
     __syncthreads();
     return n;
 }
@@ -585,7 +586,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     __shared__ float s_red[13][16];    // per-wave partials: emin, emax, umin, umax, ke, ku, angmax, dmax2, sums
     __shared__ Window s_win;
     __shared__ unsigned s_cnt[3];
-    __shared__ PrimTable<BLOCKING> s_tab;
+    __shared__ PrimTable<BLOCKING, false> s_tab;
 
     const int pblock = item.pblock;
     const int h = item.h;
@@ -636,7 +637,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
         for (int i = tid; i < a.tile_cap / 4; i += blockDim.x) t4[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) tile[a.tile_cap + tid] = 0u;
     }
-    const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
+    const int n_prims = load_prims<BLOCKING, false>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
     ART_TIMELINE(2);
@@ -985,7 +986,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     __shared__ float s_red[13][16];
     __shared__ Window s_win;
     __shared__ unsigned s_cnt[3];
-    __shared__ PrimTable<BLOCKING> s_tab;
+    __shared__ PrimTable<BLOCKING, false> s_tab;
     const int pblock = item.pblock;
     const int h = item.h;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
@@ -1032,7 +1033,7 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         for (int i = tid; i < a.tile_cap / 4; i += blockDim.x) t4[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) tile[a.tile_cap + tid] = 0u;
     }
-    const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
+    const int n_prims = load_prims<BLOCKING, false>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
     ART_TIMELINE(2);
@@ -3230,7 +3231,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     hipLaunchKernelGGL(trace_fwd_prep_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, stream, counts, (int)(3 * H));
     FwdConfig cfg = fwd_config();
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
-    if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
+    if (blocking && cfg.tile_cap > 154 * 256) cfg.tile_cap = 154 * 256;   // room for the rectangle tables in LDS (no gradient sums here: 4.2 KB + 1 KB of static LDS)
     if (accum == nullptr || (reinterpret_cast<uintptr_t>(accum) % 16) != 0) return ART_EINVAL;
     // unit of the pixel accumulators: 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|
     {
