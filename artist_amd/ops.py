@@ -7,6 +7,7 @@ raise.
 from __future__ import annotations
 
 import collections
+import contextlib
 import math
 
 import torch
@@ -14,11 +15,44 @@ import torch
 from . import _lib
 
 __all__ = ["trace_rays", "nurbs_surface_points_and_normals", "per_target_sum", "align_surfaces", "TraceRays",
-           "NurbsEval", "AlignSurfaces", "check_async_errors"]
+           "NurbsEval", "AlignSurfaces", "check_async_errors", "record_launch_events"]
 
 
 def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+# Measurement hook (bench.py's roofline leg, tools/): when switched on, the two trace calls are bracketed by a pair of HIP events
+# on the stream they are launched on, so a caller can read the launch durations of a region it times WITHOUT changing that region
+# (no synchronisation; two event records per call).  Off by default: None.
+_LAUNCH_EVENTS = None
+
+
+def record_launch_events(on: bool = True):
+    """Start (``True``: returns the dict that fills up, ``{"art_trace_fwd": [(start, end), ...], "art_trace_bwd": [...]}``
+    of ``torch.cuda.Event`` pairs) or stop (``False``: returns the dict collected so far) recording.  Read the pairs with
+    ``start.elapsed_time(end)`` after a synchronisation."""
+    global _LAUNCH_EVENTS
+    if on:
+        _LAUNCH_EVENTS = {}
+        return _LAUNCH_EVENTS
+    out, _LAUNCH_EVENTS = _LAUNCH_EVENTS, None
+    return out
+
+
+@contextlib.contextmanager
+def _launch(name: str, device: torch.device):
+    rec = _LAUNCH_EVENTS
+    with torch.cuda.device(device):
+        if rec is None:
+            yield
+            return
+        stream = torch.cuda.current_stream(device)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(stream)
+        yield
+        end.record(stream)
+        rec.setdefault(name, []).append((start, end))
 
 
 def _require_cuda(*tensors: torch.Tensor) -> torch.device:
@@ -232,7 +266,7 @@ class TraceRays(torch.autograd.Function):
         flux = torch.empty((n_maps, height, width), dtype=torch.float32, device=dev)
         factors = torch.empty((3, H), dtype=torch.float32, device=dev)
         accum = _accumulators(dev, n_maps * height * width)
-        with torch.cuda.device(dev):
+        with _launch("art_trace_fwd", dev):
             rc = _lib.lib().art_trace_fwd(
                 *geometry, *block_ptrs, Cmax, float(max_scatter_angle), float(ray_magnitude), float(extinction),
                 float(reflectivity),
@@ -282,7 +316,7 @@ class TraceRays(torch.autograd.Function):
             g_pc, g_ps, g_pn = (torch.empty_like(t) for t in block_tabs[:3])
         n_scratch = int(_lib.lib().art_trace_bwd_scratch_floats(H, R, P, points_per_facet, Cmax if block_tabs else 0))
         scratch = torch.empty((n_scratch,), dtype=torch.float32, device=dev) if n_scratch else None
-        with torch.cuda.device(dev):
+        with _launch("art_trace_bwd", dev):
             rc = _lib.lib().art_trace_bwd(
                 origins.data_ptr(), normals.data_ptr(), incident.data_ptr(), dist_u.data_ptr(), dist_e.data_ptr(),
                 sh, sr, sp, target_idx.data_ptr(), *_planar_ptrs(centers, plane_normals, dims), *cyl_ptrs,

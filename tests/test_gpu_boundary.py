@@ -342,3 +342,29 @@ def test_every_entry_point_is_independent_of_lds_leftovers(monkeypatch):
             "art_flux_center_of_mass", "art_flux_center_of_mass_bwd", "art_reflect"} <= set(calls), sorted(set(calls))
     for a_, b_ in zip(clean, dirty):
         np.testing.assert_array_equal(a_, b_)
+
+
+def test_launch_event_recorder_brackets_the_trace_calls(golden):
+    """``ops.record_launch_events`` (bench.py's roofline leg): one HIP-event pair per art_trace_fwd / art_trace_bwd call, on the
+    stream the call is launched on - also a side stream -, results unchanged, nothing recorded once switched off."""
+    from artist_amd import ops, trace_rays
+    d = golden("mid_256")
+    base = trace_inputs(d)
+    ref_flux, _ = trace_rays(**base)
+    assert ops._LAUNCH_EVENTS is None
+    rec = ops.record_launch_events(True)
+    side = torch.cuda.Stream(DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    for stream in (torch.cuda.current_stream(DEV), side):
+        with torch.cuda.stream(stream):
+            o = base["origins"].clone().requires_grad_(True)
+            flux, _ = trace_rays(**dict(base, origins=o))
+            torch.autograd.grad(flux, o, torch.ones_like(flux))
+            np.testing.assert_array_equal(n(flux), n(ref_flux))
+    assert ops.record_launch_events(False) is rec and ops._LAUNCH_EVENTS is None
+    trace_rays(**base)                                    # off again: not recorded
+    torch.cuda.synchronize()
+    assert sorted(rec) == ["art_trace_bwd", "art_trace_fwd"] and all(len(v) == 2 for v in rec.values())
+    for pairs in rec.values():
+        for start, end in pairs:
+            assert 0.0 < start.elapsed_time(end) < 1e3
