@@ -2277,6 +2277,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
 //   dL/dbu = (cle (g1 - g4) + che (g2 - g3)) I
 // --------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(1))) const float glb_f32;
 
 // BLOCKING: the same item with the soft blocking mask recomputed per ray, its factor `keep` in the intensity, and the mask's
 // adjoint (block_adjoint: ray side into this thread's sums, rectangle side into the wave's owner-lane registers, see there) -
@@ -2374,8 +2375,28 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         // (four rows per wave in flight: 6-8 us per item, tools/timeline.sh.  Eight rows measured 3.65 against 3.53 ms for the
         //  kernel, twelve 4.4 - the batch's registers are allocated on top of the ray loop's; as a real call the batch faulted
         //  on the dynamic-LDS table the compiler builds for callees, and was not pursued)
-        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;
+#ifndef ART_STAGE_THROUGH_VGPRS
+        // LDS-direct loads (global_load_lds_dword: lane l's dword lands at LDS address M0 + 4 l, no destination registers): the
+        // window is one contiguous run of pth x tw cells, a wave takes every nwaves-th group of 64 cells and keeps ALL its loads
+        // in flight - one round trip per item instead of one per four rows.
+        {
+            const int n_cells = pth * win.tw;
+            const int twd = max(win.tw, 1);
+            const int step = nwaves * 64;
+            const int sq = step / twd, sr = step - sq * twd;
+            const int i0 = wave * 64 + lane;
+            int row = i0 / twd, col = i0 - row * twd;
+            const float* __restrict__ gb = G + gbase;
+            for (int base = wave * 64; base < n_cells; base += step) {
+                if (base + lane < n_cells)
+                    __builtin_amdgcn_global_load_lds((glb_f32*)(gb + (col - row * a.W)), (lds_f32*)(gtile + base), 4, 0, 0);
+                col += sr; row += sq;
+                if (col >= twd) { col -= twd; ++row; }
+            }
+        }
+#else
+        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int64_t dg = (int64_t)nwaves * a.W;
         const int dt = nwaves * win.tw;
         const int tw4c = win.tw & ~3;
@@ -2402,6 +2423,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             float* t0 = gtile + rb * win.tw;
             for (int c = lane; c < win.tw; c += 64) t0[c] = g0[c];
         }
+#endif
     }
     // an empty window (no chief ray of the block reaches the target; or a degenerate one of a single row / column) holds no
     // ray: every valid ray is then a stray.  Its masked rays still READ two cells - clamped onto cells 0 and 1, see addr_hi_f -
@@ -2723,10 +2745,24 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
 }
 
 // Persistent workgroups over the work-item queue, like the forward kernel.
-// (the lean instantiation runs 768-thread workgroups - three waves per SIMD, 168 registers: the ring of distortion
-//  samples and the gradient sums do not fit the 128 registers of a 1024-thread workgroup, and vector issue is no slower
-//  with three waves than with four, tools/issue_bench.hip)
-constexpr int kLeanBwdThreads = 768;
+// The lean instantiation is compiled for 1024-thread workgroups (118 registers since the gradient window is staged with LDS-direct
+// loads - the staging batch's sixteen registers per lane were the kernel's peak, 155) and launched with 768 or 1024 threads:
+// items of 2048 points and more (a facet of the metric field: 2500 = 1024 + 1024 + 452 instead of 768 + 768 + 768 + 196, whose
+// last trip leaves one wave per SIMD) take 1024 - 3.61 -> 3.38 ms on the metric field, same box, interleaved -, smaller items
+// (one of eight ranks' share: 1250 points = 768 + 482) stay at 768 (0.512 against 0.529 ms).  The block GEOMETRY is always
+// computed for 768 threads, so the items - and with them every bit of the results - do not depend on the choice.
+#ifndef ART_LEAN_BWD_THREADS
+#define ART_LEAN_BWD_THREADS 1024
+#endif
+constexpr int kLeanBwdThreads = ART_LEAN_BWD_THREADS;       // launch bound
+constexpr int kLeanBwdGeometryThreads = 768;
+constexpr int kLeanBwdWidePoints = 2048;
+static int lean_bwd_threads(int p_block)
+{
+    const int forced = env_int("ARTIST_HIP_BWD_THREADS", 0);       // (tests, A/B: 768 or 1024)
+    if (forced == 768 || forced == 1024) return std::min(forced, kLeanBwdThreads);
+    return std::min(p_block >= kLeanBwdWidePoints ? 1024 : 768, kLeanBwdThreads);
+}
 // Points per item: every item stages a 158 KB gradient window and runs a window phase (~16 us), so fewer, larger blocks pay
 // as long as the chip still gets its rounds (window_geometry adds blocks when it does not).  Same-box sweep on the metric
 // field (10 000 points per heliostat): 7 blocks of 1429 points 4.16 ms, 5 x 2000 3.92, 4 x 2500 3.85-3.94, 3 x 3334 4.09-4.35,
@@ -3489,7 +3525,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                                 env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
         size_t perm_bytes = 0;
         if (lean || lean_block) {
-            cfg.block = lean_block ? kLeanBlockBwdThreads : kLeanBwdThreads;
+            cfg.block = lean_block ? kLeanBlockBwdThreads : kLeanBwdGeometryThreads;
             cfg.exact_pblock = true;
             if (lean || env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {
                 cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
@@ -3515,7 +3551,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         }
         if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
             fprintf(stderr, "art_trace_bwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
-                    a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean);
+                    a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, lean ? lean_bwd_threads(a.p_block) : cfg.block, (int)lean);
         const bool atomic_out = a.n_rchunks > 1;      // (round 1's name: today the chunks write slabs, nothing is atomic)
         // Blocking: every item of the blocking launch leaves its rectangle gradients in a slab [Cmax,12] of the scratch buffer
         // (behind the chunk slabs); reduce_prim_grads_kernel adds them in item order.
@@ -3541,7 +3577,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             TraceArgs al = a;
             al.split = mixed_split ? 0 : 1;
             FwdConfig cl = fwd_config();
-            cl.block = kLeanBwdThreads;
+            cl.block = kLeanBwdGeometryThreads;
             cl.exact_pblock = true;
             cl.facet_points = (int)facet_points;
             if (!cl.p_block_bwd_fixed) cl.p_block_bwd = kLeanBwdPoints;
@@ -3561,7 +3597,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                 unsigned* wc = stream_work_counters(stream);
                 if (wc == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
                 wc += 4;                                 // backward, lean launch of a split call
-                const int threads_l = cl.block;
+                const int threads_l = lean_bwd_threads(al.p_block);
                 // submitted AFTER the blocking launch (see art_trace_fwd)
                 SideStream* ss = side_stream();
                 if (ss != nullptr && !ss->begin(stream)) ss = nullptr;
@@ -3585,6 +3621,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             }
         }
         if (lean && a.n_rchunks == 1) set_queue_tail(a, 384);
+        if (lean) cfg.block = lean_bwd_threads(a.p_block);       // (the geometry is fixed by now)
         const int64_t items = host_item_count(a);
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
@@ -3676,7 +3713,7 @@ extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P,
     int64_t chunks = a.n_rchunks;
     // blocking: one [Cmax,12] slab of rectangle gradients per item of the blocking launch
     const int64_t prim_floats = Cmax > 0 ? (int64_t)H * a.n_pblocks * a.n_rchunks * Cmax * 12 : 0;
-    cfg.block = kLeanBwdThreads;                   // the lean kernel's geometry (art_trace_bwd picks one of the two)
+    cfg.block = kLeanBwdGeometryThreads;           // the lean kernel's geometry (art_trace_bwd picks one of the two)
     cfg.exact_pblock = true;
     cfg.facet_points = (int)facet_points;
     if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
