@@ -1921,6 +1921,35 @@ __device__ __forceinline__ void zero_block_gradients(const TraceArgs& a, const W
     }
 }
 
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(1))) const float glb_f32;
+
+// The backward items' gradient window: pth rows of tw cells of dL/dflux (LDS row k = bitmap row at g - k W: the bitmap is
+// flipped), one contiguous run of pth x tw floats at `tile`.  LDS-direct loads (global_load_lds_dword: lane l's dword lands at
+// LDS address M0 + 4 l, no destination registers): a wave takes every nwaves-th group of 64 cells and keeps ALL its loads in
+// flight - one round trip per item where sixteen registers per lane bought four rows per round trip (6.2 -> ~2 us per item,
+// tools/timeline.sh), and the staging batch no longer is the kernel's register peak (lean item: 155 -> 118).
+// Inlined: as a real call the function would read the dynamic-LDS base through the table the compiler builds for callees.
+__device__ __forceinline__ void stage_grad_window(const float* __restrict__ g, int W, int tw, int pth, float* tile, int wave,
+                                                  int lane, int nwaves)
+{
+    const int n_cells = pth * tw;
+    const int twd = max(tw, 1);
+    const int step = nwaves * 64;
+    const int sq = step / twd, sr = step - sq * twd;
+    const int i0 = wave * 64 + lane;
+    int row = i0 / twd, col = i0 - row * twd;
+    for (int base = wave * 64; base < n_cells; base += step) {
+        if (base + lane < n_cells)
+            __builtin_amdgcn_global_load_lds((glb_f32*)(g + (col - row * W)), (lds_f32*)(tile + base), 4, 0, 0);
+        col += sr; row += sq;
+        if (col >= twd) { col -= twd; ++row; }
+    }
+    // this wave's cells are in LDS before it reaches the caller's barrier (vmcnt(0); the compiler puts the same wait there for
+    // the barrier's fence - stated here so that the staging does not depend on that)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+}
+
 // (The cylinder and blocking instantiations keep ~60 more live values per ray; they run 768-thread workgroups =
 // 168 VGPRs, see kCylBwdThreads.)
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING>
@@ -1999,8 +2028,11 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     // this staging was 48 exposed round trips per wave - 16 us of a 195 us workgroup (tools/timeline.sh), 12 us of it
     // waiting for memory.
     {
-        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;      // flat row k sits at gbase - k W
+#ifndef ART_STAGE_THROUGH_VGPRS
+        stage_grad_window(G + gbase, a.W, win.tw, pth, gtile, wave, lane, nwaves);    // (round 3: LDS-direct loads, see there)
+#else
+        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int64_t dg = (int64_t)nwaves * a.W;
         const int dt = nwaves * win.tw;
         const int tw4 = win.tw & ~3;                                         // columns covered by whole 16-byte loads
@@ -2027,6 +2059,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
             float* t0 = gtile + rb * win.tw;
             for (int c = lane; c < win.tw; c += 64) t0[c] = g0[c];
         }
+#endif
     }
     if (tid < 2) gtile[a.tile_cap + tid] = 0.0f;
     __syncthreads();
@@ -2276,8 +2309,6 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
 //   A = chu g1 + clu g4,  B = chu g2 + clu g3   ->  dL/dI = cle A + che B,  dL/dbe = (B - A) I
 //   dL/dbu = (cle (g1 - g4) + che (g2 - g3)) I
 // --------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) float lds_f32;
-typedef __attribute__((address_space(1))) const float glb_f32;
 
 // BLOCKING: the same item with the soft blocking mask recomputed per ray, its factor `keep` in the intensity, and the mask's
 // adjoint (block_adjoint: ray side into this thread's sums, rectangle side into the wave's owner-lane registers, see there) -
@@ -2371,30 +2402,13 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const int pth = min(win.ths, win.u0 + win.th - pu0);
     const bool first = pass == 0;
     if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
-    {   // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped: see trace_bwd_item
-        // (four rows per wave in flight: 6-8 us per item, tools/timeline.sh.  Eight rows measured 3.65 against 3.53 ms for the
-        //  kernel, twelve 4.4 - the batch's registers are allocated on top of the ray loop's; as a real call the batch faulted
-        //  on the dynamic-LDS table the compiler builds for callees, and was not pursued)
+    {   // stage dL/dflux rows (flat row k = output row Hh-1-k) into LDS, un-flipped: stage_grad_window
+        // (until late in round 3 through registers, four rows per wave in flight - the #else branch: 6-8 us per item,
+        //  tools/timeline.sh; eight rows measured 3.65 against 3.53 ms for the kernel, twelve 4.4 - the batch's registers are
+        //  allocated on top of the ray loop's)
         const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;
 #ifndef ART_STAGE_THROUGH_VGPRS
-        // LDS-direct loads (global_load_lds_dword: lane l's dword lands at LDS address M0 + 4 l, no destination registers): the
-        // window is one contiguous run of pth x tw cells, a wave takes every nwaves-th group of 64 cells and keeps ALL its loads
-        // in flight - one round trip per item instead of one per four rows.
-        {
-            const int n_cells = pth * win.tw;
-            const int twd = max(win.tw, 1);
-            const int step = nwaves * 64;
-            const int sq = step / twd, sr = step - sq * twd;
-            const int i0 = wave * 64 + lane;
-            int row = i0 / twd, col = i0 - row * twd;
-            const float* __restrict__ gb = G + gbase;
-            for (int base = wave * 64; base < n_cells; base += step) {
-                if (base + lane < n_cells)
-                    __builtin_amdgcn_global_load_lds((glb_f32*)(gb + (col - row * a.W)), (lds_f32*)(gtile + base), 4, 0, 0);
-                col += sr; row += sq;
-                if (col >= twd) { col -= twd; ++row; }
-            }
-        }
+        stage_grad_window(G + gbase, a.W, win.tw, pth, gtile, wave, lane, nwaves);
 #else
         struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
         const int64_t dg = (int64_t)nwaves * a.W;
