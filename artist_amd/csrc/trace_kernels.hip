@@ -2761,8 +2761,8 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
 // Persistent workgroups over the work-item queue, like the forward kernel.
 // The lean instantiation is compiled for 1024-thread workgroups (118 registers since the gradient window is staged with LDS-direct
 // loads - the staging batch's sixteen registers per lane were the kernel's peak, 155) and launched with 768 or 1024 threads:
-// items of 2048 points and more (a facet of the metric field: 2500 = 1024 + 1024 + 452 instead of 768 + 768 + 768 + 196, whose
-// last trip leaves one wave per SIMD) take 1024 - 3.61 -> 3.38 ms on the metric field, same box, interleaved -, smaller items
+// items of 2048 points and more (a facet of the metric field: 2500 = 1024 + 1024 + 452 instead of 768 + 768 + 768 + 196)
+// take 1024 - 3.61 -> 3.38 ms on the metric field, same box, interleaved -, smaller items
 // (one of eight ranks' share: 1250 points = 768 + 482) stay at 768 (0.512 against 0.529 ms).  The block GEOMETRY is always
 // computed for 768 threads, so the items - and with them every bit of the results - do not depend on the choice.
 #ifndef ART_LEAN_BWD_THREADS
