@@ -18,7 +18,8 @@ def run(name, H, R, steps=5):
     tix = torch.zeros(H, dtype=torch.long, device=dev)
     inc = torch.tensor([[0.0, 1.0, 0.0, 0.0]], device=dev).repeat(H, 1)
     g.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask)
-    both = torch.randn((H, R, g.active_surface_points.shape[1], 2), device=dev).mul_(4.3681e-06 ** 0.5)
+    gen = torch.Generator(device=dev).manual_seed(7)       # (the same sample in every run: the printed flux sums are comparable)
+    both = torch.randn((H, R, g.active_surface_points.shape[1], 2), device=dev, generator=gen).mul_(4.3681e-06 ** 0.5)
     planar = scenario.solar_tower.target_areas[0]
     args = (g.active_surface_points, g.active_surface_normals, inc, both[..., 0], both[..., 1], tix, planar.centers,
             planar.normals, planar.dimensions, 1.0, 0.0, 0.935, (256, 256))
