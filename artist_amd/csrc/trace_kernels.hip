@@ -1941,7 +1941,7 @@ __device__ __forceinline__ void stage_grad_window(const float* __restrict__ g, i
     int row = i0 / twd, col = i0 - row * twd;
     for (int base = wave * 64; base < n_cells; base += step) {
         if (base + lane < n_cells)
-            __builtin_amdgcn_global_load_lds((glb_f32*)(g + (col - row * W)), (lds_f32*)(tile + base), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_f32*)(g + ((int64_t)col - (int64_t)row * W)), (lds_f32*)(tile + base), 4, 0, 0);
         col += sr; row += sq;
         if (col >= twd) { col -= twd; ++row; }
     }
