@@ -42,6 +42,7 @@ SIGNATURES = {
                       _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _ptr],
     "art_trace_bwd_scratch_floats": [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64],
+    "art_trace_bwd_scratch_need": [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64],
     "art_flux_crop_fwd": [_ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],
     "art_flux_crop_bwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr],
     "art_flux_loss": [_ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr],
@@ -111,7 +112,7 @@ def lib() -> ctypes.CDLL:
             raise ArtistHipError(f"{LIB_PATH} does not export {name}") from exc
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "art_strerror"
-                      else ctypes.c_int64 if name in ("art_blocking_workspace_bytes", "art_trace_bwd_scratch_floats")
+                      else ctypes.c_int64 if name in ("art_blocking_workspace_bytes", "art_trace_bwd_scratch_floats", "art_trace_bwd_scratch_need")
                       else ctypes.c_int)
     if handle.art_abi_version() != ABI_VERSION:
         raise ArtistHipError(f"ABI mismatch: library {handle.art_abi_version()} vs binding {ABI_VERSION}")

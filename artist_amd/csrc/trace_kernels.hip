@@ -3230,6 +3230,54 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     a.reverse_items = env_int("ARTIST_HIP_REVERSE", -1);       // -1: decided on the device (farther_end_is_last)
 }
 
+// The geometry of art_trace_bwd's MAIN launch - decided in ONE place for art_trace_bwd and for the two entry points that
+// size its scratch buffer (round 3 sized the rectangle-gradient slabs from the generic geometry while the call took the lean
+// one, whose facet-sized items are more numerous: a buffer of exactly the reported size was rejected).
+//   lean        planar receivers, no blocking: trace_bwd_item_lean, one block per facet
+//   lean_block  planar receivers, blocking: the same body with the soft mask and its adjoint
+//   otherwise   the generic item (cylinders; blocking with ARTIST_HIP_BLOCK_LEAN=0)
+//   whole_samples: never cut a point's samples into chunks (no room for the [n_rchunks,H,P] slabs)
+static size_t bwd_main_geometry(TraceArgs& a, FwdConfig& cfg, bool lean, bool lean_block, int64_t facet_points, bool whole_samples)
+{
+    size_t perm_bytes = 0;
+    if (lean || lean_block) {
+        cfg.block = lean_block ? kLeanBlockBwdThreads : kLeanBwdGeometryThreads;
+        cfg.exact_pblock = true;
+        if (lean || env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {
+            cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
+            if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
+        }
+        // edge points packed into the block's last waves (trace_bwd_item_lean): the permutation lives behind the window
+        a.pack_edge = std::min(std::max(env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
+        if (a.pack_edge != 0) {
+            perm_bytes = 2 * kPackPoints;
+            cfg.tile_cap = std::min<int>(cfg.tile_cap, (int)((160 * 1024 - 1408 - (lean_block ? kLeanBlockBwdStatic : 0) - perm_bytes - 8) / 4) / 64 * 64);
+        }
+    }
+    if (whole_samples) cfg.target_blocks = 1;
+    // (cylinders, the generic item: facet-sized balanced blocks measured slower - 12.7 vs 12.45 ms forward + backward,
+    //  tools/cylinder_bench.py - so they keep round 2's 2048-point blocks)
+    window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+    return perm_bytes;
+}
+
+// Scratch floats a backward launch of geometry `a` needs: [n_rchunks,H,P,8] slabs of partial point gradients when the samples
+// are cut into chunks, then one [Cmax,12] slab of rectangle gradients per item when blocking is on.
+struct BwdScratch { int64_t chunk_floats, slab_floats; };
+static BwdScratch bwd_scratch_need(const TraceArgs& a, bool blocking, int64_t Cmax)
+{
+    BwdScratch n;
+    n.chunk_floats = a.n_rchunks > 1 ? (int64_t)a.n_rchunks * a.H * a.P * 8 : 0;
+    n.slab_floats = blocking ? (int64_t)a.H * a.n_pblocks * a.n_rchunks * Cmax * 12 : 0;
+    return n;
+}
+
+static bool bwd_uses_lean(bool blocking, int64_t T, int64_t Tc) { return !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0; }
+static bool bwd_uses_lean_block(bool blocking, int64_t T, int64_t Tc)
+{
+    return blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0 && env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
+}
+
 }  // namespace art
 
 using namespace art;
@@ -3532,36 +3580,21 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;   // room for the rectangle tables in LDS
     if (cfg.variant == 0) {
         // the lean ray body (trace_bwd_item_lean): planar receivers, no blocking; 768-thread workgroups, one block per facet
-        const bool lean = !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0;
+        const bool lean = bwd_uses_lean(blocking, T, Tc);
         // ... and with blocking on, the heliostats WITH candidate rectangles take the same body with the soft mask and its
         // adjoint (trace_bwd_item_lean<.., BLOCKING>) instead of the generic item
-        const bool lean_block = blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0 &&
-                                env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
-        size_t perm_bytes = 0;
-        if (lean || lean_block) {
-            cfg.block = lean_block ? kLeanBlockBwdThreads : kLeanBwdGeometryThreads;
-            cfg.exact_pblock = true;
-            if (lean || env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {
-                cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
-                if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
-            }
-            // edge points packed into the block's last waves (trace_bwd_item_lean): the permutation lives behind the window
-            a.pack_edge = std::min(std::max(env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
-            if (a.pack_edge != 0) {
-                perm_bytes = 2 * kPackPoints;
-                cfg.tile_cap = std::min<int>(cfg.tile_cap, (int)((160 * 1024 - 1408 - (lean_block ? kLeanBlockBwdStatic : 0) - perm_bytes - 8) / 4) / 64 * 64);
-            }
-        }
-        // (cylinders, the generic item: facet-sized balanced blocks measured slower - 12.7 vs 12.45 ms forward + backward,
-        //  tools/cylinder_bench.py - so they keep round 2's 2048-point blocks)
-        window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+        const bool lean_block = bwd_uses_lean_block(blocking, T, Tc);
+        const FwdConfig cfg0 = cfg;
+        size_t perm_bytes = bwd_main_geometry(a, cfg, lean, lean_block, facet_points, false);
         // A small field is cut into sample chunks to fill the chip; the chunks of a point then write partial gradients
         // to [n_rchunks,H,P] slabs in the caller's scratch buffer and reduce_chunks_kernel adds them in chunk order
         // (no float atomics: bit-reproducible gradients).  Without (enough) scratch the samples stay in one item.
-        if (a.n_rchunks > 1 && (grad_scratch == nullptr || (reinterpret_cast<uintptr_t>(grad_scratch) % 16) != 0 ||
-                                grad_scratch_floats < (int64_t)a.n_rchunks * H * P * 8)) {
-            cfg.target_blocks = 1;
-            window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
+        const bool scratch_usable = grad_scratch != nullptr && (reinterpret_cast<uintptr_t>(grad_scratch) % 16) == 0;
+        BwdScratch need = bwd_scratch_need(a, blocking, Cmax);
+        if (a.n_rchunks > 1 && (!scratch_usable || grad_scratch_floats < need.chunk_floats + need.slab_floats)) {
+            cfg = cfg0;
+            perm_bytes = bwd_main_geometry(a, cfg, lean, lean_block, facet_points, true);
+            need = bwd_scratch_need(a, blocking, Cmax);
         }
         if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
             fprintf(stderr, "art_trace_bwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
@@ -3571,12 +3604,9 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         // (behind the chunk slabs); reduce_prim_grads_kernel adds them in item order.
         float* prim_slabs = nullptr;
         if (blocking) {
-            const int64_t chunk_floats = atomic_out ? (int64_t)a.n_rchunks * H * P * 8 : 0;
-            const int64_t slab_floats = (int64_t)a.H * a.n_pblocks * a.n_rchunks * a.Cmax * 12;
-            if (grad_scratch == nullptr || (reinterpret_cast<uintptr_t>(grad_scratch) % 16) != 0 ||
-                grad_scratch_floats < chunk_floats + slab_floats)
+            if (!scratch_usable || grad_scratch_floats < need.chunk_floats + need.slab_floats)
                 return ART_EINVAL;                    // (art_trace_bwd_scratch_floats says how much)
-            prim_slabs = grad_scratch + chunk_floats;
+            prim_slabs = grad_scratch + need.chunk_floats;
         }
         SideJoin side = {nullptr};                    // (joins `stream` when this scope is left, errors included)
         std::function<int()> launch_lean;
@@ -3714,26 +3744,31 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     return ART_OK;
 }
 
-extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t Cmax)
+// What art_trace_bwd asks of its scratch buffer for ONE receiver configuration (T planar, Tc cylindrical areas; Cmax > 0:
+// blocking on), when it is given at least that much: the floats of the geometry it then takes.  Host arithmetic only.
+extern "C" int64_t art_trace_bwd_scratch_need(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t Cmax)
 {
-    if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || Cmax < 0 || Cmax > kMaxCand) return 0;
-    TraceArgs a = {};
-    a.H = (int)H; a.R = (int)R; a.P = (int)P;
+    if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || Cmax < 0 || Cmax > kMaxCand || T < 0 || Tc < 0) return 0;
     FwdConfig cfg = fwd_config();
     if (cfg.variant != 0) return 0;
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return 0;
-    a.facet_points = (int)P; a.blocks_per_facet = 1;
-    window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);      // the generic kernels' geometry (cylinders, blocking)
-    int64_t chunks = a.n_rchunks;
-    // blocking: one [Cmax,12] slab of rectangle gradients per item of the blocking launch
-    const int64_t prim_floats = Cmax > 0 ? (int64_t)H * a.n_pblocks * a.n_rchunks * Cmax * 12 : 0;
-    cfg.block = kLeanBwdGeometryThreads;           // the lean kernel's geometry (art_trace_bwd picks one of the two)
-    cfg.exact_pblock = true;
-    cfg.facet_points = (int)facet_points;
-    if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
-    window_geometry(a, cfg, cfg.p_block_bwd, cfg.p_block_bwd_fixed);
-    chunks = std::max<int64_t>(chunks, a.n_rchunks);
-    return (chunks > 1 ? chunks * H * P * 8 : 0) + prim_floats;
+    const bool blocking = Cmax > 0;
+    TraceArgs a = {};
+    a.H = (int)H; a.R = (int)R; a.P = (int)P; a.Cmax = (int)Cmax;
+    if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;
+    (void)bwd_main_geometry(a, cfg, bwd_uses_lean(blocking, T, Tc), bwd_uses_lean_block(blocking, T, Tc), facet_points, false);
+    const BwdScratch n = bwd_scratch_need(a, blocking, Cmax);
+    return n.chunk_floats + n.slab_floats;
+}
+
+// The caller's side of it: enough for every receiver configuration (the tables' types are not known when the buffer is
+// allocated) = the largest need over the geometries art_trace_bwd can take for these sizes.
+extern "C" int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t Cmax)
+{
+    int64_t most = 0;
+    for (int cfgno = 0; cfgno < 3; ++cfgno)       // planar only / cylinders only / both
+        most = std::max(most, art_trace_bwd_scratch_need(H, R, P, facet_points, cfgno == 1 ? 0 : 1, cfgno == 0 ? 0 : 1, Cmax));
+    return most;
 }
 
 extern "C" int art_per_target_sum(const float* bitmaps, const int32_t* target_idx, int64_t H, int64_t T,

@@ -163,8 +163,15 @@ int art_trace_bwd(const float *origins, const float *normals, const float *incid
  * in one work item, which is reproducible too but leaves most of the chip idle on a field of a few heliostats.
  * With blocking (Cmax = the capacity passed to art_blocking_filter) the buffer is REQUIRED: every work item leaves its
  * rectangle gradients in a [Cmax,12] slab and a last kernel adds the slabs in item order - the rectangle gradients are
- * bit-reproducible as well (no float atomics anywhere in the trace kernels). */
+ * bit-reproducible as well (no float atomics anywhere in the trace kernels).
+ * The size covers every receiver configuration art_trace_bwd can meet for these sizes (planar, cylindrical, mixed: the
+ * launch geometries differ and the caller allocates before the tables' types matter); art_trace_bwd never rejects a
+ * buffer of this size (tests/test_host_logic.py sweeps it). */
 int64_t art_trace_bwd_scratch_floats(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t Cmax);
+
+/* ... and what art_trace_bwd uses of it for ONE receiver configuration (T planar and Tc cylindrical target areas): the
+ * floats of the launch geometry it takes when given at least that much.  Host arithmetic only, no GPU call. */
+int64_t art_trace_bwd_scratch_need(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t Cmax);
 
 /* ---------------------------------------------------------------------------------------------
  * art_blocking_filter - lbvh_filter_blocking_planes (artist/raytracing/blocking.py:832-995, with the tree of

@@ -1492,6 +1492,44 @@ def test_random_scenes_split_calls(seed, H, P, R, variant, monkeypatch):
     assert rel_l2(n(o.grad), go) < tol and rel_l2(n(nn_.grad), gn) < tol
 
 
+def test_blocking_backward_with_facet_sized_items():
+    """Blocking backward on a planar tower at the metric config's point count (P = 10 000 in four facets, ~100 heliostats): the
+    call takes the lean blocking item in FACET-sized blocks, whose rectangle-gradient slabs are more numerous than the generic
+    geometry's - round 3 sized the scratch buffer from the latter and this call raised ART_EINVAL (advisor finding; every other
+    blocking-backward test runs at P <= 1500, where the two geometries coincide).  Against the oracle on the same inputs."""
+    from artist_amd import _lib, trace_rays
+    H, P, R, facet = 100, 10000, 24, 2500
+    lib = _lib.lib()
+    # the case is only worth its time while the two geometries differ at this size
+    assert lib.art_trace_bwd_scratch_need(H, R, P, facet, 2, 0, 8) != lib.art_trace_bwd_scratch_need(H, R, P, facet, 0, 1, 8)
+    sc = _random_feature_scene(21, H, P, R)
+    dv = lambda x: x.to(DEV)
+    f32 = lambda x: np.ascontiguousarray(x.detach().cpu().numpy())
+    tix = sc["target_idx"] % 2
+    prims = {k: dv(v) for k, v in sc["prims"].items()}
+    prims["corners"].requires_grad_(True)
+    o, nn_ = dv(sc["origins"]).requires_grad_(True), dv(sc["normals"]).requires_grad_(True)
+    both = dv(sc["both"])
+    args = (o, nn_, dv(sc["incident"]), both[..., 0], both[..., 1], dv(tix), dv(sc["planes"]["centers"]),
+            dv(sc["planes"]["normals"]), dv(sc["planes"]["dims"]))
+    res = (128, 128)
+    flux, fac, _ = trace_rays(*args, ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=res,
+                              blocking=dict(prims, lbvh_compat=False), points_per_facet=facet)
+    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(21)).to(DEV)
+    (flux * w).sum().backward()                       # raised ArtistHipError(ART_EINVAL) before the fix
+    torch.cuda.synchronize()
+    oracle_args = (f32(sc["origins"]), f32(sc["normals"]), f32(sc["incident"]), f32(sc["both"][..., 0]), f32(sc["both"][..., 1]),
+                   f32(tix), f32(sc["planes"]["centers"]), f32(sc["planes"]["normals"]), f32(sc["planes"]["dims"]), res)
+    okw = dict(blocking=dict({k: f32(v) for k, v in sc["prims"].items()}, lbvh_compat=False))
+    o_flux, o_fac = oracle.trace_fwd(*oracle_args, 0.7, 0.05, 0.9, **okw)[:2]
+    assert o_flux.sum() > 0 and (n(fac[2]) < 1).any()
+    assert rel_l2(n(flux), o_flux) < 1e-5, rel_l2(n(flux), o_flux)
+    go, gn, gpc, _, _ = oracle.trace_bwd(*oracle_args, f32(w), 0.7, 0.05, 0.9, **okw)
+    assert rel_l2(n(o.grad), go) < 2e-5, rel_l2(n(o.grad), go)
+    assert rel_l2(n(nn_.grad), gn) < 2e-5, rel_l2(n(nn_.grad), gn)
+    assert np.linalg.norm(gpc) > 0 and rel_l2(n(prims["corners"].grad), gpc) < 2e-5, rel_l2(n(prims["corners"].grad), gpc)
+
+
 @pytest.mark.parametrize("res", [(700, 40), (40, 700), (2, 2), (3, 1500)])
 def test_extreme_bitmap_shapes(golden, res):
     """Very wide / very tall / minimal bitmaps: windows wider than half the LDS capacity, multi-pass row bands, and

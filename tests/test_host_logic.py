@@ -352,3 +352,60 @@ def test_h5lite_is_pinned_by_an_independent_scan_of_the_raw_bytes(name):
         walk(f)
     assert seen == table, (sorted(seen - table)[:3], sorted(table - seen)[:3])
     assert len(table) >= 35 and 3 <= strings <= 40
+
+
+def test_trace_bwd_never_rejects_a_buffer_of_the_reported_scratch_size():
+    """Round-3 advisor finding: `art_trace_bwd_scratch_floats` sized the rectangle-gradient slabs from the generic launch geometry
+    while a planar tower with blocking takes the lean one (facet-sized items: more of them), so `art_trace_bwd` rejected a buffer
+    of exactly the reported size (H=100, R=100, P=10000, facet 2500, Cmax=8: 67200 reported).  The two now share one geometry
+    routine; this sweeps sizes, facets, capacities and receiver configurations through the host arithmetic
+    (`art_trace_bwd_scratch_need` = what the call takes for one configuration) ..."""
+    from artist_amd import _lib
+    lib = _lib.lib()
+    worst = 0
+    for R, P, facet in ((100, 10000, 2500), (180, 3600, 900), (1, 10000, 2500), (4, 400, 100), (100, 10000, 0), (7, 1024, 256)):
+        for Cmax in (0, 1, 8, 16, 32):
+            for H in list(range(1, 600, 7)) + [1000, 4096]:
+                reported = lib.art_trace_bwd_scratch_floats(H, R, P, facet, Cmax)
+                for T, Tc in ((1, 0), (0, 1), (2, 1)):
+                    need = lib.art_trace_bwd_scratch_need(H, R, P, facet, T, Tc, Cmax)
+                    assert need <= reported, (H, R, P, facet, Cmax, T, Tc, need, reported)
+                    worst = max(worst, need)
+                assert Cmax == 0 or reported >= H * Cmax * 12
+    assert worst > 0
+    assert lib.art_trace_bwd_scratch_floats(100, 100, 10000, 2500, 8) > 67200      # the advisor's case
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="host arithmetic with placeholder pointers: only where no kernel can be launched")
+def test_trace_bwd_accepts_the_reported_scratch_size_on_the_host():
+    """... and, where there is no GPU to launch on, through `art_trace_bwd` itself: with placeholder pointers (the host code never
+    dereferences device memory) the call must get PAST its argument checks with a buffer of the reported size - it then fails
+    at the first HIP call (ART_ELAUNCH), never with ART_EINVAL - and must fail WITH ART_EINVAL when blocking is on and the
+    buffer is one float short."""
+    import ctypes
+
+    from artist_amd import _lib
+    lib = _lib.lib()
+    fake = ctypes.c_void_p(0x1000)       # 16-byte aligned, never dereferenced
+    null = ctypes.c_void_p(0)
+
+    def call(H, R, P, facet, T, Tc, Cmax, scratch_floats):
+        planar = [fake if T else null] * 3
+        cyl = [fake if Tc else null] * 6
+        prim = [fake if Cmax else null] * 5
+        return lib.art_trace_bwd(fake, fake, fake, fake, fake, 2 * R * P, 2 * P, 2, fake, *planar, *cyl, *prim, Cmax, max(Cmax, 1) * 4, 0.01,
+                                 1.0, 1.0, 0.935, H, R, P, facet, T, Tc, 256, 256, 0, fake, fake, fake,
+                                 *([fake if Cmax else null] * 3), fake, scratch_floats, null)
+
+    ART_EINVAL = -1
+    for R, P, facet in ((100, 10000, 2500), (180, 3600, 900)):
+        for Cmax in (0, 8, 16):
+            for H in (1, 3, 60, 100, 101, 313, 599):
+                reported = lib.art_trace_bwd_scratch_floats(H, R, P, facet, Cmax)
+                for T, Tc in ((1, 0), (0, 1), (1, 1)):
+                    rc = call(H, R, P, facet, T, Tc, Cmax, reported)
+                    assert rc != ART_EINVAL and rc != 0, (H, R, P, facet, Cmax, T, Tc, rc)
+                    if Cmax:
+                        need = lib.art_trace_bwd_scratch_need(H, R, P, facet, T, Tc, Cmax)
+                        whole = H * Cmax * 12          # the least any geometry needs
+                        assert call(H, R, P, facet, T, Tc, Cmax, min(need, whole) - 1) == ART_EINVAL
