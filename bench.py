@@ -311,21 +311,36 @@ def main():
 
     for _ in range(args.warmup):
         step(True)
-    # the two trace calls of every timed step are bracketed by HIP events on the stream they are launched on
-    # (ops.record_launch_events: two event records per call, no synchronisation) - the roofline's launch duration
-    launches = ops.record_launch_events(True)
+    # ---- region 1, the headline: EXACTLY K steps between barrier + synchronize on both sides, nothing else inside ----
     dt = timed(lambda: step(True), args.steps)
+    # ---- region 2, the same K steps once more with HIP events: one pair per STEP (the median step) and one pair around each
+    # of the two trace calls, on the stream they are launched on (ops.record_launch_events: two event records per call, no
+    # synchronisation) - the roofline's launch durations.  Outside the headline region (round 3 recorded them inside it).
+    launches = ops.record_launch_events(True)
+    step_events = []
+
+    def step_with_events():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step(True)
+        b.record()
+        step_events.append((a, b))
+
+    dt_events = timed(step_with_events, args.steps)
     ops.record_launch_events(False)
     dt_fwd = timed(lambda: step(False), args.steps)
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
+    median_step_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     def mean_ms(pairs):
         return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
 
     # art_trace_bwd at this size = ONE launch of trace_bwd_lds_kernel (small fields: + reduce_chunks_kernel);
     # art_trace_fwd = trace_fwd_lds_kernel + the accumulator conversion + the factors
+    assert len(launches.get("art_trace_bwd", ())) == args.steps and len(launches.get("art_trace_fwd", ())) == args.steps, \
+        {k: len(v) for k, v in launches.items()}
     ms_bwd_timed = mean_ms(launches["art_trace_bwd"])
     ms_fwd_call_timed = mean_ms(launches["art_trace_fwd"])
-    assert len(launches["art_trace_bwd"]) == args.steps and len(launches["art_trace_fwd"]) == args.steps
 
     # ---- the same calls back to back (five of each), HIP events on the launch stream: reported beside the timed region's ----
     def kernel_ms(fn, k=5):
@@ -354,9 +369,14 @@ def main():
     # + one bitmap write (fwd) / one grad-bitmap read + 32 B/point grad write (bwd)
     bytes_fwd = rays_local * 8 + H * P * 32 + H * 256 * 256 * 4
     bytes_bwd = rays_local * 8 + H * P * 32 + H * P * 32 + H * 256 * 256 * 4
-    # dominant kernel: the backward one (its launch is all of art_trace_bwd; the forward CALL holds 0.2 ms of conversion pass
-    # beside its trace kernel and still is the shorter of the two) - priced with its launches INSIDE the timed region
-    dom = dict(kernel="trace_bwd_lds_kernel", ms=ms_bwd_timed, bytes=bytes_bwd)
+    # dominant kernel: the longer of the two trace CALLS as measured in region 2.  art_trace_bwd is ONE launch of
+    # trace_bwd_lds_kernel at this size; the forward call is trace_fwd_lds_kernel + the accumulator conversion pass (+ two
+    # 5 us kernels), priced as a whole with the call's algorithmic bytes (the conversion's traffic is overhead, not algorithm).
+    if ms_bwd_timed >= ms_fwd_call_timed:
+        dom = dict(kernel="trace_bwd_lds_kernel", ms=ms_bwd_timed, bytes=bytes_bwd, what="one launch = all of art_trace_bwd")
+    else:
+        dom = dict(kernel="trace_fwd_lds_kernel", ms=ms_fwd_call_timed, bytes=bytes_fwd,
+                   what="the art_trace_fwd call: trace_fwd_lds_kernel + accum_to_flux_kernel + factor kernels")
     achieved = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
     # HBM bytes per launch: REPLAYED from the rocprofv3 --pmc passes of this same command that are committed under
     # profiles/ (separate passes, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes) - not measured by this run,
@@ -416,6 +436,10 @@ def main():
             "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # region 2 (same K steps again, one HIP-event pair per step on the launch stream): median and spread of a step
+            "step_events": {"median_ms": median_step_ms, "min_ms": step_ms[0], "max_ms": step_ms[-1],
+                            "wall_ms_per_step": dt_events / args.steps * 1e3,
+                            "what": "second timed region of K steps, HIP events per step + per trace call; the headline region holds no event record"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -428,8 +452,8 @@ def main():
                        "parallelism": f"heliostat-sharded dp{world}", "heliostats_per_rank": H},
             "fwd_only": {"value": total_rays * args.steps / dt_fwd, "unit": "rays/s",
                          "ms_per_step": dt_fwd / args.steps * 1e3},
-            "kernels": {"where": "HIP events around art_trace_fwd / art_trace_bwd on their launch stream, mean over the timed "
-                                 "region's steps (art_trace_fwd = trace kernel + accumulator conversion + factors)",
+            "kernels": {"where": "HIP events around art_trace_fwd / art_trace_bwd on their launch stream, mean over the K steps of the "
+                                 "second timed region (art_trace_fwd = trace kernel + accumulator conversion + factors)",
                         "trace_fwd_ms": ms_fwd_call_timed, "trace_bwd_ms": ms_bwd_timed,
                         "trace_fwd_rays_per_s": rays_local / (ms_fwd_call_timed * 1e-3),
                         "trace_fwd_GBps": bytes_fwd / (ms_fwd_call_timed * 1e-3) / 1e9,
@@ -444,7 +468,7 @@ def main():
                                          "trace_bwd_GBps": bytes_bwd / (ms_bwd * 1e-3) / 1e9}},
             "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"],
+                         "bytes_per_launch": dom["bytes"], "ms_per_launch": dom["ms"], "launch": dom["what"],
                          # what a hand-written float4 streaming kernel reaches on this pool's MI355X (tools/hbm_peak.hip):
                          # replayed from profiles/, next to the 8 TB/s spec peak that `frac` is quoted against
                          "peak_measured": None if measured_peak is None else {
