@@ -10,6 +10,7 @@ backward, behind ARTIST's own call surface:
                                     <-> artist.flux.bitmap / artist.optim.loss (the per-epoch flux epilogue)
     artist_amd.RigidBody            <-> artist.field.kinematics_rigid_body.RigidBody (ideal + linear actuators)
     artist_amd.Scenario             <-> artist.scenario.scenario.Scenario (load_scenario_from_hdf5, index_mapping)
+    artist_amd.optim.Adam           <-> torch.optim.Adam as the reconstructors use it (the epoch's optimiser step)
 
 All arithmetic runs in hand-written HIP kernels (``artist_amd/csrc``) reached through the C ABI in
 ``include/artist_hip.h``; there is no CPU fallback.
@@ -20,6 +21,7 @@ from .flux import (FocalSpotLoss, KLDivergenceLoss, PixelLoss, bitmap_coordinate
                    crop_and_kl_loss, crop_and_pixel_loss, crop_flux_distributions_around_center, get_center_of_mass)
 from .kinematics import Actuators, RigidBody  # noqa: F401
 from .ops import align_surfaces, nurbs_surface_points_and_normals, per_target_sum, trace_rays  # noqa: F401
+from . import optim  # noqa: F401
 from .raytracing import HeliostatRayTracer  # noqa: F401
 from .scenario import Scenario, open_scenario_file  # noqa: F401
 from .sampling import DistortionsDataset, RestrictedDistributedSampler  # noqa: F401

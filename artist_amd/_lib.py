@@ -15,7 +15,7 @@ _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ArtistHipError(RuntimeError):
@@ -67,6 +67,7 @@ SIGNATURES = {
     "art_nurbs_bwd": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_i64,
                       _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_reflect": [_ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr],
+    "art_adam_step": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_int, _c_i64, _c_i64, _ptr],
     "art_align_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr],
     "art_align_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr],
     "art_abi_version": [],

@@ -1,6 +1,7 @@
 // launch_common.hpp - error plumbing + small wave-level helpers shared by the kernel files.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/artist_hip.h"
 
@@ -17,6 +18,17 @@ extern thread_local int g_last_hip_error;
             return ART_ELAUNCH;                         \
         }                                               \
     } while (0)
+
+// Diagnostic knobs (launch geometry, A/B paths; results are the same bits or within the documented rounding for every value):
+// the library reads ARTIST_HIP_* variables ONLY when ARTIST_HIP_DEBUG=1 is set - a caller's environment cannot change what the
+// product launches (tests and tools/ set both).
+static inline int debug_env_int(const char* name, int dflt)
+{
+    const char* dbg = getenv("ARTIST_HIP_DEBUG");
+    if (dbg == nullptr || dbg[0] != '1') return dflt;
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 // 64-lane wave sum (gfx950 wavefront = 64); result valid in lane 0.
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v)

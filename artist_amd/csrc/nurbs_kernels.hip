@@ -1,13 +1,29 @@
 // nurbs_kernels.hip - NURBS surface points + normals (forward) and control-point gradients
 // (backward) for gfx950 / MI355X.
 //
-// One workgroup per (heliostat, facet) x tile of evaluation points.  The facet's control-point
-// net (nu*nv*3 floats, 1.2 KB at 10x10) and its two knot vectors are staged once in LDS and
-// then gathered from there (16 control points per evaluation at degree 3); one thread owns one
-// evaluation point.  Backward privatises the facet's gradient net in LDS and writes it out once
-// with plain stores - no global atomics.  The LDS accumulator is DOUBLE: on gfx950 ds_add_f64 retires
-// a wave instruction in ~25 cycles whereas ds_add_f32 needs ~193 (tools/lds_atomic_bench.hip), and the
-// wider accumulator makes the sum insensitive to the order of the adds at fp32 output precision.
+// Two evaluation schemes behind one entry point, chosen per workgroup ON THE DEVICE:
+//
+//  * TENSOR-PRODUCT (round 4).  ARTIST's evaluation points are a cartesian grid (artist/nurbs/utils.py:37-49:
+//    cartesian_prod(u_lin, v_lin), point m = i Mv + j at (u_i, v_j)), so S = B_u CP B_v^T factorises: the basis functions
+//    are computed once per grid ROW and COLUMN (Mu + Mv evaluations of A2.3 with its divisions instead of 2 Mu Mv), stage 1
+//    contracts the control net with the row bases (temp[i][c] = sum_r Nu_i[r] CP[su_i-p+r][c], and the same with Du), stage 2
+//    contracts with the column bases per point.  The sums run in the reference's order (r, then s, from a zero
+//    accumulator, no FMA contraction), so points are bit-identical to the scattered scheme, the oracle and the reference.
+//    The backward is the adjoint of the two stages with every output element owned by ONE thread that adds its terms in
+//    index order - no atomics of any kind, control-point gradients are bit-reproducible.  The workgroup discovers the grid
+//    itself (row length = index of the first point whose u differs from point 0's; then every point is compared with
+//    (u of its row's first point, v of its column's first point)): no flag in the API, no host synchronisation, and points
+//    that are not a grid simply take the other scheme.
+//  * SCATTERED.  Arbitrary evaluation points (SurfaceGenerator.fit_nurbs evaluates at deflectometry points,
+//    artist/field/surface_generator.py:133-202): one thread owns one evaluation point, gathers its (p+1)(q+1) control points
+//    from LDS; backward privatises the facet's gradient net in LDS in DOUBLE (ds_add_f64 retires a wave instruction in ~25
+//    cycles, ds_add_f32 needs ~193: tools/lds_atomic_bench.hip) - the order of those adds is not fixed, the result is the same
+//    to fp32 output precision but not bit-reproducible.
+//
+// MFMA: not used.  gfx950's f32-input MFMA (v_mfma_f32_16x16x4_f32) issues at 64 FLOP/clk/SIMD - exactly the v_fma_f32 rate
+// (MI355X_MICROARCH.md: 157.3 TFLOP/s both) - the basis matrices are banded (p+1 = 4 of nv = 10 columns non-zero), so a dense
+// contraction does 2.5x the multiply-adds, and its fused accumulation breaks the bit-parity of the points.  Measured:
+// tools/nurbs_mfma_bench.hip, profiles/r04_nurbs_bench.json, DESIGN.md 4.3.
 //
 // Replaces (ARTIST v2.0.0): artist/nurbs/surfaces.py:157-245 (find_spans), :247-417
 // (basis_functions_and_derivatives, NURBS Book A2.3), :419-473 + :578-613 (gather + A3.6),
@@ -19,6 +35,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "launch_common.hpp"
 #include "ray_math.hpp"      // div_noscale: n / a bit for bit, without the range scaling of the IEEE sequence
 
@@ -26,6 +44,7 @@ namespace art {
 
 constexpr int kMaxDeg = 7;
 constexpr int kNurbsBlock = 256;
+constexpr int kBwdStripPoints = 2;      // tensor-product backward: points per thread and strip of grid rows
 
 struct NurbsArgs {
     const float* cp;        // [H,F,nu,nv,3]
@@ -40,8 +59,9 @@ struct NurbsArgs {
     int p, q, uniform;
     int n_unique_u, n_unique_v;
     int H, F, M, nu, nv;
-    int n_mtiles;
-    int tiles_per_wg;       // forward: tiles of 256 points one workgroup evaluates
+    int groups;             // forward: workgroups per facet (each takes a run of grid rows / of points)
+    int grid_mode;          // 1: look for a cartesian grid (tensor-product scheme), 0: scattered scheme only
+    int lds_floats;         // dynamic LDS of the launch, in floats
 };
 
 // surfaces.py:198-207 (uniform) / :209-243 (search).
@@ -202,31 +222,20 @@ __device__ __forceinline__ void stage_facet(const NurbsArgs& a, int hf, float* l
     __syncthreads();
 }
 
-template <int DEG>
-__global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, float4* __restrict__ points,
-                                                                float4* __restrict__ normals)
+// ---- shared per-point pieces ---------------------------------------------------------------------------------------
+
+// surfaces.py:615-689 for one evaluation point: cross product, homogeneous divide, normalisation, canting rotation + facet
+// translation (transforms.py:334-347), and - when fused - the alignment (heliostat_group_rigid_body.py:217-222).
+__device__ __forceinline__ void finish_point(const NurbsArgs& a, const float* S0, const float* Su, const float* Sv,
+                                             const float* s_B, int hf, int h, int m, float4* __restrict__ points,
+                                             float4* __restrict__ normals)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // a workgroup evaluates tiles_per_wg consecutive tiles of 256 points of one facet: staging the control net and building
-    // the canting basis (one thread, ~100 dependent instructions) cost more than evaluating one tile
-    const int groups = (a.n_mtiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-    const int hf = blockIdx.x / groups;
-    const int mt0 = (blockIdx.x % groups) * a.tiles_per_wg;
-    float *s_cp, *s_ku, *s_kv, *s_B;
-    stage_facet(a, hf, lds, s_cp, s_ku, s_kv, s_B);
-    const int h = hf / a.F, f = hf % a.F;
-  for (int mt = mt0; mt < min(mt0 + a.tiles_per_wg, a.n_mtiles); ++mt) {
-    const int m = mt * kNurbsBlock + threadIdx.x;
-    if (m >= a.M) return;
-    const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * m);
-    Eval<DEG> E;
-    evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
     // surfaces.py:615-632
-    const float cx = E.Su[1] * E.Sv[2] - E.Su[2] * E.Sv[1];
-    const float cy = E.Su[2] * E.Sv[0] - E.Su[0] * E.Sv[2];
-    const float cz = E.Su[0] * E.Sv[1] - E.Su[1] * E.Sv[0];
+    const float cx = Su[1] * Sv[2] - Su[2] * Sv[1];
+    const float cy = Su[2] * Sv[0] - Su[0] * Sv[2];
+    const float cz = Su[0] * Sv[1] - Su[1] * Sv[0];
     // :642-657
-    const float px = E.S0[0] / E.S0[3], py = E.S0[1] / E.S0[3], pz = E.S0[2] / E.S0[3];
+    const float px = S0[0] / S0[3], py = S0[1] / S0[3], pz = S0[2] / S0[3];
     // :659-661 (F.normalize, eps = 1e-12)
     const float nc = fmaxf(norm3(cx, cy, cz), 1e-12f);
     const float nx = cx / nc, ny = cy / nc, nz = cz / nc;
@@ -253,34 +262,238 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, flo
     }
     points[(int64_t)hf * a.M + m] = po;
     normals[(int64_t)hf * a.M + m] = no;
-  }
 }
 
-// One workgroup per (h,f); threads stride over the M evaluation points; gradient net in LDS.
+// The adjoint of finish_point for one evaluation point: dL/dS (position), dL/dSu, dL/dSv from the two incoming gradients.
+__device__ __forceinline__ void point_adjoint(const NurbsArgs& a, float w, const float* Su, const float* Sv, const float* s_B,
+                                              int hf, int h, int m, const float4* __restrict__ g_points,
+                                              const float4* __restrict__ g_normals, float* gS, float* gSu, float* gSv)
+{
+    float4 gp = g_points[(int64_t)hf * a.M + m];
+    float4 gn = g_normals[(int64_t)hf * a.M + m];
+    if (a.orientation) {      // align_bwd_kernel's arithmetic
+        const float* Mo = a.orientation + (int64_t)h * 16;
+        gp = apply_m(gp, Mo);
+        gn = apply_m(gn, Mo);
+    }
+    float gpt[3], gnr[3];
+    if (a.canting) {   // out_j = sum_k data_k B[k][j]  ->  g_data_k = sum_j g_out_j B[k][j]
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gpt[k] = gp.x * s_B[3 * k] + gp.y * s_B[3 * k + 1] + gp.z * s_B[3 * k + 2];
+            gnr[k] = gn.x * s_B[3 * k] + gn.y * s_B[3 * k + 1] + gn.z * s_B[3 * k + 2];
+        }
+    } else {
+        gpt[0] = gp.x; gpt[1] = gp.y; gpt[2] = gp.z; gnr[0] = gn.x; gnr[1] = gn.y; gnr[2] = gn.z;
+    }
+    const float cx = Su[1] * Sv[2] - Su[2] * Sv[1];
+    const float cy = Su[2] * Sv[0] - Su[0] * Sv[2];
+    const float cz = Su[0] * Sv[1] - Su[1] * Sv[0];
+    const float nc = norm3(cx, cy, cz);
+    float gc[3];
+    if (nc < 1e-12f) {
+        gc[0] = gnr[0] / 1e-12f; gc[1] = gnr[1] / 1e-12f; gc[2] = gnr[2] / 1e-12f;
+    } else {
+        const float inv = 1.0f / nc;
+        const float nx = cx * inv, ny = cy * inv, nz = cz * inv;
+        const float dot = nx * gnr[0] + ny * gnr[1] + nz * gnr[2];
+        gc[0] = (gnr[0] - nx * dot) * inv; gc[1] = (gnr[1] - ny * dot) * inv; gc[2] = (gnr[2] - nz * dot) * inv;
+    }
+    // c = Su x Sv : gSu = Sv x gc ; gSv = gc x Su
+    gSu[0] = Sv[1] * gc[2] - Sv[2] * gc[1]; gSu[1] = Sv[2] * gc[0] - Sv[0] * gc[2]; gSu[2] = Sv[0] * gc[1] - Sv[1] * gc[0];
+    gSv[0] = gc[1] * Su[2] - gc[2] * Su[1]; gSv[1] = gc[2] * Su[0] - gc[0] * Su[2]; gSv[2] = gc[0] * Su[1] - gc[1] * Su[0];
+    const float iw = 1.0f / w;
+    gS[0] = gpt[0] * iw; gS[1] = gpt[1] * iw; gS[2] = gpt[2] * iw;
+}
+
+// ---- tensor-product scheme: grid discovery, row / column bases, stage 1 ----------------------------------------------
+
+struct GridInfo { int Mu, Mv; bool ok; };
+
+// Is the facet's point list a cartesian grid, m = i Mv + j at (u_i, v_j)?  Mv = index of the first point whose u differs
+// from point 0's (M when there is none: one row); then EVERY point must carry its row's u and its column's v, bit for bit
+// (every workgroup of a facet checks all of them, so that all of them take the same scheme).  s_int: two LDS words.
+__device__ __forceinline__ GridInfo detect_grid(const NurbsArgs& a, const float* __restrict__ uvp, int* s_int)
+{
+    if (threadIdx.x == 0) { s_int[0] = a.M; s_int[1] = 0; }
+    __syncthreads();
+    const float u0 = uvp[0];
+    for (int m = threadIdx.x; m < a.M; m += blockDim.x)
+        if (uvp[2 * (int64_t)m] != u0) { atomicMin(&s_int[0], m); break; }
+    __syncthreads();
+    GridInfo g;
+    g.Mv = s_int[0];
+    if (g.Mv <= 0) { g.Mu = 0; g.ok = false; return g; }      // (a NaN at point 0 differs from itself)
+    g.Mu = a.M / g.Mv;
+    g.ok = g.Mu * g.Mv == a.M;
+    if (!g.ok) return g;
+    bool bad = false;
+    for (int m = threadIdx.x; m < a.M; m += blockDim.x) {
+        const int i = m / g.Mv, j = m - i * g.Mv;
+        const float2 x = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
+        bad |= !(x.x == uvp[2 * (int64_t)i * g.Mv]) || !(x.y == uvp[2 * (int64_t)j + 1]);
+    }
+    if (bad) s_int[1] = 1;
+    __syncthreads();
+    g.ok = s_int[1] == 0;
+    return g;
+}
+
+// Row / column basis records in LDS: kBasisWords<DEG> words per grid line - [span (int bits), N[0..S-1], D[0..S-1], sum_r N[r] * 1]
+template <int DEG> struct BasisRec { static constexpr int S = (DEG > 0 ? DEG : kMaxDeg) + 1; static constexpr int words = 2 * S + 2; };
+
 template <int DEG>
-__global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, const float4* __restrict__ g_points,
-                                                                const float4* __restrict__ g_normals,
-                                                                float* __restrict__ g_cp)
+__device__ __forceinline__ void line_basis(const NurbsArgs& a, float x, const float* knots, int n, int deg, int n_unique, float* rec)
+{
+    constexpr int S = BasisRec<DEG>::S;
+    float N[S], D[S];
+    const int span = find_span(x, knots, n, deg, a.uniform, n_unique);
+    basis<DEG>(x, knots, span, deg, N, D);
+    rec[0] = __int_as_float(span);
+    float w = 0.f;
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+        if (r > deg) break;
+        rec[1 + r] = N[r]; rec[1 + S + r] = D[r];
+        w += N[r] * 1.0f;          // the homogeneous coordinate's inner sum (weights are all ones, surfaces.py:524-537)
+    }
+    rec[1 + 2 * S] = w;
+}
+
+// stage 1 for grid rows [r0, r0 + rs): temp[il][c][0..2] = sum_r Nu[r] CP[su-p+r][c], temp[il][c][3..5] the same with Du
+// (surfaces.py:592-603: loop order r from a zero accumulator)
+template <int DEG>
+__device__ __forceinline__ void stage1_rows(const NurbsArgs& a, const float* s_cp, const float* s_bu, int bu_row0, int r0, int rs,
+                                            float* s_temp)
+{
+    constexpr int S = BasisRec<DEG>::S, W = BasisRec<DEG>::words;
+    const int p = DEG > 0 ? DEG : a.p;
+    for (int idx = threadIdx.x; idx < rs * a.nv; idx += blockDim.x) {
+        const int il = idx / a.nv, c = idx - il * a.nv;
+        const float* rec = s_bu + (r0 + il - bu_row0) * W;
+        const int su = __float_as_int(rec[0]);
+        float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            if (r > p) break;
+            const float* c3 = s_cp + ((su - p + r) * a.nv + c) * 3;
+            const float bn = rec[1 + r], bd = rec[1 + S + r];
+            t[0] += bn * c3[0]; t[1] += bn * c3[1]; t[2] += bn * c3[2];
+            t[3] += bd * c3[0]; t[4] += bd * c3[1]; t[5] += bd * c3[2];
+        }
+        float* o = s_temp + (il * a.nv + c) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = t[k];
+    }
+}
+
+// stage 2 for one point: S0 (with w), Su, Sv from its row's temps and its column's basis record (surfaces.py:604-613)
+template <int DEG>
+__device__ __forceinline__ void stage2_point(const NurbsArgs& a, const float* trow, const float* recv, float wrow, float* S0,
+                                             float* Su, float* Sv)
+{
+    constexpr int S = BasisRec<DEG>::S;
+    const int q = DEG > 0 ? DEG : a.q;
+    const int sv = __float_as_int(recv[0]);
+    float d0[4] = {0.f, 0.f, 0.f, 0.f}, du[3] = {0.f, 0.f, 0.f}, dv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s > q) break;
+        const float* t = trow + (sv - q + s) * 6;
+        const float bn = recv[1 + s], bd = recv[1 + S + s];
+        d0[0] += bn * t[0]; d0[1] += bn * t[1]; d0[2] += bn * t[2]; d0[3] += bn * wrow;
+        du[0] += bn * t[3]; du[1] += bn * t[4]; du[2] += bn * t[5];
+        dv[0] += bd * t[0]; dv[1] += bd * t[1]; dv[2] += bd * t[2];
+    }
+    S0[0] = d0[0]; S0[1] = d0[1]; S0[2] = d0[2]; S0[3] = d0[3];
+    Su[0] = du[0]; Su[1] = du[1]; Su[2] = du[2];
+    Sv[0] = dv[0]; Sv[1] = dv[1]; Sv[2] = dv[2];
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------------
+
+// grid = H * F * groups.  Workgroup `group` of a facet takes grid rows [group * ceil(Mu / groups), ...) in the tensor-product
+// scheme, points [group * ceil(M / groups), ...) in the scattered one.
+template <int DEG>
+__global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, float4* __restrict__ points,
+                                                                float4* __restrict__ normals)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int S = Eval<DEG>::S;
-    const int hf = blockIdx.x;
+    constexpr int W = BasisRec<DEG>::words;
+    const int hf = blockIdx.x / a.groups, group = blockIdx.x % a.groups;
     float *s_cp, *s_ku, *s_kv, *s_B;
     stage_facet(a, hf, lds, s_cp, s_ku, s_kv, s_B);
+    const int h = hf / a.F, f = hf % a.F;
+    const float* uvp = a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf;
+    const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
+    const int n0 = nurbs_f64_offset(a);
+    int* s_int = reinterpret_cast<int*>(lds + n0);
+    GridInfo g = {0, 0, false};
+    if (a.grid_mode) g = detect_grid(a, uvp, s_int);
+    if (g.ok) {
+        const int rpg = (g.Mu + a.groups - 1) / a.groups;
+        const int i0 = group * rpg, i1 = min(g.Mu, i0 + rpg);
+        // LDS behind the facet tables: [2 ints][row bases rpg][column bases Mv][temps rows_pass x nv x 6]
+        // (sized by rpg, not by this group's row count: all groups of a facet decide alike whether the scheme fits)
+        float* s_bu = lds + n0 + 2;
+        float* s_bv = s_bu + rpg * W;
+        float* s_temp = s_bv + g.Mv * W;
+        const int room = a.lds_floats - (int)(s_temp - lds);
+        const int rows_pass = room > 0 ? min(rpg, room / (a.nv * 6)) : 0;
+        if (rows_pass >= 1) {
+            if (i0 >= i1) return;
+            for (int t = threadIdx.x; t < (i1 - i0) + g.Mv; t += blockDim.x) {
+                if (t < i1 - i0) line_basis<DEG>(a, uvp[2 * (int64_t)(i0 + t) * g.Mv], s_ku, a.nu, p, a.n_unique_u, s_bu + t * W);
+                else line_basis<DEG>(a, uvp[2 * (int64_t)(t - (i1 - i0)) + 1], s_kv, a.nv, q, a.n_unique_v, s_bv + (t - (i1 - i0)) * W);
+            }
+            __syncthreads();
+            for (int r0 = i0; r0 < i1; r0 += rows_pass) {
+                const int rs = min(rows_pass, i1 - r0);
+                stage1_rows<DEG>(a, s_cp, s_bu, i0, r0, rs, s_temp);
+                __syncthreads();
+                for (int idx = threadIdx.x; idx < rs * g.Mv; idx += blockDim.x) {
+                    const int il = idx / g.Mv, j = idx - il * g.Mv;
+                    float S0[4], Su[3], Sv[3];
+                    stage2_point<DEG>(a, s_temp + il * a.nv * 6, s_bv + j * W, s_bu[(r0 + il - i0) * W + W - 1], S0, Su, Sv);
+                    finish_point(a, S0, Su, Sv, s_B, hf, h, (r0 + il) * g.Mv + j, points, normals);
+                }
+                if (r0 + rows_pass < i1) __syncthreads();
+            }
+            return;
+        }
+    }
+    // scattered scheme
+    const int per = (a.M + a.groups - 1) / a.groups;
+    const int m1 = min(a.M, (group + 1) * per);
+    for (int m = group * per + threadIdx.x; m < m1; m += blockDim.x) {
+        const float2 xy = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
+        Eval<DEG> E;
+        evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
+        finish_point(a, E.S0, E.Su, E.Sv, s_B, hf, h, m, points, normals);
+    }
+}
+
+// ---- backward ------------------------------------------------------------------------------------------------------------
+
+// Scattered scheme: threads stride over runs of points; gradient net in LDS (double, LDS atomics).
+template <int DEG>
+__device__ __forceinline__ void nurbs_bwd_scattered(const NurbsArgs& a, int hf, float* lds, const float* s_cp, const float* s_ku,
+                                                    const float* s_kv, const float* s_B, const float4* __restrict__ g_points,
+                                                    const float4* __restrict__ g_normals, float* __restrict__ g_cp)
+{
+    constexpr int S = Eval<DEG>::S;
     const int ncp = a.nu * a.nv * 3;
     double* s_g = reinterpret_cast<double*>(lds + nurbs_f64_offset(a));   // 8-byte aligned tail of the LDS block
+    __syncthreads();                                                       // (the grid discovery may still be reading its two words)
     for (int i = threadIdx.x; i < ncp; i += blockDim.x) s_g[i] = 0.0;
     __syncthreads();
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int h = hf / a.F, f = hf % a.F;
     // A thread owns a RUN of consecutive evaluation points and keeps the (p+1)(q+1) x 3 sums of the control points of the
     // current knot-span cell in registers; they go to the LDS accumulator - one ds_add_f64 each, the pipe that bounds this
-    // kernel - only when the run leaves the cell and at its end.  On a row-major evaluation grid (50 x 50 points over 7 x 7
-    // cells) a run of ten points meets ~2.4 cells: 4 x fewer LDS atomics than one set per point (0.47 -> see DESIGN.md 4.3);
-    // scattered evaluation points flush after every point, as before.  Neighbouring runs share their control points, so lanes
+    // scheme - only when the run leaves the cell and at its end.  Neighbouring runs share their control points, so lanes
     // that took neighbouring runs would all add to the same LDS cells (up to 64-way serialisation): lane t takes run
-    // (t K) mod n_runs, K prime and coprime to n_runs (a bijection), which puts the lanes of a wave in different cells; the
-    // gradient loads become gathers of 32 B per point and are L2-resident.
+    // (t K) mod n_runs, K prime and coprime to n_runs (a bijection), which puts the lanes of a wave in different cells.
     const int run_len = (a.M + (int)blockDim.x - 1) / (int)blockDim.x;
     const int n_runs = (a.M + run_len - 1) / run_len;
     int K = 1;
@@ -309,46 +522,11 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
     if ((int)threadIdx.x < n_runs) {
       const int run = (int)(((int64_t)threadIdx.x * K) % n_runs);
       for (int m = run * run_len; m < min(a.M, (run + 1) * run_len); ++m) {
-        const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * m);
+        const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * (int64_t)m);
         Eval<DEG> E;
         evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
-        float4 gp = g_points[(int64_t)hf * a.M + m];
-        float4 gn = g_normals[(int64_t)hf * a.M + m];
-        if (a.orientation) {      // align_bwd_kernel's arithmetic
-            const float* Mo = a.orientation + (int64_t)h * 16;
-            gp = apply_m(gp, Mo);
-            gn = apply_m(gn, Mo);
-        }
-        float gpt[3], gnr[3];
-        if (a.canting) {   // out_j = sum_k data_k B[k][j]  ->  g_data_k = sum_j g_out_j B[k][j]
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                gpt[k] = gp.x * s_B[3 * k] + gp.y * s_B[3 * k + 1] + gp.z * s_B[3 * k + 2];
-                gnr[k] = gn.x * s_B[3 * k] + gn.y * s_B[3 * k + 1] + gn.z * s_B[3 * k + 2];
-            }
-        } else {
-            gpt[0] = gp.x; gpt[1] = gp.y; gpt[2] = gp.z; gnr[0] = gn.x; gnr[1] = gn.y; gnr[2] = gn.z;
-        }
-        const float cx = E.Su[1] * E.Sv[2] - E.Su[2] * E.Sv[1];
-        const float cy = E.Su[2] * E.Sv[0] - E.Su[0] * E.Sv[2];
-        const float cz = E.Su[0] * E.Sv[1] - E.Su[1] * E.Sv[0];
-        const float nc = norm3(cx, cy, cz);
-        float gc[3];
-        if (nc < 1e-12f) {
-            gc[0] = gnr[0] / 1e-12f; gc[1] = gnr[1] / 1e-12f; gc[2] = gnr[2] / 1e-12f;
-        } else {
-            const float inv = 1.0f / nc;
-            const float nx = cx * inv, ny = cy * inv, nz = cz * inv;
-            const float dot = nx * gnr[0] + ny * gnr[1] + nz * gnr[2];
-            gc[0] = (gnr[0] - nx * dot) * inv; gc[1] = (gnr[1] - ny * dot) * inv; gc[2] = (gnr[2] - nz * dot) * inv;
-        }
-        // c = Su x Sv : gSu = Sv x gc ; gSv = gc x Su
-        const float gSu[3] = {E.Sv[1] * gc[2] - E.Sv[2] * gc[1], E.Sv[2] * gc[0] - E.Sv[0] * gc[2],
-                              E.Sv[0] * gc[1] - E.Sv[1] * gc[0]};
-        const float gSv[3] = {gc[1] * E.Su[2] - gc[2] * E.Su[1], gc[2] * E.Su[0] - gc[0] * E.Su[2],
-                              gc[0] * E.Su[1] - gc[1] * E.Su[0]};
-        const float iw = 1.0f / E.S0[3];
-        const float gS[3] = {gpt[0] * iw, gpt[1] * iw, gpt[2] * iw};
+        float gS[3], gSu[3], gSv[3];
+        point_adjoint(a, E.S0[3], E.Su, E.Sv, s_B, hf, h, m, g_points, g_normals, gS, gSu, gSv);
         const bool same = E.su == cur_u && E.sv == cur_v;
         if (!same) { flush(); cur_u = E.su; cur_v = E.sv; }
 #pragma unroll
@@ -373,6 +551,119 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
     for (int i = threadIdx.x; i < ncp; i += blockDim.x) out[i] = (float)s_g[i];
 }
 
+// One workgroup per (h,f).  Tensor-product scheme = the adjoint of the forward's two stages, strip of rows by strip:
+//   points   (thread <-> point)    recompute Su, Sv, w from the strip's temps; (gS, gSu, gSv) -> LDS [point][9]
+//   stage A  (thread <-> (row, column c, component))   gT[i][c][0..2] = sum_j Nv_j[c - sv_j + q] gS[i][j] + Dv_j[..] gSv[i][j],
+//            gT[i][c][3..5] = sum_j Nv_j[..] gSu[i][j]      j in index order over the columns whose span covers c
+//   stage B  (thread <-> control-point component, once, after the last strip)
+//            gCP[a][c] = sum_i Nu_i[a - su_i + p] gT[i][c][0..2] + Du_i[..] gT[i][c][3..5]      i in index order
+// Every output element has ONE owner that adds in a fixed order: no atomics, bit-reproducible gradients.
+template <int DEG>
+__global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, const float4* __restrict__ g_points,
+                                                                const float4* __restrict__ g_normals,
+                                                                float* __restrict__ g_cp)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int S = BasisRec<DEG>::S, W = BasisRec<DEG>::words;
+    const int hf = blockIdx.x;
+    float *s_cp, *s_ku, *s_kv, *s_B;
+    stage_facet(a, hf, lds, s_cp, s_ku, s_kv, s_B);
+    const int h = hf / a.F, f = hf % a.F;
+    const float* uvp = a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf;
+    const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
+    const int n0 = nurbs_f64_offset(a);
+    const int ncp = a.nu * a.nv * 3;
+    int* s_int = reinterpret_cast<int*>(lds + n0);
+    GridInfo g = {0, 0, false};
+    if (a.grid_mode) g = detect_grid(a, uvp, s_int);
+    if (g.ok) {
+        // LDS behind the facet tables: [2 ints][jlo, jhi per column c: 2 nv ints][ilo, ihi per row a: 2 nu ints]
+        //   [row bases Mu][column bases Mv][gT Mu x nv x 6][temps rs x nv x 6][point gradients rs x Mv x 9]
+        int* s_jr = s_int + 2;
+        int* s_ir = s_jr + 2 * a.nv;
+        float* s_bu = reinterpret_cast<float*>(s_ir + 2 * a.nu);
+        float* s_bv = s_bu + g.Mu * W;
+        float* s_gt = s_bv + g.Mv * W;
+        float* s_temp = s_gt + g.Mu * a.nv * 6;
+        const int room = a.lds_floats - (int)(s_temp - lds);
+        const int per_row = a.nv * 6 + g.Mv * 9;
+        int rs_max = room > 0 ? room / per_row : 0;
+        rs_max = min(rs_max, max(1, (kBwdStripPoints * (int)blockDim.x) / g.Mv));      // points per thread and strip
+        rs_max = min(rs_max, g.Mu);
+        if (rs_max >= 1) {
+            for (int t = threadIdx.x; t < 2 * a.nv + 2 * a.nu; t += blockDim.x) s_jr[t] = (t & 1) ? -1 : 0x7fffffff;
+            for (int t = threadIdx.x; t < g.Mu + g.Mv; t += blockDim.x) {
+                if (t < g.Mu) line_basis<DEG>(a, uvp[2 * (int64_t)t * g.Mv], s_ku, a.nu, p, a.n_unique_u, s_bu + t * W);
+                else line_basis<DEG>(a, uvp[2 * (int64_t)(t - g.Mu) + 1], s_kv, a.nv, q, a.n_unique_v, s_bv + (t - g.Mu) * W);
+            }
+            __syncthreads();
+            // which grid columns / rows touch control column c / control row a (any order of the grid lines is fine: the range
+            // only bounds the loops, the band test inside them decides)
+            for (int t = threadIdx.x; t < g.Mu + g.Mv; t += blockDim.x) {
+                const bool is_u = t < g.Mu;
+                const int line = is_u ? t : t - g.Mu;
+                const int span = __float_as_int((is_u ? s_bu : s_bv)[line * W]);
+                const int deg = is_u ? p : q;
+                int* rng = is_u ? s_ir : s_jr;
+                for (int r = 0; r <= deg; ++r) {
+                    atomicMin(&rng[2 * (span - deg + r)], line);
+                    atomicMax(&rng[2 * (span - deg + r) + 1], line);
+                }
+            }
+            float* s_pg = s_temp + rs_max * a.nv * 6;
+            for (int r0 = 0; r0 < g.Mu; r0 += rs_max) {
+                const int rs = min(rs_max, g.Mu - r0);
+                stage1_rows<DEG>(a, s_cp, s_bu, 0, r0, rs, s_temp);
+                __syncthreads();             // (also: the previous strip's stage A has read s_pg)
+                for (int idx = threadIdx.x; idx < rs * g.Mv; idx += blockDim.x) {
+                    const int il = idx / g.Mv, j = idx - il * g.Mv;
+                    float S0[4], Su[3], Sv[3], gS[3], gSu[3], gSv[3];
+                    stage2_point<DEG>(a, s_temp + il * a.nv * 6, s_bv + j * W, s_bu[(r0 + il) * W + W - 1], S0, Su, Sv);
+                    point_adjoint(a, S0[3], Su, Sv, s_B, hf, h, (r0 + il) * g.Mv + j, g_points, g_normals, gS, gSu, gSv);
+                    float* o = s_pg + idx * 9;
+                    o[0] = gS[0]; o[1] = gS[1]; o[2] = gS[2]; o[3] = gSu[0]; o[4] = gSu[1]; o[5] = gSu[2];
+                    o[6] = gSv[0]; o[7] = gSv[1]; o[8] = gSv[2];
+                }
+                __syncthreads();
+                for (int o = threadIdx.x; o < rs * a.nv * 3; o += blockDim.x) {
+                    const int il = o / (a.nv * 3), rem = o - il * (a.nv * 3);
+                    const int c = rem / 3, k = rem - c * 3;
+                    const int jlo = s_jr[2 * c], jhi = s_jr[2 * c + 1];
+                    float acc_n = 0.f, acc_d = 0.f;
+                    for (int j = jlo; j <= jhi; ++j) {
+                        const float* rec = s_bv + j * W;
+                        const int s = c - (__float_as_int(rec[0]) - q);
+                        if ((unsigned)s > (unsigned)q) continue;
+                        const float* pg = s_pg + (il * g.Mv + j) * 9;
+                        acc_n = fmaf(rec[1 + S + s], pg[6 + k], fmaf(rec[1 + s], pg[k], acc_n));
+                        acc_d = fmaf(rec[1 + s], pg[3 + k], acc_d);
+                    }
+                    float* gt = s_gt + ((r0 + il) * a.nv + c) * 6;
+                    gt[k] = acc_n; gt[3 + k] = acc_d;
+                }
+            }
+            __syncthreads();
+            float* out = g_cp + (int64_t)hf * ncp;
+            for (int o = threadIdx.x; o < ncp; o += blockDim.x) {
+                const int ar = o / (a.nv * 3), rem = o - ar * (a.nv * 3);
+                const int c = rem / 3, k = rem - c * 3;
+                const int ilo = s_ir[2 * ar], ihi = s_ir[2 * ar + 1];
+                float acc = 0.f;
+                for (int i = ilo; i <= ihi; ++i) {
+                    const float* rec = s_bu + i * W;
+                    const int r = ar - (__float_as_int(rec[0]) - p);
+                    if ((unsigned)r > (unsigned)p) continue;
+                    const float* gt = s_gt + (i * a.nv + c) * 6;
+                    acc = fmaf(rec[1 + S + r], gt[3 + k], fmaf(rec[1 + r], gt[k], acc));
+                }
+                out[o] = acc;
+            }
+            return;
+        }
+    }
+    nurbs_bwd_scattered<DEG>(a, hf, lds, s_cp, s_ku, s_kv, s_B, g_points, g_normals, g_cp);
+}
+
 static bool fill_nurbs(NurbsArgs& a, const float* cp, const float* uv, int64_t uv_sh, int64_t uv_sf,
                        const float* ku, const float* kv, const float* canting, const float* transl, int p, int q,
                        int uniform, int64_t nuq_u, int64_t nuq_v, int64_t H, int64_t F, int64_t M, int64_t nu,
@@ -381,22 +672,38 @@ static bool fill_nurbs(NurbsArgs& a, const float* cp, const float* uv, int64_t u
     if (!cp || !uv || !ku || !kv) return false;
     if (canting && !transl) return false;
     if (p < 1 || q < 1 || p > kMaxDeg || q > kMaxDeg || nu <= p || nv <= q) return false;
-    if (H < 0 || F <= 0 || M <= 0 || nu > 4096 || nv > 4096 || H * F > 2147483647LL || M > 2147483647LL) return false;
+    if (H < 0 || F <= 0 || M <= 0 || nu > 4096 || nv > 4096 || H * F > 2147483647LL || M > 1073741823LL) return false;
     if (uniform && (nuq_u < 2 || nuq_v < 2)) return false;
     a.cp = cp; a.uv = uv; a.uv_sh = uv_sh; a.uv_sf = uv_sf; a.knots_u = ku; a.knots_v = kv;
     a.canting = canting; a.transl = transl; a.orientation = nullptr; a.p = p; a.q = q; a.uniform = uniform;
     a.n_unique_u = (int)nuq_u; a.n_unique_v = (int)nuq_v;
     a.H = (int)H; a.F = (int)F; a.M = (int)M; a.nu = (int)nu; a.nv = (int)nv;
-    a.n_mtiles = (int)((M + kNurbsBlock - 1) / kNurbsBlock);
-    a.tiles_per_wg = 1;
+    a.groups = 1;
+    a.grid_mode = debug_env_int("ARTIST_HIP_NURBS_GRID", 1) != 0 ? 1 : 0;
+    a.lds_floats = 0;
     return true;
 }
 
-static size_t nurbs_lds_bytes(const NurbsArgs& a, bool bwd)
+// Dynamic LDS of a launch in bytes: what the scattered scheme needs, or - when the grid scheme is on - room for a roughly
+// square grid of M points (row / column bases, the stage-1 temps of all rows, and in the backward the gradient temps plus a
+// strip of point gradients); a grid that does not fit (long and thin) is evaluated by the scattered scheme.
+static size_t nurbs_lds_bytes(const NurbsArgs& a, bool bwd, int groups)
 {
     const size_t ncp = (size_t)a.nu * a.nv * 3;
-    size_t n = ncp + (a.nu + a.p + 1) + (a.nv + a.q + 1) + 12;
-    if (bwd) n = (size_t)nurbs_f64_offset(a) + 2 * ncp;
+    const size_t n0 = (size_t)nurbs_f64_offset(a);
+    size_t scattered = bwd ? n0 + 2 * ncp : n0;
+    size_t n = scattered;
+    if (a.grid_mode) {
+        const int deg = (a.p == a.q && a.p <= 4) ? a.p : 0;
+        const size_t W = 2 * (size_t)((deg > 0 ? deg : kMaxDeg) + 1) + 2;
+        size_t side = 1;
+        while (side * side < (size_t)a.M) ++side;
+        const size_t rows = bwd ? side : (side + groups - 1) / groups;
+        size_t grid = n0 + 2 + (rows + side) * W + rows * a.nv * 6;
+        if (bwd) grid += 2 * (size_t)(a.nu + a.nv) + std::min<size_t>(side, std::max<size_t>(1, kBwdStripPoints * kNurbsBlock / side)) * (a.nv * 6 + side * 9);
+        grid += 64;
+        if (grid * sizeof(float) <= 64 * 1024) n = std::max(n, grid);
+    }
     return n * sizeof(float);
 }
 
@@ -430,21 +737,20 @@ extern "C" int art_nurbs_fwd(const float* control_points, const float* eval_poin
                     uniform, n_unique_u, n_unique_v, H, F, M, nu, nv))
         return ART_EINVAL;
     a.orientation = orientation;
-    if (H == 0) return ART_OK;
-    const size_t lds = nurbs_lds_bytes(a, false);
-    if (lds > 64 * 1024) return ART_EUNSUPPORTED;
-    // enough workgroups to fill the chip a few times over, as few stagings as that allows
+    // workgroups per facet: as few as still give ~1000 workgroups (every workgroup stages the control net and builds the
+    // canting basis - one thread, ~100 dependent instructions), at least ~256 points each
     {
-        static const int env_tiles = getenv("ARTIST_HIP_NURBS_TILES") ? atoi(getenv("ARTIST_HIP_NURBS_TILES")) : 0;
-        int t = env_tiles;
-        if (t <= 0) {      // as few workgroups per facet as still give ~1000 workgroups, tiles dealt evenly
-            int groups = 1;
-            while (groups < a.n_mtiles && (int64_t)H * F * groups < 1024) ++groups;
-            t = (a.n_mtiles + groups - 1) / groups;
+        int groups = debug_env_int("ARTIST_HIP_NURBS_GROUPS", 0);
+        if (groups <= 0) {
+            groups = 1;
+            while ((int64_t)H * F * groups < 1024 && M / (groups + 1) >= kNurbsBlock) ++groups;
         }
-        a.tiles_per_wg = t;      // (1000 heliostats x 4 facets x 2500 points: 1 / 2 / 5 / 10 tiles = 0.257 / 0.235 / 0.225 / 0.220 ms)
+        a.groups = (int)std::min<int64_t>(groups, M);
     }
-    const int64_t blocks = (int64_t)H * F * ((a.n_mtiles + a.tiles_per_wg - 1) / a.tiles_per_wg);
+    const size_t lds = nurbs_lds_bytes(a, false, a.groups);
+    if (lds > 64 * 1024) return ART_EUNSUPPORTED;
+    a.lds_floats = (int)(lds / sizeof(float));
+    const int64_t blocks = (int64_t)H * F * a.groups;
     if (blocks > 2147483647LL) return ART_EINVAL;
     ART_DISPATCH_DEG(nurbs_fwd_kernel, dim3((unsigned)blocks), lds, stream, a, reinterpret_cast<float4*>(points),
                      reinterpret_cast<float4*>(normals));
@@ -468,9 +774,9 @@ extern "C" int art_nurbs_bwd(const float* control_points, const float* eval_poin
         return ART_EINVAL;
     a.transl = nullptr;   // unused by the backward
     a.orientation = orientation;
-    if (H == 0) return ART_OK;
-    const size_t lds = nurbs_lds_bytes(a, true);
+    const size_t lds = nurbs_lds_bytes(a, true, 1);
     if (lds > 64 * 1024) return ART_EUNSUPPORTED;
+    a.lds_floats = (int)(lds / sizeof(float));
     ART_DISPATCH_DEG(nurbs_bwd_kernel, dim3((unsigned)(H * F)), lds, stream, a,
                      reinterpret_cast<const float4*>(grad_points), reinterpret_cast<const float4*>(grad_normals),
                      grad_control_points);

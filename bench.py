@@ -281,10 +281,10 @@ def main():
         return per_target
 
     # the reconstructor's optimiser (surface_reconstructor.py:452-455); a small rate keeps the workload stationary
-    try:
-        optimizer = torch.optim.Adam([cp], lr=1e-6, fused=True)
-    except (RuntimeError, TypeError):
-        optimizer = torch.optim.Adam([cp], lr=1e-6)
+    # (artist_amd.optim.Adam: torch.optim.Adam's update rule as one HIP kernel - torch's fused multi-tensor launch costs 41-48 us
+    #  at any size, tests/test_gpu_optim.py compares the two)
+    from artist_amd.optim import Adam
+    optimizer = Adam([cp], lr=1e-6)
     crop_dims = planar.dimensions.index_select(0, tix.long()).contiguous()
     with torch.no_grad():
         f0, _ = forward()

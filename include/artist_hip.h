@@ -253,6 +253,20 @@ int art_nurbs_bwd(const float *control_points, const float *eval_points, int64_t
 int art_reflect(const float *incident, const float *normals, int64_t H, int64_t P, float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * art_adam_step - the optimiser step of the reconstruction epochs: torch.optim.Adam's update rule
+ * (torch/optim/adam.py, _single_tensor_adam; no amsgrad) on ONE contiguous fp32 tensor of n elements, as the reference
+ * steps the control points (artist/optim/surface_reconstructor.py:452-455 creates the optimiser, :779 steps it) and the
+ * kinematics deviations (artist/optim/kinematics_reconstructor.py).  `step` = number of this step (1 for the first): the
+ * bias corrections are computed on the host from it, in double.  param, exp_avg, exp_avg_sq are updated in place.
+ *   lock_nu, lock_nv > 0: the tensor is a batch of [nu,nv,3] control nets and the gradient of every net's outer edge counts
+ *   as zero - SurfaceReconstructor.lock_control_points_on_outer_edges (surface_reconstructor.py:749-788) without a pass
+ *   over the gradient; 0, 0: plain Adam.
+ * ------------------------------------------------------------------------------------------- */
+int art_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int64_t step, int maximize, int64_t lock_nu, int64_t lock_nv,
+                  void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * art_align_fwd - the alignment apply of HeliostatGroupRigidBody.align_surfaces_with_incident_ray_directions /
  * align_surfaces_with_motor_positions (artist/field/heliostat_group_rigid_body.py:217-222, 265-270):
  *   out_points = points @ orientation^T, out_normals = normals @ orientation^T, one pass over both.

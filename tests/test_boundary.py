@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
         "art_per_target_sum", "art_nurbs_fwd", "art_nurbs_bwd", "art_align_fwd", "art_align_bwd", "art_reflect",
         "art_blocking_filter", "art_blocking_workspace_bytes", "art_flux_crop_fwd", "art_flux_crop_bwd",
         "art_flux_loss", "art_rigid_body_fwd", "art_rigid_body_bwd", "art_async_status", "art_trace_bwd_scratch_floats",
-        "art_trace_bwd_scratch_need",
+        "art_trace_bwd_scratch_need", "art_adam_step",
         "art_flux_crop_pixel_loss_fwd", "art_flux_crop_pixel_loss_bwd", "art_flux_crop_kl_loss_fwd",
         "art_flux_crop_kl_loss_bwd", "art_flux_center_of_mass", "art_flux_center_of_mass_bwd"])
 

@@ -615,6 +615,112 @@ def test_nurbs_nonuniform_knots_and_many_points():
     assert rel_l2(n(surf.control_points.grad), o_g) < 1e-4
 
 
+def _grid_points(us, vs):
+    """cartesian_prod(us, vs) as ARTIST builds its evaluation grid (artist/nurbs/utils.py:37-49): point m = i Mv + j at (u_i, v_j)."""
+    return torch.cartesian_prod(us, vs)
+
+
+@pytest.mark.parametrize("deg,ncp,mu,mv,uniform,canted", [
+    ([3, 3], (10, 10), 50, 50, True, True),        # the metric config's facet
+    ([3, 3], (6, 6), 7, 13, True, True),           # rectangular grid, fewer points than threads
+    ([2, 2], (5, 8), 1, 40, True, False),          # one row
+    ([1, 1], (4, 4), 33, 1, True, True),           # one column (the row length is found to be 1)
+    ([3, 2], (7, 6), 21, 17, False, True),         # mixed degrees (run-time degree kernel), non-uniform knots
+    ([4, 4], (9, 8), 64, 30, True, False),         # more rows than one LDS pass holds in the forward's row groups
+    ([5, 2], (8, 5), 12, 11, True, True)])
+def test_nurbs_tensor_product_scheme_equals_the_scattered_scheme(monkeypatch, deg, ncp, mu, mv, uniform, canted):
+    """The tensor-product scheme (cartesian evaluation grid, found by the workgroup itself) against the scattered one on the
+    same inputs (ARTIST_HIP_NURBS_GRID=0 under ARTIST_HIP_DEBUG=1) and against the oracle: points and normals are the SAME
+    BITS (same sums in the same order), the control-point gradient agrees to fp32 rounding with the scattered scheme's (double
+    LDS sums) and the oracle's, and two backward passes of the tensor-product scheme give identical bits (every output element
+    has one owner that adds in index order)."""
+    from artist_amd import NURBSSurfaces
+    g = torch.Generator().manual_seed(mu * 100 + mv)
+    H, F = 3, 2
+    cp = torch.rand(H, F, ncp[0], ncp[1], 3, generator=g)
+    us = torch.sort(torch.rand(mu, generator=g) * 0.98 + 0.01).values
+    vs = torch.rand(mv, generator=g) * 0.98 + 0.01                     # columns in no particular order
+    if mu > 2:
+        us[0], us[-1] = 1e-7, 1.0 - 1e-7
+    uv = _grid_points(us, vs)[None, None].expand(H, F, -1, -1)
+    cant = tr = None
+    if canted:
+        cant = torch.tensor([[0.8, 0.05, 0.0, 0.0], [0.02, 0.6, 0.1, 0.0]])[None, None].expand(H, F, -1, -1).contiguous()
+        tr = torch.rand(H, F, 4, generator=g)
+        tr[..., 3] = 0.0
+    kw = {}
+    if not uniform:
+        ku = torch.cat([torch.zeros(deg[0]), torch.sort(torch.rand(ncp[0] - deg[0] + 1, generator=g)).values, torch.ones(deg[0])])
+        kv = torch.cat([torch.zeros(deg[1]), torch.sort(torch.rand(ncp[1] - deg[1] + 1, generator=g)).values, torch.ones(deg[1])])
+        ku[deg[0]], ku[-deg[0] - 1], kv[deg[1]], kv[-deg[1] - 1] = 0.0, 1.0, 0.0, 1.0
+        kw = dict(knots_u=ku.numpy(), knots_v=kv.numpy(), uniform=False)
+    gp = torch.rand(H, F, mu * mv, 4, generator=g)
+    gn = torch.rand(H, F, mu * mv, 4, generator=g)
+    dv = lambda x: None if x is None else x.to(DEV)
+
+    def run():
+        c = cp.to(DEV).requires_grad_(True)
+        surf = NURBSSurfaces(torch.tensor(deg), c, uniform=uniform, device=DEV)
+        if not uniform:
+            surf.knot_vectors_u = torch.from_numpy(kw["knots_u"]).to(DEV)[None, None].expand(H, F, -1)
+            surf.knot_vectors_v = torch.from_numpy(kw["knots_v"]).to(DEV)[None, None].expand(H, F, -1)
+        pts, nrm = surf(uv.to(DEV), dv(cant), dv(tr))
+        (g1,) = torch.autograd.grad([pts, nrm], [c], [gp.to(DEV), gn.to(DEV)], retain_graph=True)
+        (g2,) = torch.autograd.grad([pts, nrm], [c], [gp.to(DEV), gn.to(DEV)])
+        return n(pts), n(nrm), n(g1), n(g2)
+
+    monkeypatch.setenv("ARTIST_HIP_DEBUG", "1")
+    monkeypatch.setenv("ARTIST_HIP_NURBS_GRID", "1")
+    pts_t, nrm_t, g_t, g_t2 = run()
+    monkeypatch.setenv("ARTIST_HIP_NURBS_GRID", "0")
+    pts_s, nrm_s, g_s, _ = run()
+    np.testing.assert_array_equal(pts_t, pts_s)
+    np.testing.assert_array_equal(nrm_t, nrm_s)
+    np.testing.assert_array_equal(g_t, g_t2)                               # bit-reproducible
+    assert rel_l2(g_t, g_s) < 2e-6, rel_l2(g_t, g_s)
+    o_pts, o_nrm = oracle.nurbs_fwd(cp.numpy(), uv.contiguous().numpy(), deg, None if cant is None else cant.numpy(),
+                                    None if tr is None else tr.numpy(), **kw)
+    if deg[0] == deg[1] and deg[0] <= 4 and uniform:
+        np.testing.assert_array_equal(pts_t, o_pts)                        # the compile-time-degree kernels: the oracle's bits
+    else:
+        np.testing.assert_allclose(pts_t, o_pts, rtol=0, atol=1e-6)
+    o_g = oracle.nurbs_bwd(cp.numpy(), uv.contiguous().numpy(), deg, gp.numpy(), gn.numpy(), None if cant is None else cant.numpy(), **kw)
+    ok = np.linalg.norm(o_nrm[..., :3], axis=-1) > 0.5
+    if ok.all():
+        assert rel_l2(g_t, o_g) < 2e-5, rel_l2(g_t, o_g)
+
+
+def test_nurbs_points_that_are_almost_a_grid_take_the_scattered_scheme(monkeypatch):
+    """One point of a 20 x 30 grid moved by one ULP, a grid whose point count is not a multiple of its first row, a NaN at
+    point 0, and a different list per facet (one a grid, one not): the workgroup's own check sends each facet to the scheme
+    that fits it - the results equal the scattered scheme's bit for bit in every case."""
+    from artist_amd import NURBSSurfaces
+    g = torch.Generator().manual_seed(77)
+    H, F = 2, 2
+    cp = torch.rand(H, F, 6, 7, 3, generator=g).to(DEV)
+    base = _grid_points(torch.linspace(1e-7, 1 - 1e-7, 20), torch.linspace(1e-7, 1 - 1e-7, 30))
+    cases = {}
+    moved = base.clone()
+    moved[317, 1] = torch.nextafter(moved[317, 1], torch.tensor(2.0))
+    cases["one ulp"] = moved[None, None].expand(H, F, -1, -1)
+    cases["ragged"] = base[:-7][None, None].expand(H, F, -1, -1)
+    per_facet = base[None, None].repeat(H, F, 1, 1)
+    per_facet[1, 0] = torch.rand(600, 2, generator=g)
+    cases["per facet"] = per_facet
+    monkeypatch.setenv("ARTIST_HIP_DEBUG", "1")
+    for name, uv in cases.items():
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("ARTIST_HIP_NURBS_GRID", flag)
+            c = cp.clone().requires_grad_(True)
+            pts, nrm = NURBSSurfaces(torch.tensor([3, 3]), c, device=DEV)(uv.to(DEV), None, None)
+            (pts.sum() + nrm[..., 0].sum()).backward()
+            got[flag] = (n(pts), n(nrm), n(c.grad))
+        np.testing.assert_array_equal(got["1"][0], got["0"][0], err_msg=name)
+        np.testing.assert_array_equal(got["1"][1], got["0"][1], err_msg=name)
+        assert rel_l2(got["1"][2], got["0"][2]) < 2e-6, (name, rel_l2(got["1"][2], got["0"][2]))
+
+
 # ---------------------------------------------------------------------------------------------
 # Cylindrical receivers (geometry.line_cylinder_intersections, artist/raytracing/geometry.py:207-445).
 # In fp32 the hit is ill-conditioned at the fixtures' geometry (b^2 - 4ac cancels ~400x): the yardstick
@@ -1492,11 +1598,14 @@ def test_random_scenes_split_calls(seed, H, P, R, variant, monkeypatch):
     assert rel_l2(n(o.grad), go) < tol and rel_l2(n(nn_.grad), gn) < tol
 
 
-def test_blocking_backward_with_facet_sized_items():
+def test_blocking_backward_with_facet_sized_items(monkeypatch):
     """Blocking backward on a planar tower at the metric config's point count (P = 10 000 in four facets, ~100 heliostats): the
     call takes the lean blocking item in FACET-sized blocks, whose rectangle-gradient slabs are more numerous than the generic
     geometry's - round 3 sized the scratch buffer from the latter and this call raised ART_EINVAL (advisor finding; every other
-    blocking-backward test runs at P <= 1500, where the two geometries coincide).  Against the oracle on the same inputs."""
+    blocking-backward test runs at P <= 1500, where the two geometries coincide).  Flux and point gradients of a sample of
+    heliostats against the oracle (its blocking has no culling: 100 rectangles per ray, so not the whole field); the rectangle
+    gradients - sums over every ray of the field - against the same call through the generic item (round 3's path at this
+    size), whose slabs are cut differently."""
     from artist_amd import _lib, trace_rays
     H, P, R, facet = 100, 10000, 24, 2500
     lib = _lib.lib()
@@ -1506,28 +1615,40 @@ def test_blocking_backward_with_facet_sized_items():
     dv = lambda x: x.to(DEV)
     f32 = lambda x: np.ascontiguousarray(x.detach().cpu().numpy())
     tix = sc["target_idx"] % 2
-    prims = {k: dv(v) for k, v in sc["prims"].items()}
-    prims["corners"].requires_grad_(True)
-    o, nn_ = dv(sc["origins"]).requires_grad_(True), dv(sc["normals"]).requires_grad_(True)
-    both = dv(sc["both"])
-    args = (o, nn_, dv(sc["incident"]), both[..., 0], both[..., 1], dv(tix), dv(sc["planes"]["centers"]),
-            dv(sc["planes"]["normals"]), dv(sc["planes"]["dims"]))
     res = (128, 128)
-    flux, fac, _ = trace_rays(*args, ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=res,
-                              blocking=dict(prims, lbvh_compat=False), points_per_facet=facet)
-    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(21)).to(DEV)
-    (flux * w).sum().backward()                       # raised ArtistHipError(ART_EINVAL) before the fix
-    torch.cuda.synchronize()
-    oracle_args = (f32(sc["origins"]), f32(sc["normals"]), f32(sc["incident"]), f32(sc["both"][..., 0]), f32(sc["both"][..., 1]),
-                   f32(tix), f32(sc["planes"]["centers"]), f32(sc["planes"]["normals"]), f32(sc["planes"]["dims"]), res)
-    okw = dict(blocking=dict({k: f32(v) for k, v in sc["prims"].items()}, lbvh_compat=False))
+    both = dv(sc["both"])
+    w = torch.rand((H, res[1], res[0]), generator=torch.Generator().manual_seed(21)).to(DEV)
+
+    def run():
+        prims = {k: dv(v) for k, v in sc["prims"].items()}
+        prims["corners"].requires_grad_(True)
+        o, nn_ = dv(sc["origins"]).requires_grad_(True), dv(sc["normals"]).requires_grad_(True)
+        args = (o, nn_, dv(sc["incident"]), both[..., 0], both[..., 1], dv(tix), dv(sc["planes"]["centers"]),
+                dv(sc["planes"]["normals"]), dv(sc["planes"]["dims"]))
+        flux, fac, _ = trace_rays(*args, ray_magnitude=0.7, extinction=0.05, reflectivity=0.9, resolution=res,
+                                  blocking=dict(prims, lbvh_compat=False), points_per_facet=facet)
+        (flux * w).sum().backward()                       # raised ArtistHipError(ART_EINVAL) before the fix
+        torch.cuda.synchronize()
+        return n(flux), n(fac), n(o.grad), n(nn_.grad), n(prims["corners"].grad)
+
+    flux, fac, go_hip, gn_hip, gpc_hip = run()
+    monkeypatch.setenv("ARTIST_HIP_DEBUG", "1")
+    monkeypatch.setenv("ARTIST_HIP_BLOCK_LEAN", "0")
+    flux_g, fac_g, go_g, gn_g, gpc_g = run()
+    np.testing.assert_array_equal(flux, flux_g)                                    # integer accumulators: same bits
+    assert np.linalg.norm(gpc_g) > 0 and rel_l2(gpc_hip, gpc_g) < 1e-5, rel_l2(gpc_hip, gpc_g)
+    assert rel_l2(go_hip, go_g) < 1e-5 and rel_l2(gn_hip, gn_g) < 1e-5
+    sel = [0, 1, 17, 50, 99]                                # (0 and 1 have a free-standing panel in their beams)
+    sub = lambda x: f32(x[sel])
+    oracle_args = (sub(sc["origins"]), sub(sc["normals"]), sub(sc["incident"]), sub(sc["both"][..., 0]), sub(sc["both"][..., 1]),
+                   sub(tix), f32(sc["planes"]["centers"]), f32(sc["planes"]["normals"]), f32(sc["planes"]["dims"]), res)
+    okw = dict(blocking=dict({k: (sub(v) if k == "owner" else f32(v)) for k, v in sc["prims"].items()}, lbvh_compat=False))
     o_flux, o_fac = oracle.trace_fwd(*oracle_args, 0.7, 0.05, 0.9, **okw)[:2]
-    assert o_flux.sum() > 0 and (n(fac[2]) < 1).any()
-    assert rel_l2(n(flux), o_flux) < 1e-5, rel_l2(n(flux), o_flux)
-    go, gn, gpc, _, _ = oracle.trace_bwd(*oracle_args, f32(w), 0.7, 0.05, 0.9, **okw)
-    assert rel_l2(n(o.grad), go) < 2e-5, rel_l2(n(o.grad), go)
-    assert rel_l2(n(nn_.grad), gn) < 2e-5, rel_l2(n(nn_.grad), gn)
-    assert np.linalg.norm(gpc) > 0 and rel_l2(n(prims["corners"].grad), gpc) < 2e-5, rel_l2(n(prims["corners"].grad), gpc)
+    assert o_flux.sum() > 0 and (fac[2][sel] < 1).any()
+    assert rel_l2(flux[sel], o_flux) < 1e-5, rel_l2(flux[sel], o_flux)
+    go, gn = oracle.trace_bwd(*oracle_args, f32(w[sel]), 0.7, 0.05, 0.9, **okw)[:2]
+    assert rel_l2(go_hip[sel], go) < 2e-5, rel_l2(go_hip[sel], go)
+    assert rel_l2(gn_hip[sel], gn) < 2e-5, rel_l2(gn_hip[sel], gn)
 
 
 @pytest.mark.parametrize("res", [(700, 40), (40, 700), (2, 2), (3, 1500)])
