@@ -43,8 +43,8 @@
 namespace art {
 
 constexpr int kMaxDeg = 7;
-constexpr int kNurbsBlock = 256;
-constexpr int kBwdStripPoints = 2;      // tensor-product backward: points per thread and strip of grid rows
+constexpr int kNurbsFwdBlock = 64;      // forward: one wave per (facet, group of grid rows) - no workgroup barriers
+constexpr int kNurbsBwdBlock = 512;     // backward: launch bound; 4 or 8 waves per facet (art_nurbs_bwd)
 
 struct NurbsArgs {
     const float* cp;        // [H,F,nu,nv,3]
@@ -154,59 +154,6 @@ __host__ __device__ inline int nurbs_f64_offset(const NurbsArgs& a)
     return (n + 1) & ~1;
 }
 
-template <int DEG>
-struct Eval {
-    static constexpr int S = (DEG > 0 ? DEG : kMaxDeg) + 1;
-    int su, sv;
-    float Nu[S], Du[S], Nv[S], Dv[S];
-    float S0[4], Su[3], Sv[3];   // S0 = homogeneous point (w in [3])
-};
-
-// surfaces.py:592-613 with the reference's loop order (k, s, r) and zero-initialised accumulators.
-template <int DEG>
-__device__ __forceinline__ void evaluate(const NurbsArgs& a, const float* s_cp, const float* s_ku, const float* s_kv,
-                                         float x, float y, Eval<DEG>& E)
-{
-    constexpr int S = Eval<DEG>::S;
-    const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
-    E.su = find_span(x, s_ku, a.nu, p, a.uniform, a.n_unique_u);
-    E.sv = find_span(y, s_kv, a.nv, q, a.uniform, a.n_unique_v);
-    basis<DEG>(x, s_ku, E.su, p, E.Nu, E.Du);
-    basis<DEG>(y, s_kv, E.sv, q, E.Nv, E.Dv);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        float temp[S][4];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (s > q) break;
-            float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
-            for (int r = 0; r < S; ++r) {
-                if (r > p) break;
-                const float b = k ? E.Du[r] : E.Nu[r];
-                const float* c3 = s_cp + ((E.su - p + r) * a.nv + (E.sv - q + s)) * 3;
-                t0 += b * c3[0]; t1 += b * c3[1]; t2 += b * c3[2];
-                t3 += b * 1.0f;          // control-point weights are all ones (surfaces.py:524-537)
-            }
-            temp[s][0] = t0; temp[s][1] = t1; temp[s][2] = t2; temp[s][3] = t3;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t > 1 - k) break;
-            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (s > q) break;
-                const float b = t ? E.Dv[s] : E.Nv[s];
-                d0 += b * temp[s][0]; d1 += b * temp[s][1]; d2 += b * temp[s][2]; d3 += b * temp[s][3];
-            }
-            if (k == 0 && t == 0) { E.S0[0] = d0; E.S0[1] = d1; E.S0[2] = d2; E.S0[3] = d3; }
-            else if (k == 1) { E.Su[0] = d0; E.Su[1] = d1; E.Su[2] = d2; }
-            else { E.Sv[0] = d0; E.Sv[1] = d1; E.Sv[2] = d2; }
-        }
-    }
-}
-
 // Stage one facet's control net + knots (+ canting basis) in LDS.
 // LDS layout: [cp nu*nv*3][knots_u nu+p+1][knots_v nv+q+1][B 9]
 __device__ __forceinline__ void stage_facet(const NurbsArgs& a, int hf, float* lds, float*& s_cp, float*& s_ku,
@@ -308,39 +255,34 @@ __device__ __forceinline__ void point_adjoint(const NurbsArgs& a, float w, const
 
 // ---- tensor-product scheme: grid discovery, row / column bases, stage 1 ----------------------------------------------
 
-struct GridInfo { int Mu, Mv; bool ok; };
-
-// Is the facet's point list a cartesian grid, m = i Mv + j at (u_i, v_j)?  Mv = index of the first point whose u differs
-// from point 0's (M when there is none: one row); then EVERY point must carry its row's u and its column's v, bit for bit
-// (every workgroup of a facet checks all of them, so that all of them take the same scheme).  s_int: two LDS words.
-__device__ __forceinline__ GridInfo detect_grid(const NurbsArgs& a, const float* __restrict__ uvp, int* s_int)
+// Writes of one wave to LDS become visible to its other lanes (the LDS unit executes a wave's instructions in order; this
+// keeps the compiler from moving them across).  No hardware barrier: the waves of a workgroup work independently.
+__device__ __forceinline__ void wave_sync()
 {
-    if (threadIdx.x == 0) { s_int[0] = a.M; s_int[1] = 0; }
-    __syncthreads();
-    const float u0 = uvp[0];
-    for (int m = threadIdx.x; m < a.M; m += blockDim.x)
-        if (uvp[2 * (int64_t)m] != u0) { atomicMin(&s_int[0], m); break; }
-    __syncthreads();
-    GridInfo g;
-    g.Mv = s_int[0];
-    if (g.Mv <= 0) { g.Mu = 0; g.ok = false; return g; }      // (a NaN at point 0 differs from itself)
-    g.Mu = a.M / g.Mv;
-    g.ok = g.Mu * g.Mv == a.M;
-    if (!g.ok) return g;
-    bool bad = false;
-    for (int m = threadIdx.x; m < a.M; m += blockDim.x) {
-        const int i = m / g.Mv, j = m - i * g.Mv;
-        const float2 x = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
-        bad |= !(x.x == uvp[2 * (int64_t)i * g.Mv]) || !(x.y == uvp[2 * (int64_t)j + 1]);
-    }
-    if (bad) s_int[1] = 1;
-    __syncthreads();
-    g.ok = s_int[1] == 0;
-    return g;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Row / column basis records in LDS: kBasisWords<DEG> words per grid line - [span (int bits), N[0..S-1], D[0..S-1], sum_r N[r] * 1]
-template <int DEG> struct BasisRec { static constexpr int S = (DEG > 0 ? DEG : kMaxDeg) + 1; static constexpr int words = 2 * S + 2; };
+// Row length of a cartesian point list m = i Mv + j at (u_i, v_j): the index of the first point whose u differs from
+// point 0's (M when there is none: one row).  Found by every wave for itself (64 points per step: one step for ARTIST's 50).
+// Returns 0 when point 0's u is a NaN (it differs from itself).
+__device__ __forceinline__ int find_row_length(const float* __restrict__ uvp, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const float u0 = uvp[0];
+    for (int base = 0; base < M; base += 64) {
+        const int m = base + lane;
+        const bool differs = m < M && uvp[2 * (int64_t)m] != u0;
+        const unsigned long long mask = __ballot(differs);
+        if (mask != 0ull) return base + (int)__builtin_ctzll(mask);
+    }
+    return M;
+}
+
+// Row / column basis records in LDS, BasisRec<DEG>::words words per grid line:
+//   [span (int bits), N[0..S-1], D[0..S-1], sum_r N[r] * 1, the line's coordinate]
+template <int DEG> struct BasisRec { static constexpr int S = (DEG > 0 ? DEG : kMaxDeg) + 1; static constexpr int words = 2 * S + 3; };
 
 template <int DEG>
 __device__ __forceinline__ void line_basis(const NurbsArgs& a, float x, const float* knots, int n, int deg, int n_unique, float* rec)
@@ -358,18 +300,20 @@ __device__ __forceinline__ void line_basis(const NurbsArgs& a, float x, const fl
         w += N[r] * 1.0f;          // the homogeneous coordinate's inner sum (weights are all ones, surfaces.py:524-537)
     }
     rec[1 + 2 * S] = w;
+    rec[2 + 2 * S] = x;
 }
 
 // stage 1 for grid rows [r0, r0 + rs): temp[il][c][0..2] = sum_r Nu[r] CP[su-p+r][c], temp[il][c][3..5] the same with Du
-// (surfaces.py:592-603: loop order r from a zero accumulator)
+// (surfaces.py:592-603: loop order r from a zero accumulator).  Threads t0, t0 + stride, ... of the caller's team.
 template <int DEG>
 __device__ __forceinline__ void stage1_rows(const NurbsArgs& a, const float* s_cp, const float* s_bu, int bu_row0, int r0, int rs,
-                                            float* s_temp)
+                                            float* s_temp, int t0, int stride)
 {
     constexpr int S = BasisRec<DEG>::S, W = BasisRec<DEG>::words;
     const int p = DEG > 0 ? DEG : a.p;
-    for (int idx = threadIdx.x; idx < rs * a.nv; idx += blockDim.x) {
-        const int il = idx / a.nv, c = idx - il * a.nv;
+    const float inv_nv = 1.0f / (float)a.nv;
+    for (int idx = t0; idx < rs * a.nv; idx += stride) {
+        const int il = (int)(((float)idx + 0.5f) * inv_nv), c = idx - il * a.nv;      // (exact: idx < 2^22)
         const float* rec = s_bu + (r0 + il - bu_row0) * W;
         const int su = __float_as_int(rec[0]);
         float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -410,13 +354,51 @@ __device__ __forceinline__ void stage2_point(const NurbsArgs& a, const float* tr
     Sv[0] = dv[0]; Sv[1] = dv[1]; Sv[2] = dv[2];
 }
 
+// The scattered scheme's point: its own u- and v-records (line_basis, in the thread's LDS slots) contracted with the control
+// net - the arithmetic of stage 1 + stage 2 for a single point, i.e. surfaces.py:592-613 in the reference's order.
+template <int DEG>
+__device__ __forceinline__ void eval_from_records(const NurbsArgs& a, const float* s_cp, const float* recu, const float* recv,
+                                                  float* S0, float* Su, float* Sv)
+{
+    constexpr int S = BasisRec<DEG>::S;
+    const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
+    const int su = __float_as_int(recu[0]), sv = __float_as_int(recv[0]);
+    float d0[4] = {0.f, 0.f, 0.f, 0.f}, du[3] = {0.f, 0.f, 0.f}, dv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s > q) break;
+        float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            if (r > p) break;
+            const float* c3 = s_cp + ((su - p + r) * a.nv + (sv - q + s)) * 3;
+            const float bn = recu[1 + r], bd = recu[1 + S + r];
+            t[0] += bn * c3[0]; t[1] += bn * c3[1]; t[2] += bn * c3[2];
+            t[3] += bd * c3[0]; t[4] += bd * c3[1]; t[5] += bd * c3[2];
+        }
+        const float bn = recv[1 + s], bd = recv[1 + S + s];
+        d0[0] += bn * t[0]; d0[1] += bn * t[1]; d0[2] += bn * t[2]; d0[3] += bn * recu[1 + 2 * S];
+        du[0] += bn * t[3]; du[1] += bn * t[4]; du[2] += bn * t[5];
+        dv[0] += bd * t[0]; dv[1] += bd * t[1]; dv[2] += bd * t[2];
+    }
+    S0[0] = d0[0]; S0[1] = d0[1]; S0[2] = d0[2]; S0[3] = d0[3];
+    Su[0] = du[0]; Su[1] = du[1]; Su[2] = du[2];
+    Sv[0] = dv[0]; Sv[1] = dv[1]; Sv[2] = dv[2];
+}
+
+constexpr int kScatterThreads = 256;     // threads of a workgroup that take points in the scattered scheme (LDS records each)
+
 // ---- forward -------------------------------------------------------------------------------------------------------------
 
-// grid = H * F * groups.  Workgroup `group` of a facet takes grid rows [group * ceil(Mu / groups), ...) in the tensor-product
-// scheme, points [group * ceil(M / groups), ...) in the scattered one.
+// One WAVE (a 64-thread workgroup: its barriers are free) per (facet, group of grid rows); grid = H * F * groups.  Group g
+// takes grid rows [g ceil(Mu / groups), ...), i.e. points [row0 Mv, row1 Mv).  The wave finds the row length, builds the
+// column bases and its rows' bases (one grid line per lane), then alternates stage 1 (a pass of rows) and stage 2 (their
+// points).  Every point's coordinates are compared with its row's u and its column's v as it is evaluated; if any point of
+// the wave's rows is off the grid, the wave evaluates its points again one by one (scattered scheme) - so a point list that
+// is not a grid costs one wasted pass, never a wrong result, and nobody has to say what kind of list it is.
 template <int DEG>
-__global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, float4* __restrict__ points,
-                                                                float4* __restrict__ normals)
+__global__ __launch_bounds__(kNurbsFwdBlock) void nurbs_fwd_kernel(NurbsArgs a, float4* __restrict__ points,
+                                                                   float4* __restrict__ normals)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int W = BasisRec<DEG>::words;
@@ -427,141 +409,141 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_fwd_kernel(NurbsArgs a, flo
     const float* uvp = a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf;
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int n0 = nurbs_f64_offset(a);
-    int* s_int = reinterpret_cast<int*>(lds + n0);
-    GridInfo g = {0, 0, false};
-    if (a.grid_mode) g = detect_grid(a, uvp, s_int);
-    if (g.ok) {
-        const int rpg = (g.Mu + a.groups - 1) / a.groups;
-        const int i0 = group * rpg, i1 = min(g.Mu, i0 + rpg);
-        // LDS behind the facet tables: [2 ints][row bases rpg][column bases Mv][temps rows_pass x nv x 6]
-        // (sized by rpg, not by this group's row count: all groups of a facet decide alike whether the scheme fits)
-        float* s_bu = lds + n0 + 2;
-        float* s_bv = s_bu + rpg * W;
-        float* s_temp = s_bv + g.Mv * W;
+    // the points this wave evaluates when the list is not a grid
+    const int per = (a.M + a.groups - 1) / a.groups;
+    int m0 = min(a.M, group * per), m1 = min(a.M, m0 + per);
+    const int Mv = a.grid_mode ? find_row_length(uvp, a.M) : 0;
+    if (Mv > 0 && a.M % Mv == 0) {
+        const int Mu = a.M / Mv;
+        const int rpg = (Mu + a.groups - 1) / a.groups;
+        const int i0 = min(Mu, group * rpg), i1 = min(Mu, i0 + rpg);
+        // LDS behind the facet tables: [column bases Mv][row bases rpg][temps rows_pass x nv x 6]
+        float* s_bv = lds + n0;
+        float* s_bu = s_bv + Mv * W;
+        float* s_temp = s_bu + rpg * W;
         const int room = a.lds_floats - (int)(s_temp - lds);
-        const int rows_pass = room > 0 ? min(rpg, room / (a.nv * 6)) : 0;
-        if (rows_pass >= 1) {
+        int rows_pass = room > 0 ? min(rpg, room / (a.nv * 6)) : 0;
+        rows_pass = min(rows_pass, max(1, 128 / a.nv));          // ~two lane-steps of (row, column) pairs per pass
+        if (rows_pass >= 1) {                                     // (all groups of a facet decide alike: sized by rpg)
+            m0 = i0 * Mv; m1 = i1 * Mv;
             if (i0 >= i1) return;
-            for (int t = threadIdx.x; t < (i1 - i0) + g.Mv; t += blockDim.x) {
-                if (t < i1 - i0) line_basis<DEG>(a, uvp[2 * (int64_t)(i0 + t) * g.Mv], s_ku, a.nu, p, a.n_unique_u, s_bu + t * W);
-                else line_basis<DEG>(a, uvp[2 * (int64_t)(t - (i1 - i0)) + 1], s_kv, a.nv, q, a.n_unique_v, s_bv + (t - (i1 - i0)) * W);
+            for (int t = threadIdx.x; t < (i1 - i0) + Mv; t += blockDim.x) {
+                if (t < Mv) line_basis<DEG>(a, uvp[2 * (int64_t)t + 1], s_kv, a.nv, q, a.n_unique_v, s_bv + t * W);
+                else line_basis<DEG>(a, uvp[2 * (int64_t)(i0 + t - Mv) * Mv], s_ku, a.nu, p, a.n_unique_u, s_bu + (t - Mv) * W);
             }
             __syncthreads();
+            const float inv_mv = 1.0f / (float)Mv;
+            bool off_grid = false;
             for (int r0 = i0; r0 < i1; r0 += rows_pass) {
                 const int rs = min(rows_pass, i1 - r0);
-                stage1_rows<DEG>(a, s_cp, s_bu, i0, r0, rs, s_temp);
+                stage1_rows<DEG>(a, s_cp, s_bu, i0, r0, rs, s_temp, threadIdx.x, blockDim.x);
                 __syncthreads();
-                for (int idx = threadIdx.x; idx < rs * g.Mv; idx += blockDim.x) {
-                    const int il = idx / g.Mv, j = idx - il * g.Mv;
+                for (int idx = threadIdx.x; idx < rs * Mv; idx += blockDim.x) {
+                    const int il = (int)(((float)idx + 0.5f) * inv_mv), j = idx - il * Mv;
+                    const float* recu = s_bu + (r0 + il - i0) * W;
+                    const float* recv = s_bv + j * W;
+                    const int m = (r0 + il) * Mv + j;
+                    const float2 x = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
+                    off_grid |= !(x.x == recu[W - 1]) || !(x.y == recv[W - 1]);
                     float S0[4], Su[3], Sv[3];
-                    stage2_point<DEG>(a, s_temp + il * a.nv * 6, s_bv + j * W, s_bu[(r0 + il - i0) * W + W - 1], S0, Su, Sv);
-                    finish_point(a, S0, Su, Sv, s_B, hf, h, (r0 + il) * g.Mv + j, points, normals);
+                    stage2_point<DEG>(a, s_temp + il * a.nv * 6, recv, recu[W - 2], S0, Su, Sv);
+                    finish_point(a, S0, Su, Sv, s_B, hf, h, m, points, normals);
                 }
-                if (r0 + rows_pass < i1) __syncthreads();
+                __syncthreads();
             }
-            return;
+            if (__syncthreads_or(off_grid ? 1 : 0) == 0) return;
         }
     }
-    // scattered scheme
-    const int per = (a.M + a.groups - 1) / a.groups;
-    const int m1 = min(a.M, (group + 1) * per);
-    for (int m = group * per + threadIdx.x; m < m1; m += blockDim.x) {
+    // scattered scheme (the thread's two basis records live in LDS, behind the facet tables)
+    float* recu = lds + n0 + threadIdx.x * 2 * W;
+    float* recv = recu + W;
+    for (int m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
         const float2 xy = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
-        Eval<DEG> E;
-        evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
-        finish_point(a, E.S0, E.Su, E.Sv, s_B, hf, h, m, points, normals);
+        line_basis<DEG>(a, xy.x, s_ku, a.nu, p, a.n_unique_u, recu);
+        line_basis<DEG>(a, xy.y, s_kv, a.nv, q, a.n_unique_v, recv);
+        float S0[4], Su[3], Sv[3];
+        eval_from_records<DEG>(a, s_cp, recu, recv, S0, Su, Sv);
+        finish_point(a, S0, Su, Sv, s_B, hf, h, m, points, normals);
     }
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------------
 
-// Scattered scheme: threads stride over runs of points; gradient net in LDS (double, LDS atomics).
+// Scattered scheme: one point per thread and step, 3 (p+1)(q+1) double LDS atomics per point into the facet's gradient net
+// (ds_add_f64; the order of the adds is not fixed - the sums are the same to fp32 output precision, not bit-reproducible).
+// (Round 3 merged the sums of consecutive points of a knot-span cell in registers first - 48 accumulators that set the
+// kernel's register count; the scheme now serves SurfaceGenerator.fit_nurbs only, not the epoch.)
+// LDS: [facet tables][gradient net: ncp doubles][two basis records per working thread]
 template <int DEG>
 __device__ __forceinline__ void nurbs_bwd_scattered(const NurbsArgs& a, int hf, float* lds, const float* s_cp, const float* s_ku,
                                                     const float* s_kv, const float* s_B, const float4* __restrict__ g_points,
                                                     const float4* __restrict__ g_normals, float* __restrict__ g_cp)
 {
-    constexpr int S = Eval<DEG>::S;
+    constexpr int S = BasisRec<DEG>::S, W = BasisRec<DEG>::words;
     const int ncp = a.nu * a.nv * 3;
-    double* s_g = reinterpret_cast<double*>(lds + nurbs_f64_offset(a));   // 8-byte aligned tail of the LDS block
-    __syncthreads();                                                       // (the grid discovery may still be reading its two words)
+    const int n0 = nurbs_f64_offset(a);
+    double* s_g = reinterpret_cast<double*>(lds + n0);                     // 8-byte aligned
+    __syncthreads();
     for (int i = threadIdx.x; i < ncp; i += blockDim.x) s_g[i] = 0.0;
     __syncthreads();
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int h = hf / a.F, f = hf % a.F;
-    // A thread owns a RUN of consecutive evaluation points and keeps the (p+1)(q+1) x 3 sums of the control points of the
-    // current knot-span cell in registers; they go to the LDS accumulator - one ds_add_f64 each, the pipe that bounds this
-    // scheme - only when the run leaves the cell and at its end.  Neighbouring runs share their control points, so lanes
-    // that took neighbouring runs would all add to the same LDS cells (up to 64-way serialisation): lane t takes run
-    // (t K) mod n_runs, K prime and coprime to n_runs (a bijection), which puts the lanes of a wave in different cells.
-    const int run_len = (a.M + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int n_runs = (a.M + run_len - 1) / run_len;
+    const float* uvp = a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf;
+    // neighbouring points share their control points: thread t takes points (t K) mod M, ((t + T) K) mod M, ... with K
+    // coprime to M (a bijection), so that the lanes of a wave add to different cells
     int K = 1;
     {
         const int primes[8] = {61, 59, 53, 47, 43, 41, 37, 31};
 #pragma unroll
         for (int i = 7; i >= 0; --i)
-            if (n_runs % primes[i] != 0) K = primes[i];
+            if (a.M % primes[i] != 0) K = primes[i];
     }
-    float acc[S][S][3];
-    int cur_u = -1, cur_v = -1;
-    auto flush = [&]() {
-        if (cur_u < 0) return;
+    const int team = min((int)blockDim.x, kScatterThreads);
+    if ((int)threadIdx.x < team) {
+        float* recu = lds + n0 + 2 * ncp + threadIdx.x * 2 * W;
+        float* recv = recu + W;
+        for (int t = threadIdx.x; t < a.M; t += team) {
+            const int m = (int)(((int64_t)t * K) % a.M);
+            const float2 xy = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
+            line_basis<DEG>(a, xy.x, s_ku, a.nu, p, a.n_unique_u, recu);
+            line_basis<DEG>(a, xy.y, s_kv, a.nv, q, a.n_unique_v, recv);
+            float S0[4], Su[3], Sv[3], gS[3], gSu[3], gSv[3];
+            eval_from_records<DEG>(a, s_cp, recu, recv, S0, Su, Sv);
+            point_adjoint(a, S0[3], Su, Sv, s_B, hf, h, m, g_points, g_normals, gS, gSu, gSv);
+            const int su = __float_as_int(recu[0]), sv = __float_as_int(recv[0]);
+#pragma unroll 1
+            for (int r = 0; r <= p; ++r) {
+#pragma unroll 1
+                for (int s_ = 0; s_ <= q; ++s_) {
+                    const float nu_r = recu[1 + r], du_r = recu[1 + S + r], nv_s = recv[1 + s_], dv_s = recv[1 + S + s_];
+                    const float w00 = nu_r * nv_s, w10 = du_r * nv_s, w01 = nu_r * dv_s;
+                    double* g3 = s_g + ((su - p + r) * a.nv + (sv - q + s_)) * 3;
 #pragma unroll
-        for (int r = 0; r < S; ++r) {
-            if (r > p) break;
-#pragma unroll
-            for (int s_ = 0; s_ < S; ++s_) {
-                if (s_ > q) break;
-                double* g3 = s_g + ((cur_u - p + r) * a.nv + (cur_v - q + s_)) * 3;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) atomicAdd(g3 + k, (double)acc[r][s_][k]);
-            }
-        }
-    };
-    if ((int)threadIdx.x < n_runs) {
-      const int run = (int)(((int64_t)threadIdx.x * K) % n_runs);
-      for (int m = run * run_len; m < min(a.M, (run + 1) * run_len); ++m) {
-        const float2 xy = *reinterpret_cast<const float2*>(a.uv + (int64_t)h * a.uv_sh + (int64_t)f * a.uv_sf + 2 * (int64_t)m);
-        Eval<DEG> E;
-        evaluate<DEG>(a, s_cp, s_ku, s_kv, xy.x, xy.y, E);
-        float gS[3], gSu[3], gSv[3];
-        point_adjoint(a, E.S0[3], E.Su, E.Sv, s_B, hf, h, m, g_points, g_normals, gS, gSu, gSv);
-        const bool same = E.su == cur_u && E.sv == cur_v;
-        if (!same) { flush(); cur_u = E.su; cur_v = E.sv; }
-#pragma unroll
-        for (int r = 0; r < S; ++r) {
-            if (r > p) break;
-#pragma unroll
-            for (int s_ = 0; s_ < S; ++s_) {
-                if (s_ > q) break;
-                const float w00 = E.Nu[r] * E.Nv[s_], w10 = E.Du[r] * E.Nv[s_], w01 = E.Nu[r] * E.Dv[s_];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float c = w00 * gS[k] + w10 * gSu[k] + w01 * gSv[k];
-                    acc[r][s_][k] = same ? acc[r][s_][k] + c : c;
+                    for (int k = 0; k < 3; ++k) atomicAdd(g3 + k, (double)(w00 * gS[k] + w10 * gSu[k] + w01 * gSv[k]));
                 }
             }
         }
-      }
-      flush();
     }
     __syncthreads();
     float* out = g_cp + (int64_t)hf * ncp;
     for (int i = threadIdx.x; i < ncp; i += blockDim.x) out[i] = (float)s_g[i];
 }
 
-// One workgroup per (h,f).  Tensor-product scheme = the adjoint of the forward's two stages, strip of rows by strip:
-//   points   (thread <-> point)    recompute Su, Sv, w from the strip's temps; (gS, gSu, gSv) -> LDS [point][9]
-//   stage A  (thread <-> (row, column c, component))   gT[i][c][0..2] = sum_j Nv_j[c - sv_j + q] gS[i][j] + Dv_j[..] gSv[i][j],
-//            gT[i][c][3..5] = sum_j Nv_j[..] gSu[i][j]      j in index order over the columns whose span covers c
-//   stage B  (thread <-> control-point component, once, after the last strip)
-//            gCP[a][c] = sum_i Nu_i[a - su_i + p] gT[i][c][0..2] + Du_i[..] gT[i][c][3..5]      i in index order
+// One workgroup per (h,f).  Tensor-product scheme = the adjoint of the forward's two stages.  The workgroup's WAVES take
+// strips of grid rows on their own - no workgroup barrier while the points are processed:
+//   temps    stage 1 of the strip's rows (recomputation)
+//   points   (lane <-> point)  Su, Sv, w from the temps; (gS, gSu, gSv) -> the wave's LDS strip [point][9]
+//   stage A  (lane <-> (row, control column c, component k) x half of the column range)
+//            gT[i][c][k] = sum_j Nv_j[c - sv_j + q] gS[i][j][k] + Dv_j[..] gSv[i][j][k],  gT[i][c][3 + k] = sum_j Nv_j[..] gSu[i][j][k]
+//            j in index order over the grid columns whose span covers c (two halves, lower + upper)
+// then ONE barrier and
+//   stage B  (thread <-> control-point component)
+//            gCP[a][c][k] = sum_i Nu_i[a - su_i + p] gT[i][c][k] + Du_i[..] gT[i][c][3 + k]      i in index order
 // Every output element has ONE owner that adds in a fixed order: no atomics, bit-reproducible gradients.
 template <int DEG>
-__global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, const float4* __restrict__ g_points,
-                                                                const float4* __restrict__ g_normals,
-                                                                float* __restrict__ g_cp)
+__global__ __launch_bounds__(kNurbsBwdBlock) void nurbs_bwd_kernel(NurbsArgs a, const float4* __restrict__ g_points,
+                                                                   const float4* __restrict__ g_normals,
+                                                                   float* __restrict__ g_cp)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int S = BasisRec<DEG>::S, W = BasisRec<DEG>::words;
@@ -573,35 +555,34 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int n0 = nurbs_f64_offset(a);
     const int ncp = a.nu * a.nv * 3;
-    int* s_int = reinterpret_cast<int*>(lds + n0);
-    GridInfo g = {0, 0, false};
-    if (a.grid_mode) g = detect_grid(a, uvp, s_int);
-    if (g.ok) {
-        // LDS behind the facet tables: [2 ints][jlo, jhi per column c: 2 nv ints][ilo, ihi per row a: 2 nu ints]
-        //   [row bases Mu][column bases Mv][gT Mu x nv x 6][temps rs x nv x 6][point gradients rs x Mv x 9]
-        int* s_jr = s_int + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int Mv = a.grid_mode ? find_row_length(uvp, a.M) : 0;          // (every wave for itself: the same number)
+    if (Mv > 0 && a.M % Mv == 0) {
+        const int Mu = a.M / Mv;
+        // LDS behind the facet tables: [flag][jlo, jhi per control column: 2 nv ints][ilo, ihi per control row: 2 nu ints]
+        //   [row bases Mu][column bases Mv][gT Mu x nv x 6][per wave: temps rs x nv x 6, point gradients rs x Mv x 9]
+        int* s_flag = reinterpret_cast<int*>(lds + n0);
+        int* s_jr = s_flag + 2;
         int* s_ir = s_jr + 2 * a.nv;
         float* s_bu = reinterpret_cast<float*>(s_ir + 2 * a.nu);
-        float* s_bv = s_bu + g.Mu * W;
-        float* s_gt = s_bv + g.Mv * W;
-        float* s_temp = s_gt + g.Mu * a.nv * 6;
-        const int room = a.lds_floats - (int)(s_temp - lds);
-        const int per_row = a.nv * 6 + g.Mv * 9;
-        int rs_max = room > 0 ? room / per_row : 0;
-        rs_max = min(rs_max, max(1, (kBwdStripPoints * (int)blockDim.x) / g.Mv));      // points per thread and strip
-        rs_max = min(rs_max, g.Mu);
-        if (rs_max >= 1) {
+        float* s_bv = s_bu + Mu * W;
+        float* s_gt = s_bv + Mv * W;
+        float* s_wave = s_gt + Mu * a.nv * 6;
+        const int rs = max(1, 64 / Mv);                                   // rows per strip: one lane-step of points
+        const int per_wave = rs * (a.nv * 6 + Mv * 9);
+        if ((int)(s_wave - lds) + nwaves * per_wave <= a.lds_floats) {
+            if (threadIdx.x == 0) s_flag[0] = 0;
             for (int t = threadIdx.x; t < 2 * a.nv + 2 * a.nu; t += blockDim.x) s_jr[t] = (t & 1) ? -1 : 0x7fffffff;
-            for (int t = threadIdx.x; t < g.Mu + g.Mv; t += blockDim.x) {
-                if (t < g.Mu) line_basis<DEG>(a, uvp[2 * (int64_t)t * g.Mv], s_ku, a.nu, p, a.n_unique_u, s_bu + t * W);
-                else line_basis<DEG>(a, uvp[2 * (int64_t)(t - g.Mu) + 1], s_kv, a.nv, q, a.n_unique_v, s_bv + (t - g.Mu) * W);
+            for (int t = threadIdx.x; t < Mu + Mv; t += blockDim.x) {
+                if (t < Mu) line_basis<DEG>(a, uvp[2 * (int64_t)t * Mv], s_ku, a.nu, p, a.n_unique_u, s_bu + t * W);
+                else line_basis<DEG>(a, uvp[2 * (int64_t)(t - Mu) + 1], s_kv, a.nv, q, a.n_unique_v, s_bv + (t - Mu) * W);
             }
             __syncthreads();
             // which grid columns / rows touch control column c / control row a (any order of the grid lines is fine: the range
             // only bounds the loops, the band test inside them decides)
-            for (int t = threadIdx.x; t < g.Mu + g.Mv; t += blockDim.x) {
-                const bool is_u = t < g.Mu;
-                const int line = is_u ? t : t - g.Mu;
+            for (int t = threadIdx.x; t < Mu + Mv; t += blockDim.x) {
+                const bool is_u = t < Mu;
+                const int line = is_u ? t : t - Mu;
                 const int span = __float_as_int((is_u ? s_bu : s_bv)[line * W]);
                 const int deg = is_u ? p : q;
                 int* rng = is_u ? s_ir : s_jr;
@@ -610,55 +591,96 @@ __global__ __launch_bounds__(kNurbsBlock) void nurbs_bwd_kernel(NurbsArgs a, con
                     atomicMax(&rng[2 * (span - deg + r) + 1], line);
                 }
             }
-            float* s_pg = s_temp + rs_max * a.nv * 6;
-            for (int r0 = 0; r0 < g.Mu; r0 += rs_max) {
-                const int rs = min(rs_max, g.Mu - r0);
-                stage1_rows<DEG>(a, s_cp, s_bu, 0, r0, rs, s_temp);
-                __syncthreads();             // (also: the previous strip's stage A has read s_pg)
-                for (int idx = threadIdx.x; idx < rs * g.Mv; idx += blockDim.x) {
-                    const int il = idx / g.Mv, j = idx - il * g.Mv;
+            __syncthreads();
+            float* s_temp = s_wave + wave * per_wave;
+            float* s_pg = s_temp + rs * a.nv * 6;
+            const float inv_mv = 1.0f / (float)Mv;
+            const int n_strips = (Mu + rs - 1) / rs;
+            bool off_grid = false;
+            for (int strip = wave; strip < n_strips; strip += nwaves) {
+                const int r0 = strip * rs, rows = min(rs, Mu - r0);
+                stage1_rows<DEG>(a, s_cp, s_bu, 0, r0, rows, s_temp, lane, 64);
+                wave_sync();
+                for (int idx = lane; idx < rows * Mv; idx += 64) {
+                    const int il = (int)(((float)idx + 0.5f) * inv_mv), j = idx - il * Mv;
+                    const float* recu = s_bu + (r0 + il) * W;
+                    const float* recv = s_bv + j * W;
+                    const int m = (r0 + il) * Mv + j;
+                    const float2 x = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
+                    off_grid |= !(x.x == recu[W - 1]) || !(x.y == recv[W - 1]);
                     float S0[4], Su[3], Sv[3], gS[3], gSu[3], gSv[3];
-                    stage2_point<DEG>(a, s_temp + il * a.nv * 6, s_bv + j * W, s_bu[(r0 + il) * W + W - 1], S0, Su, Sv);
-                    point_adjoint(a, S0[3], Su, Sv, s_B, hf, h, (r0 + il) * g.Mv + j, g_points, g_normals, gS, gSu, gSv);
+                    stage2_point<DEG>(a, s_temp + il * a.nv * 6, recv, recu[W - 2], S0, Su, Sv);
+                    point_adjoint(a, S0[3], Su, Sv, s_B, hf, h, m, g_points, g_normals, gS, gSu, gSv);
                     float* o = s_pg + idx * 9;
                     o[0] = gS[0]; o[1] = gS[1]; o[2] = gS[2]; o[3] = gSu[0]; o[4] = gSu[1]; o[5] = gSu[2];
                     o[6] = gSv[0]; o[7] = gSv[1]; o[8] = gSv[2];
                 }
-                __syncthreads();
-                for (int o = threadIdx.x; o < rs * a.nv * 3; o += blockDim.x) {
-                    const int il = o / (a.nv * 3), rem = o - il * (a.nv * 3);
-                    const int c = rem / 3, k = rem - c * 3;
-                    const int jlo = s_jr[2 * c], jhi = s_jr[2 * c + 1];
+                wave_sync();
+                const int n_out = rows * a.nv * 3;
+                if (n_out <= 32) {
+                    // two lanes per output: lane o adds the lower half of the column range, lane o + 32 the upper half
+                    const int o = lane & 31, half = lane >> 5;
                     float acc_n = 0.f, acc_d = 0.f;
-                    for (int j = jlo; j <= jhi; ++j) {
-                        const float* rec = s_bv + j * W;
-                        const int s = c - (__float_as_int(rec[0]) - q);
-                        if ((unsigned)s > (unsigned)q) continue;
-                        const float* pg = s_pg + (il * g.Mv + j) * 9;
-                        acc_n = fmaf(rec[1 + S + s], pg[6 + k], fmaf(rec[1 + s], pg[k], acc_n));
-                        acc_d = fmaf(rec[1 + s], pg[3 + k], acc_d);
+                    int il = 0, c = 0, k = 0;
+                    if (o < n_out) {
+                        il = o / (a.nv * 3);
+                        const int rem = o - il * (a.nv * 3);
+                        c = rem / 3; k = rem - c * 3;
+                        const int jlo = s_jr[2 * c], jhi = s_jr[2 * c + 1];
+                        const int jmid = (jlo + jhi + 1) >> 1;
+                        const int ja = half ? jmid : jlo, jb = half ? jhi : jmid - 1;
+                        for (int j = ja; j <= jb; ++j) {
+                            const float* rec = s_bv + j * W;
+                            const int s = c - (__float_as_int(rec[0]) - q);
+                            if ((unsigned)s > (unsigned)q) continue;
+                            const float* pg = s_pg + (il * Mv + j) * 9;
+                            acc_n = fmaf(rec[1 + S + s], pg[6 + k], fmaf(rec[1 + s], pg[k], acc_n));
+                            acc_d = fmaf(rec[1 + s], pg[3 + k], acc_d);
+                        }
                     }
-                    float* gt = s_gt + ((r0 + il) * a.nv + c) * 6;
-                    gt[k] = acc_n; gt[3 + k] = acc_d;
+                    const float up_n = __shfl_xor(acc_n, 32, 64), up_d = __shfl_xor(acc_d, 32, 64);
+                    if (half == 0 && o < n_out) {
+                        float* gt = s_gt + ((r0 + il) * a.nv + c) * 6;
+                        gt[k] = acc_n + up_n; gt[3 + k] = acc_d + up_d;
+                    }
+                } else {
+                    for (int o = lane; o < n_out; o += 64) {
+                        const int il = o / (a.nv * 3), rem = o - il * (a.nv * 3);
+                        const int c = rem / 3, k = rem - c * 3;
+                        const int jlo = s_jr[2 * c], jhi = s_jr[2 * c + 1];
+                        float acc_n = 0.f, acc_d = 0.f;
+                        for (int j = jlo; j <= jhi; ++j) {
+                            const float* rec = s_bv + j * W;
+                            const int s = c - (__float_as_int(rec[0]) - q);
+                            if ((unsigned)s > (unsigned)q) continue;
+                            const float* pg = s_pg + (il * Mv + j) * 9;
+                            acc_n = fmaf(rec[1 + S + s], pg[6 + k], fmaf(rec[1 + s], pg[k], acc_n));
+                            acc_d = fmaf(rec[1 + s], pg[3 + k], acc_d);
+                        }
+                        float* gt = s_gt + ((r0 + il) * a.nv + c) * 6;
+                        gt[k] = acc_n; gt[3 + k] = acc_d;
+                    }
                 }
+                wave_sync();       // (the next strip overwrites the temps and the point gradients)
             }
-            __syncthreads();
-            float* out = g_cp + (int64_t)hf * ncp;
-            for (int o = threadIdx.x; o < ncp; o += blockDim.x) {
-                const int ar = o / (a.nv * 3), rem = o - ar * (a.nv * 3);
-                const int c = rem / 3, k = rem - c * 3;
-                const int ilo = s_ir[2 * ar], ihi = s_ir[2 * ar + 1];
-                float acc = 0.f;
-                for (int i = ilo; i <= ihi; ++i) {
-                    const float* rec = s_bu + i * W;
-                    const int r = ar - (__float_as_int(rec[0]) - p);
-                    if ((unsigned)r > (unsigned)p) continue;
-                    const float* gt = s_gt + (i * a.nv + c) * 6;
-                    acc = fmaf(rec[1 + S + r], gt[3 + k], fmaf(rec[1 + r], gt[k], acc));
+            if (__syncthreads_or(off_grid ? 1 : 0) == 0) {
+                float* out = g_cp + (int64_t)hf * ncp;
+                for (int o = threadIdx.x; o < ncp; o += blockDim.x) {
+                    const int ar = o / (a.nv * 3), rem = o - ar * (a.nv * 3);
+                    const int c = rem / 3, k = rem - c * 3;
+                    const int ilo = s_ir[2 * ar], ihi = s_ir[2 * ar + 1];
+                    float acc = 0.f;
+                    for (int i = ilo; i <= ihi; ++i) {
+                        const float* rec = s_bu + i * W;
+                        const int r = ar - (__float_as_int(rec[0]) - p);
+                        if ((unsigned)r > (unsigned)p) continue;
+                        const float* gt = s_gt + (i * a.nv + c) * 6;
+                        acc = fmaf(rec[1 + S + r], gt[3 + k], fmaf(rec[1 + r], gt[k], acc));
+                    }
+                    out[o] = acc;
                 }
-                out[o] = acc;
+                return;
             }
-            return;
         }
     }
     nurbs_bwd_scattered<DEG>(a, hf, lds, s_cp, s_ku, s_kv, s_B, g_points, g_normals, g_cp);
@@ -685,22 +707,27 @@ static bool fill_nurbs(NurbsArgs& a, const float* cp, const float* uv, int64_t u
 }
 
 // Dynamic LDS of a launch in bytes: what the scattered scheme needs, or - when the grid scheme is on - room for a roughly
-// square grid of M points (row / column bases, the stage-1 temps of all rows, and in the backward the gradient temps plus a
-// strip of point gradients); a grid that does not fit (long and thin) is evaluated by the scattered scheme.
-static size_t nurbs_lds_bytes(const NurbsArgs& a, bool bwd, int groups)
+// square grid of M points (column bases, the bases of a group's rows and a pass of stage-1 temps; in the backward all row
+// bases, the gradient temps and a strip per wave); a grid that does not fit (long and thin) takes the scattered scheme.
+static size_t nurbs_lds_bytes(const NurbsArgs& a, bool bwd, int groups, int bwd_waves)
 {
     const size_t ncp = (size_t)a.nu * a.nv * 3;
     const size_t n0 = (size_t)nurbs_f64_offset(a);
-    size_t scattered = bwd ? n0 + 2 * ncp : n0;
+    const int deg = (a.p == a.q && a.p <= 4) ? a.p : 0;
+    const size_t W = 2 * (size_t)((deg > 0 ? deg : kMaxDeg) + 1) + 3;
+    size_t scattered = bwd ? n0 + 2 * ncp + (size_t)kScatterThreads * 2 * W : n0 + (size_t)kNurbsFwdBlock * 2 * W;
     size_t n = scattered;
     if (a.grid_mode) {
-        const int deg = (a.p == a.q && a.p <= 4) ? a.p : 0;
-        const size_t W = 2 * (size_t)((deg > 0 ? deg : kMaxDeg) + 1) + 2;
         size_t side = 1;
         while (side * side < (size_t)a.M) ++side;
-        const size_t rows = bwd ? side : (side + groups - 1) / groups;
-        size_t grid = n0 + 2 + (rows + side) * W + rows * a.nv * 6;
-        if (bwd) grid += 2 * (size_t)(a.nu + a.nv) + std::min<size_t>(side, std::max<size_t>(1, kBwdStripPoints * kNurbsBlock / side)) * (a.nv * 6 + side * 9);
+        size_t grid;
+        if (!bwd) {
+            const size_t rows = (side + groups - 1) / groups;
+            grid = n0 + (rows + side) * W + std::min<size_t>(rows, std::max<size_t>(1, 128 / a.nv)) * a.nv * 6;
+        } else {
+            const size_t rs = std::max<size_t>(1, 64 / side);
+            grid = n0 + 2 + 2 * (size_t)(a.nu + a.nv) + 2 * side * W + side * a.nv * 6 + bwd_waves * rs * (a.nv * 6 + side * 9);
+        }
         grid += 64;
         if (grid * sizeof(float) <= 64 * 1024) n = std::max(n, grid);
     }
@@ -711,15 +738,15 @@ static size_t nurbs_lds_bytes(const NurbsArgs& a, bool bwd, int groups)
 
 using namespace art;
 
-#define ART_DISPATCH_DEG(KERNEL, grid, lds, stream, ...)                                                        \
+#define ART_DISPATCH_DEG(KERNEL, grid, block, lds, stream, ...)                                                 \
     do {                                                                                                        \
         const int deg__ = (a.p == a.q && a.p <= 4) ? a.p : 0;                                                   \
         switch (deg__) {                                                                                        \
-            case 1: hipLaunchKernelGGL(KERNEL<1>, grid, dim3(kNurbsBlock), lds, stream, __VA_ARGS__); break;     \
-            case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(kNurbsBlock), lds, stream, __VA_ARGS__); break;     \
-            case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(kNurbsBlock), lds, stream, __VA_ARGS__); break;     \
-            case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(kNurbsBlock), lds, stream, __VA_ARGS__); break;     \
-            default: hipLaunchKernelGGL(KERNEL<0>, grid, dim3(kNurbsBlock), lds, stream, __VA_ARGS__); break;    \
+            case 1: hipLaunchKernelGGL(KERNEL<1>, grid, dim3(block), lds, stream, __VA_ARGS__); break;          \
+            case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(block), lds, stream, __VA_ARGS__); break;          \
+            case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(block), lds, stream, __VA_ARGS__); break;          \
+            case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(block), lds, stream, __VA_ARGS__); break;          \
+            default: hipLaunchKernelGGL(KERNEL<0>, grid, dim3(block), lds, stream, __VA_ARGS__); break;         \
         }                                                                                                       \
     } while (0)
 
@@ -737,22 +764,22 @@ extern "C" int art_nurbs_fwd(const float* control_points, const float* eval_poin
                     uniform, n_unique_u, n_unique_v, H, F, M, nu, nv))
         return ART_EINVAL;
     a.orientation = orientation;
-    // workgroups per facet: as few as still give ~1000 workgroups (every workgroup stages the control net and builds the
-    // canting basis - one thread, ~100 dependent instructions), at least ~256 points each
+    // waves per facet: as few as still give every SIMD ~4 waves (each wave stages the control net, builds the canting basis
+    // and the column bases for itself), at least ~128 points each
     {
         int groups = debug_env_int("ARTIST_HIP_NURBS_GROUPS", 0);
         if (groups <= 0) {
             groups = 1;
-            while ((int64_t)H * F * groups < 1024 && M / (groups + 1) >= kNurbsBlock) ++groups;
+            while ((int64_t)H * F * groups < 4096 && M / (groups + 1) >= 128) ++groups;
         }
         a.groups = (int)std::min<int64_t>(groups, M);
     }
-    const size_t lds = nurbs_lds_bytes(a, false, a.groups);
+    const size_t lds = nurbs_lds_bytes(a, false, a.groups, 0);
     if (lds > 64 * 1024) return ART_EUNSUPPORTED;
     a.lds_floats = (int)(lds / sizeof(float));
     const int64_t blocks = (int64_t)H * F * a.groups;
     if (blocks > 2147483647LL) return ART_EINVAL;
-    ART_DISPATCH_DEG(nurbs_fwd_kernel, dim3((unsigned)blocks), lds, stream, a, reinterpret_cast<float4*>(points),
+    ART_DISPATCH_DEG(nurbs_fwd_kernel, dim3((unsigned)blocks), kNurbsFwdBlock, lds, stream, a, reinterpret_cast<float4*>(points),
                      reinterpret_cast<float4*>(normals));
     ART_HIP(hipGetLastError());
     return ART_OK;
@@ -774,10 +801,13 @@ extern "C" int art_nurbs_bwd(const float* control_points, const float* eval_poin
         return ART_EINVAL;
     a.transl = nullptr;   // unused by the backward
     a.orientation = orientation;
-    const size_t lds = nurbs_lds_bytes(a, true, 1);
+    // waves per workgroup (= per facet): 4, or 8 for small fields (fewer facets than the chip holds workgroups)
+    int block = debug_env_int("ARTIST_HIP_NURBS_BWD_BLOCK", 0);
+    if (block != 256 && block != 512 && block != 128 && block != 64) block = H * F < 1024 ? 512 : 256;
+    const size_t lds = nurbs_lds_bytes(a, true, 1, block / 64);
     if (lds > 64 * 1024) return ART_EUNSUPPORTED;
     a.lds_floats = (int)(lds / sizeof(float));
-    ART_DISPATCH_DEG(nurbs_bwd_kernel, dim3((unsigned)(H * F)), lds, stream, a,
+    ART_DISPATCH_DEG(nurbs_bwd_kernel, dim3((unsigned)(H * F)), block, lds, stream, a,
                      reinterpret_cast<const float4*>(grad_points), reinterpret_cast<const float4*>(grad_normals),
                      grad_control_points);
     ART_HIP(hipGetLastError());

@@ -1635,10 +1635,15 @@ def test_blocking_backward_with_facet_sized_items(monkeypatch):
     monkeypatch.setenv("ARTIST_HIP_DEBUG", "1")
     monkeypatch.setenv("ARTIST_HIP_BLOCK_LEAN", "0")
     flux_g, fac_g, go_g, gn_g, gpc_g = run()
-    np.testing.assert_array_equal(flux, flux_g)                                    # integer accumulators: same bits
+    assert rel_l2(flux, flux_g) < 1e-6          # (the lean and the generic ray body differ by the order of two products)
     assert np.linalg.norm(gpc_g) > 0 and rel_l2(gpc_hip, gpc_g) < 1e-5, rel_l2(gpc_hip, gpc_g)
     assert rel_l2(go_hip, go_g) < 1e-5 and rel_l2(gn_hip, gn_g) < 1e-5
-    sel = [0, 1, 17, 50, 99]                                # (0 and 1 have a free-standing panel in their beams)
+    # Oracle on a sample (1 has a free-standing panel in its beam, 50 is shaded by neighbours; heliostat 0, whose panel only
+    # grazes the beam, is left out: ONE of its 240 000 rays lands in the neighbouring pixel cell in one implementation and
+    # not in the other - measured flux 3.9e-5, gradient 6e-3 from a single point, every other point at 1e-7 - the fp32
+    # discontinuity DESIGN.md section 3 describes).  The rectangles are the whole field's; the reference's filter keeps only
+    # those that some ray of the BATCH can meet (blocking.py:832-995), so the third factor of a sample is not the field's.
+    sel = [1, 3, 17, 50, 64]
     sub = lambda x: f32(x[sel])
     oracle_args = (sub(sc["origins"]), sub(sc["normals"]), sub(sc["incident"]), sub(sc["both"][..., 0]), sub(sc["both"][..., 1]),
                    sub(tix), f32(sc["planes"]["centers"]), f32(sc["planes"]["normals"]), f32(sc["planes"]["dims"]), res)
@@ -1646,6 +1651,7 @@ def test_blocking_backward_with_facet_sized_items(monkeypatch):
     o_flux, o_fac = oracle.trace_fwd(*oracle_args, 0.7, 0.05, 0.9, **okw)[:2]
     assert o_flux.sum() > 0 and (fac[2][sel] < 1).any()
     assert rel_l2(flux[sel], o_flux) < 1e-5, rel_l2(flux[sel], o_flux)
+    np.testing.assert_array_equal(fac[:2][:, sel], o_fac[:2])
     go, gn = oracle.trace_bwd(*oracle_args, f32(w[sel]), 0.7, 0.05, 0.9, **okw)[:2]
     assert rel_l2(go_hip[sel], go) < 2e-5, rel_l2(go_hip[sel], go)
     assert rel_l2(gn_hip[sel], gn) < 2e-5, rel_l2(gn_hip[sel], gn)
@@ -2117,6 +2123,40 @@ def test_flux_is_bit_reproducible(golden, name):
         assert np.abs(g0[2]).sum() > 0 and np.abs(g0[4]).sum() > 0           # the rectangles do receive gradients
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("name", STAGE_CASES)
+def test_control_point_gradient_is_bit_reproducible(golden, name, fused):
+    """... and on through nurbs_bwd_kernel to the tensor a surface reconstruction trains: control points -> NURBS (tensor-product
+    scheme: every gradient element has one owner that adds in index order) -> alignment (separate kernel or fused into the
+    evaluation) -> trace -> loss gives the same control-point gradient bits on every run (round 3 summed the control-point
+    gradients with LDS atomics, in whatever order the lanes arrived)."""
+    from artist_amd import NURBSSurfaces, align_surfaces, trace_rays
+    d = golden(name)
+    ori = t(d["orientation"])
+    H = ori.shape[0]
+    args = (t(d["eval_points"]), t(d["canting"]), t(d["facet_translations"]))
+
+    def grad():
+        cp = t(d["control_points"]).requires_grad_(True)
+        surf = NURBSSurfaces(torch.from_numpy(d["degrees"]), cp, device=DEV)
+        if fused:
+            ap, an = surf.calculate_surface_points_and_normals(*args, orientations=ori)
+            ap, an = ap.reshape(H, -1, 4), an.reshape(H, -1, 4)
+        else:
+            pts, nrm = surf(*args)
+            ap, an = align_surfaces(pts.reshape(H, -1, 4), nrm.reshape(H, -1, 4), ori)
+        inp = trace_inputs(d)
+        inp.update(origins=ap, normals=an)
+        flux, _ = trace_rays(**inp)
+        (flux * t(d["loss_weights"])).sum().backward()
+        return n(cp.grad)
+
+    g0, g1, g2 = grad(), grad(), grad()
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_array_equal(g0, g2)
+    assert np.isfinite(g0).all() and (name == "small_offtarget" or np.abs(g0).sum() > 0)
+
+
 def test_kinematics_reconstruction_loop_converges():
     """Acceptance run in the shape of tutorials/04 (kinematics reconstruction through ray tracing), entirely on
     artist_amd: scenario file -> measured flux with the true parameters -> perturbed deviation and actuator parameters
@@ -2220,19 +2260,37 @@ def test_surface_reconstruction_loop_converges():
     true_cp = group.active_nurbs_control_points
     with torch.no_grad():
         measured = flux_of(true_cp).clone()
-    cp = true_cp.clone()
-    cp[..., 2] = 0.0                                        # the model starts from ideal (flat) facets
-    cp.requires_grad_(True)
-    optimizer = torch.optim.Adam([cp], lr=2e-5)
     loss_fn = PixelLoss()
-    history = []
-    for _ in range(150):
-        optimizer.zero_grad()
-        loss = loss_fn(flux_of(cp), measured, reduction_dimensions=(1, 2)).sum()
-        loss.backward()
-        optimizer.step()
-        history.append(float(loss))
+
+    def reconstruct(make_optimizer, epochs=150):
+        cp = true_cp.clone()
+        cp[..., 2] = 0.0                                    # the model starts from ideal (flat) facets
+        cp.requires_grad_(True)
+        optimizer = make_optimizer(cp)
+        history = []
+        for _ in range(epochs):
+            optimizer.zero_grad()
+            loss = loss_fn(flux_of(cp), measured, reduction_dimensions=(1, 2)).sum()
+            loss.backward()
+            optimizer.step()
+            history.append(float(loss))
+        return history, n(cp)
+
+    history, cp_end = reconstruct(lambda cp: torch.optim.Adam([cp], lr=2e-5))
     assert min(history[-5:]) < 0.3 * history[0], (history[0], history[-5:])
+    # the whole loop retraces itself: same loss history, same control points, bit for bit (flux through integer accumulators,
+    # trace gradients through plain stores, control-point gradients through ordered sums, crop + loss through fixed trees)
+    history2, cp_end2 = reconstruct(lambda cp: torch.optim.Adam([cp], lr=2e-5))
+    assert history == history2
+    np.testing.assert_array_equal(cp_end, cp_end2)
+    # ... and with the optimiser step on the HIP kernel (artist_amd.optim.Adam): the same trajectory up to the rounding of the
+    # update (tests/test_gpu_optim.py), and as reproducible
+    from artist_amd.optim import Adam
+    history3, cp_end3 = reconstruct(lambda cp: Adam([cp], lr=2e-5), epochs=60)
+    history4, cp_end4 = reconstruct(lambda cp: Adam([cp], lr=2e-5), epochs=60)
+    assert history3 == history4
+    np.testing.assert_array_equal(cp_end3, cp_end4)
+    np.testing.assert_allclose(history3[:20], history[:20], rtol=1e-3)
 
 
 def test_aim_point_optimisation_loop_converges():
