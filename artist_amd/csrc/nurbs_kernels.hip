@@ -213,11 +213,8 @@ __device__ __forceinline__ void finish_point(const NurbsArgs& a, const float* S0
 
 // The adjoint of finish_point for one evaluation point: dL/dS (position), dL/dSu, dL/dSv from the two incoming gradients.
 __device__ __forceinline__ void point_adjoint(const NurbsArgs& a, float w, const float* Su, const float* Sv, const float* s_B,
-                                              int hf, int h, int m, const float4* __restrict__ g_points,
-                                              const float4* __restrict__ g_normals, float* gS, float* gSu, float* gSv)
+                                              int h, float4 gp, float4 gn, float* gS, float* gSu, float* gSv)
 {
-    float4 gp = g_points[(int64_t)hf * a.M + m];
-    float4 gn = g_normals[(int64_t)hf * a.M + m];
     if (a.orientation) {      // align_bwd_kernel's arithmetic
         const float* Mo = a.orientation + (int64_t)h * 16;
         gp = apply_m(gp, Mo);
@@ -255,13 +252,14 @@ __device__ __forceinline__ void point_adjoint(const NurbsArgs& a, float w, const
 
 // ---- tensor-product scheme: grid discovery, row / column bases, stage 1 ----------------------------------------------
 
-// Writes of one wave to LDS become visible to its other lanes (the LDS unit executes a wave's instructions in order; this
-// keeps the compiler from moving them across).  No hardware barrier: the waves of a workgroup work independently.
+// Writes of one wave to LDS become visible to its other lanes: the LDS unit executes a wave's instructions in order, so all it
+// takes is to wait for the wave's own LDS operations and to keep the compiler from moving memory accesses across this point.
+// No hardware barrier - the waves of a workgroup work independently - and no wait for outstanding GLOBAL loads (a
+// wavefront-scope fence made the compiler wait for those as well, which serialised the prefetch of the next strip).
 __device__ __forceinline__ void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Row length of a cartesian point list m = i Mv + j at (u_i, v_j): the index of the first point whose u differs from
@@ -364,9 +362,8 @@ __device__ __forceinline__ void eval_from_records(const NurbsArgs& a, const floa
     const int p = DEG > 0 ? DEG : a.p, q = DEG > 0 ? DEG : a.q;
     const int su = __float_as_int(recu[0]), sv = __float_as_int(recv[0]);
     float d0[4] = {0.f, 0.f, 0.f, 0.f}, du[3] = {0.f, 0.f, 0.f}, dv[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (s > q) break;
+#pragma unroll 1      // (the rare scheme: keep its register footprint below the tensor-product scheme's)
+    for (int s = 0; s <= q; ++s) {
         float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < S; ++r) {
@@ -509,7 +506,7 @@ __device__ __forceinline__ void nurbs_bwd_scattered(const NurbsArgs& a, int hf, 
             line_basis<DEG>(a, xy.y, s_kv, a.nv, q, a.n_unique_v, recv);
             float S0[4], Su[3], Sv[3], gS[3], gSu[3], gSv[3];
             eval_from_records<DEG>(a, s_cp, recu, recv, S0, Su, Sv);
-            point_adjoint(a, S0[3], Su, Sv, s_B, hf, h, m, g_points, g_normals, gS, gSu, gSv);
+            point_adjoint(a, S0[3], Su, Sv, s_B, h, g_points[(int64_t)hf * a.M + m], g_normals[(int64_t)hf * a.M + m], gS, gSu, gSv);
             const int su = __float_as_int(recu[0]), sv = __float_as_int(recv[0]);
 #pragma unroll 1
             for (int r = 0; r <= p; ++r) {
@@ -597,20 +594,38 @@ __global__ __launch_bounds__(kNurbsBwdBlock) void nurbs_bwd_kernel(NurbsArgs a, 
             const float inv_mv = 1.0f / (float)Mv;
             const int n_strips = (Mu + rs - 1) / rs;
             bool off_grid = false;
+            // a strip is at most one lane-step of points when a row has at most 64 of them: then the NEXT strip's gradients and
+            // coordinates are requested before this strip is worked on (their latency would otherwise be exposed once per strip)
+            const bool one_step = rs * Mv <= 64;
+            const float4* __restrict__ gpf = g_points + (int64_t)hf * a.M;
+            const float4* __restrict__ gnf = g_normals + (int64_t)hf * a.M;
+            float4 gp_next = make_float4(0.f, 0.f, 0.f, 0.f), gn_next = gp_next;
+            float2 x_next = make_float2(0.f, 0.f);
+            if (one_step && wave < n_strips) {
+                const int m = wave * rs * Mv + lane;
+                if (lane < min(rs, Mu - wave * rs) * Mv) { gp_next = gpf[m]; gn_next = gnf[m]; x_next = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m); }
+            }
             for (int strip = wave; strip < n_strips; strip += nwaves) {
                 const int r0 = strip * rs, rows = min(rs, Mu - r0);
+                const float4 gp_now = gp_next, gn_now = gn_next;
+                const float2 x_now = x_next;
+                if (one_step && strip + nwaves < n_strips) {
+                    const int r0n = (strip + nwaves) * rs;
+                    const int m = r0n * Mv + lane;
+                    if (lane < min(rs, Mu - r0n) * Mv) { gp_next = gpf[m]; gn_next = gnf[m]; x_next = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m); }
+                }
                 stage1_rows<DEG>(a, s_cp, s_bu, 0, r0, rows, s_temp, lane, 64);
                 wave_sync();
                 for (int idx = lane; idx < rows * Mv; idx += 64) {
                     const int il = (int)(((float)idx + 0.5f) * inv_mv), j = idx - il * Mv;
                     const float* recu = s_bu + (r0 + il) * W;
                     const float* recv = s_bv + j * W;
-                    const int m = (r0 + il) * Mv + j;
-                    const float2 x = *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
+                    const int m = r0 * Mv + idx;
+                    const float2 x = one_step ? x_now : *reinterpret_cast<const float2*>(uvp + 2 * (int64_t)m);
                     off_grid |= !(x.x == recu[W - 1]) || !(x.y == recv[W - 1]);
                     float S0[4], Su[3], Sv[3], gS[3], gSu[3], gSv[3];
                     stage2_point<DEG>(a, s_temp + il * a.nv * 6, recv, recu[W - 2], S0, Su, Sv);
-                    point_adjoint(a, S0[3], Su, Sv, s_B, hf, h, m, g_points, g_normals, gS, gSu, gSv);
+                    point_adjoint(a, S0[3], Su, Sv, s_B, h, one_step ? gp_now : gpf[m], one_step ? gn_now : gnf[m], gS, gSu, gSv);
                     float* o = s_pg + idx * 9;
                     o[0] = gS[0]; o[1] = gS[1]; o[2] = gS[2]; o[3] = gSu[0]; o[4] = gSu[1]; o[5] = gSu[2];
                     o[6] = gSv[0]; o[7] = gSv[1]; o[8] = gSv[2];

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 tag=$1
-timeout -k 10 600 python -m pytest tests -m gpu -x -q --tb=short --timeout 240 -k "facet_sized" > gpurun_out/${tag}_tests.log 2>&1
+timeout -k 10 600 python -m pytest tests -m gpu -x -q --tb=short --timeout 240 -k "nurbs or control_point or facet_sized" > gpurun_out/${tag}_tests.log 2>&1
 grep -E "FAILED|ERROR|Timeout| passed| failed|^E  " gpurun_out/${tag}_tests.log | cut -c1-300 | tail -12
 timeout -k 10 300 python tools/nurbs_bench.py 1000 125 2> gpurun_out/${tag}_nurbs_bench.err | tail -1 > gpurun_out/${tag}_nurbs_bench.json
 python - <<PY
