@@ -43,6 +43,29 @@ __device__ __forceinline__ double block_sum(double v, double* s_red)
     return r;
 }
 
+// N sums at once, each with block_sum's tree (xor-shuffle inside a wave, then the waves in order): one pair of barriers for
+// all of them.  s_red: 16 * N doubles.
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double* s_red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < N; ++k) s_red[wave * N + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double r = 0.0;
+        for (int w = 0; w < nw; ++w) r += s_red[w * N + k];
+        v[k] = r;
+    }
+}
+
 struct CropMap {       // pixel j of the output samples input coordinate ix(j); same arithmetic in every kernel
     float sx, sy, xc, yc;
     int W, Hh;
@@ -227,7 +250,7 @@ __device__ __forceinline__ float gather_rows(const CropMap& m, const float* __re
 // Gradient of one INPUT pixel (x, y): direct part = sum over the output pixels that sampled it (the map is separable
 // and monotone, so they form a small index rectangle), plus the part through the centre of mass.  General form, any
 // crop scale; the tiled kernel below uses it for bitmaps whose scale needs more than four taps per axis.
-__device__ __forceinline__ float crop_bwd_pixel(const CropMap& m, const float* __restrict__ g, const float* __restrict__ com,
+__device__ __forceinline__ float crop_bwd_pixel(const CropMap& m, const float* __restrict__ g, float S,
                                                 const float* __restrict__ gcom, int b, int Hh, int W, int x, int y)
 {
     // ix(j) = sx (j - (W-1)/2) + (xc + 1)(W-1)/2 up to rounding (<< 1e-3 pixel for bitmaps up to 32768 wide):
@@ -258,7 +281,6 @@ __device__ __forceinline__ float crop_bwd_pixel(const CropMap& m, const float* _
             acc += row * wy;
         }
     }
-    const float S = com[3 * b + 2];
     return acc + gcom[2 * b] * (lin11(x, W) - m.xc) / S + gcom[2 * b + 1] * (lin11(y, Hh) - m.yc) / S;
 }
 
@@ -294,11 +316,19 @@ __device__ __forceinline__ void tap_range(float scale, float centre, int n, int 
 #define ART_CROP_ROW_UNROLL 4
 #endif
 constexpr int kTileX = 64, kTileY = ART_CROP_TILE_Y, kTaps = 4, kTileRows = ART_CROP_TILE_ROWS, kRowUnroll = ART_CROP_ROW_UNROLL;
+// LOSS = true: the fused crop + PixelLoss adjoint.  grad_out is then the RESIDUAL crop - truth that the forward pass kept, gcom
+// the gradient of the two centre coordinates per unit of 2 gl / sum(truth), and the whole pixel is scaled by that factor at
+// the end (everything here is linear in it): dL/dflux in ONE pass over the residual - no second sampling of the crop, no
+// dL/dcrop written and read back (round 3: two kernels, 188 + 297 us at 1000 bitmaps).  com is then the forward's record
+// [B,4] = (x centre, y centre, sum + 1e-8, sum of the measured flux).
+template <bool LOSS>
 __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* __restrict__ dims, const float* __restrict__ com,
                                                                   const float* __restrict__ gcom,
                                                                   const float* __restrict__ grad_out, int Hh, int W,
-                                                                  float crop_w, float crop_h, float* __restrict__ grad_flux)
+                                                                  float crop_w, float crop_h, float* __restrict__ grad_flux,
+                                                                  const float* __restrict__ grad_loss)
 {
+    constexpr int CS = LOSS ? 4 : 3;                 // stride of the centre record
     __shared__ int s_j0[kTileX], s_i0[kTileY];
     __shared__ float s_wx[kTileX][kTaps], s_wy[kTileY][kTaps];
     __shared__ float s_t[kTileRows][kTileX];        // horizontal pass: T[i][x] = sum_q wx[x][q] g[i][j0(x) + q]
@@ -306,7 +336,11 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     __shared__ float s_gy[kTileY];                   // the row's share of the centre-of-mass term (one division per row, not per pixel)
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * kTileX, y0 = blockIdx.y * kTileY;
-    const CropMap m = make_map(dims, com, b, W, Hh, crop_w, crop_h);
+    CropMap m;
+    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
+    m.xc = com[CS * b]; m.yc = com[CS * b + 1]; m.W = W; m.Hh = Hh;
+    const float S = com[CS * b + 2];
+    const float scale = LOSS ? (grad_loss[b] * 2.0f) / com[CS * b + 3] : 1.0f;
     if (threadIdx.x == 0) { s_wide = 0; s_ilo = 0x7fffffff; s_ihi = -1; }
     __syncthreads();
     if (threadIdx.x < kTileX + kTileY) {
@@ -323,7 +357,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
             (col ? s_wx[t] : s_wy[t])[q] = o <= hi_i ? tap(col ? m.ix(o) : m.iy(o), p) : 0.0f;
         }
         if (!col && hi_i >= lo_i) { atomicMin(&s_ilo, lo_i); atomicMax(&s_ihi, hi_i); }
-        if (!col) s_gy[t] = gcom[2 * b + 1] * (lin11(p, Hh) - m.yc) / com[3 * b + 2];
+        if (!col) s_gy[t] = gcom[2 * b + 1] * (lin11(p, Hh) - m.yc) / S;
     }
     __syncthreads();
     const int ilo = s_ilo, ihi = s_ihi;
@@ -331,7 +365,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     if (s_wide || ihi - ilo >= kTileRows) {    // strong magnification: per-pixel form for this tile
         for (int k = threadIdx.x; k < kTileX * kTileY; k += 256) {
             const int x = x0 + (k & (kTileX - 1)), y = y0 + k / kTileX;
-            if (x < W && y < Hh) grad_flux[((int64_t)b * Hh + y) * W + x] = crop_bwd_pixel(m, g, com, gcom, b, Hh, W, x, y);
+            if (x < W && y < Hh) grad_flux[((int64_t)b * Hh + y) * W + x] = scale * crop_bwd_pixel(m, g, S, gcom, b, Hh, W, x, y);
         }
         return;
     }
@@ -362,7 +396,6 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     }
     __syncthreads();
     if (!in_x) return;
-    const float S = com[3 * b + 2];
     const float gx = gcom[2 * b] * (lin11(x, W) - m.xc) / S;
     for (int ty = threadIdx.x / kTileX; ty < kTileY; ty += 256 / kTileX) {
         const int y = y0 + ty;
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
             if (wy != 0.0f) acc += s_t[r0 + a][tx] * wy;      // uniform across the 64 lanes of a row
         }
         acc += gx + s_gy[ty];
-        grad_flux[((int64_t)b * Hh + y) * W + x] = acc;
+        grad_flux[((int64_t)b * Hh + y) * W + x] = LOSS ? scale * acc : acc;
     }
 }
 
@@ -450,16 +483,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_loss_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Fused epilogue of a reconstruction epoch: crop around the centre of mass + PixelLoss, one workgroup per bitmap.
-//   forward   centre of mass (one streaming pass) -> every output pixel of the crop is sampled (four gathers that hit
-//             L2: the workgroup has just read the bitmap) and compared with the measured flux on the fly; the cropped
-//             bitmap never goes to HBM.  Traffic: the bitmap and the measured flux once each (the separate kernels:
-//             bitmap twice, cropped bitmap written and read, measured flux once).
-//   backward  one pass re-samples the crop, forms dL/dcrop = gl 2 (crop - truth) / sum(truth), writes it for the
-//             tiled gather below and accumulates the gradient of the two centre coordinates in the same loop;
-//             flux_crop_bwd_tiled_kernel then turns it into dL/dflux as before.
-// Same arithmetic as flux_com_kernel / flux_crop_fwd_kernel / flux_loss_kernel / flux_crop_bwd_com_kernel: results
-// are bit-identical to the separate calls (tests/test_gpu_parity.py::test_fused_crop_pixel_loss).
+// Sampling helpers of the fused crop + loss kernels (the arithmetic of flux_crop_fwd_kernel, tap for tap).
 // ---------------------------------------------------------------------------------------------------
 struct CropTap { int x0, y0; float tx, ty; bool xa, xb, ya, yb; };
 __device__ __forceinline__ float crop_sample(const float* __restrict__ f, const CropMap& m, int i, int j, float& v00, float& v01,
@@ -514,159 +538,26 @@ __device__ __forceinline__ float crop_sample_col(const float* __restrict__ f, co
     return acc;
 }
 
-// com4[b] = (x centre, y centre, sum + 1e-8, sum of the measured flux)
-__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(const float* __restrict__ flux,
-                                                                               const float* __restrict__ dims,
-                                                                               const float* __restrict__ truth, int Hh, int W,
-                                                                               float crop_w, float crop_h, float* __restrict__ loss,
-                                                                               float* __restrict__ com4)
-{
-    __shared__ double s_red[16];
-    __shared__ float s_com[3];
-    const int b = blockIdx.x;
-    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
-    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
-    {   // centre of mass: flux_com_kernel's loop
-        double s = 0.0, xs = 0.0, ys = 0.0;
-        if ((W & 3) == 0) {
-            const int W4 = W >> 2;
-            int x4 = threadIdx.x % W4, y = threadIdx.x / W4;
-            const int dx = blockDim.x % W4, dy = blockDim.x / W4;
-            const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f);
-#pragma unroll ART_COM_UNROLL
-            for (int k = threadIdx.x; k < Hh * W4; k += blockDim.x) {
-                const float4 v = f4[k];
-                const int x = 4 * x4;
-                s += (double)((v.x + v.y) + (v.z + v.w));
-                xs += (double)((lin11(x, W) * v.x + lin11(x + 1, W) * v.y) + (lin11(x + 2, W) * v.z + lin11(x + 3, W) * v.w));
-                ys += (double)(lin11(y, Hh) * ((v.x + v.y) + (v.z + v.w)));
-                x4 += dx; y += dy;
-                if (x4 >= W4) { x4 -= W4; ++y; }
-            }
-        } else {
-            int x = threadIdx.x % W, y = threadIdx.x / W;
-            const int dx = blockDim.x % W, dy = blockDim.x / W;
-            for (int k = threadIdx.x; k < Hh * W; k += blockDim.x) {
-                const float v = f[k];
-                s += (double)v; xs += (double)(lin11(x, W) * v); ys += (double)(lin11(y, Hh) * v);
-                x += dx; y += dy;
-                if (x >= W) { x -= W; ++y; }
-            }
-        }
-        s = block_sum(s, s_red); xs = block_sum(xs, s_red); ys = block_sum(ys, s_red);
-        if (threadIdx.x == 0) {
-            const float S = (float)s + 1e-8f;
-            s_com[0] = (float)(xs / (double)S); s_com[1] = (float)(ys / (double)S); s_com[2] = S;
-        }
-        __syncthreads();
-    }
-    CropMap m;
-    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
-    m.xc = s_com[0]; m.yc = s_com[1]; m.W = W; m.Hh = Hh;
-    double se = 0.0, sg = 0.0;
-    const int npx = Hh * W;
-    if ((int)blockDim.x % W == 0) {                 // a thread owns one column (the per-thread summation order is unchanged)
-        const int j = threadIdx.x % W, di = blockDim.x / W;
-        const CropColumn col = crop_column(m, j);
-#pragma unroll ART_CROP_UNROLL      // four rows' taps in flight: the loop is a chain of L2 round trips otherwise
-        for (int i = threadIdx.x / W; i < Hh; i += di) {
-            float v00, v01, v10, v11, ty;
-            const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
-            const float t = g[i * W + j];
-            const float d = c - t;
-            se += (double)(d * d); sg += (double)t;
-        }
-    } else
-    for (int k = threadIdx.x; k < npx; k += blockDim.x) {
-        const int i = k / W, j = k - i * W;
-        float v00, v01, v10, v11, tx, ty;
-        const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
-        const float t = g[k];
-        const float d = c - t;
-        se += (double)(d * d); sg += (double)t;
-    }
-    se = block_sum(se, s_red);
-    const float sgf = (float)block_sum(sg, s_red);
-    if (threadIdx.x == 0) {
-        loss[b] = (float)se / sgf;                              // loss.py:312-318
-        com4[4 * b] = s_com[0]; com4[4 * b + 1] = s_com[1]; com4[4 * b + 2] = s_com[2]; com4[4 * b + 3] = sgf;
-    }
-}
-
-// grad_crop[b] = gl[b] 2 (crop - truth) / sum(truth) (written), gcom[b] = its gradient w.r.t. the two centre coordinates
-__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_bwd_kernel(const float* __restrict__ flux,
-                                                                               const float* __restrict__ dims,
-                                                                               const float* __restrict__ truth,
-                                                                               const float* __restrict__ com4,
-                                                                               const float* __restrict__ grad_loss, int Hh, int W,
-                                                                               float crop_w, float crop_h,
-                                                                               float* __restrict__ grad_crop, float* __restrict__ com3,
-                                                                               float* __restrict__ gcom)
-{
-    __shared__ double s_red[16];
-    const int b = blockIdx.x;
-    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
-    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
-    float* __restrict__ gc = grad_crop + (int64_t)b * Hh * W;
-    CropMap m;
-    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
-    m.xc = com4[4 * b]; m.yc = com4[4 * b + 1]; m.W = W; m.Hh = Hh;
-    const float sgf = com4[4 * b + 3], gl = grad_loss[b];
-    double gx = 0.0, gy = 0.0;
-    const int npx = Hh * W;
-    if ((int)blockDim.x % W == 0) {
-        const int j = threadIdx.x % W, di = blockDim.x / W;
-        const CropColumn col = crop_column(m, j);
-#pragma unroll ART_CROP_UNROLL
-        for (int i = threadIdx.x / W; i < Hh; i += di) {
-            float v00, v01, v10, v11, ty;
-            const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
-            const int k = i * W + j;
-            const float go = gl * (2.0f * (c - g[k])) / sgf;
-            gc[k] = go;
-            gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
-            gy += (double)(go * ((v10 - v00) * (1.0f - col.tx) + (v11 - v01) * col.tx));
-        }
-    } else
-    for (int k = threadIdx.x; k < npx; k += blockDim.x) {
-        const int i = k / W, j = k - i * W;
-        float v00, v01, v10, v11, tx, ty;
-        const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
-        const float go = gl * (2.0f * (c - g[k])) / sgf;          // flux_loss_kernel's gradient
-        gc[k] = go;
-        gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));     // flux_crop_bwd_com_kernel
-        gy += (double)(go * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
-    }
-    gx = block_sum(gx, s_red);
-    gy = block_sum(gy, s_red);
-    if (threadIdx.x == 0) {
-        gcom[2 * b] = (float)(gx * (double)((float)(W - 1) / 2.0f));
-        gcom[2 * b + 1] = (float)(gy * (double)((float)(Hh - 1) / 2.0f));
-        com3[3 * b] = m.xc; com3[3 * b + 1] = m.yc; com3[3 * b + 2] = com4[4 * b + 2];     // the layout the tiled kernel reads
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// The fused crop + PixelLoss pair for SMALL batches (one of eight ranks' share of a field: 125 bitmaps on 256 CUs).  One
-// workgroup per bitmap leaves half of the chip idle (42 + 84 us at 125 bitmaps, 40 + 71 at 64).  Here a bitmap's rows are cut
-// into kLossParts = 4 parts and up to four workgroups - as many as still have a CU each - share a bitmap:
-//   flux_com_parts_kernel          grid (P, B): the centre-of-mass sums of each part -> parts[b][v][0..2] (fp64)
-//   flux_crop_pixel_loss_parts_fwd grid (P, B): every workgroup adds the four parts in part order (the same centre in all of
-//                                  them), crops and compares its parts' rows, leaves (sum d^2, sum truth) per part
-//   ..._fwd_final                  one thread per bitmap: the parts in part order -> loss, the record for the backward pass
-//   flux_crop_pixel_loss_parts_bwd grid (P, B): the loss gradient's rows of the cropped gradient and, per part, the sums of the
-//                                  gradient of the centre;  ..._bwd_final: one thread per bitmap adds them.
-// (Kernel boundaries carry the parts from one step to the next.  A "last workgroup adds the parts" ticket was built first: its
-//  device-scope fences write back and invalidate the L2 of every XCD - 0.24 instead of 0.04 ms at 125 bitmaps.)
-// Sums are fixed functions of the data (per-thread order, block tree, parts in order): reproducible from run to run, and the
-// same for P = 1, 2, 4.  They differ from the one-workgroup kernels above in the LAST BITS of the fp64 sums (rows are
-// grouped by part), which is below fp32 output precision except for an occasional last-bit flip
-// (tests/test_gpu_parity.py::test_fused_crop_pixel_loss asserts 1e-6 for this path and identical bits for the other).
-// Scratch: the parts, per (device, stream), allocated by the library on first use (flux_parts_scratch).
+// The fused crop + PixelLoss pair.  A bitmap's rows are ALWAYS summed in kLossParts = 4 parts, whatever the batch size: the
+// parts' fp64 sums (per-thread order, block tree) are added in part order, so the loss, the centre and the gradient are the
+// same bits whether a bitmap has one workgroup (large batches: all four parts in one workgroup, one launch) or two / four
+// (small batches - one of eight ranks' 125 bitmaps on 256 CUs; as many workgroups as still have a CU each, the parts
+// carried from kernel to kernel through a small scratch).  Round 3's one-workgroup kernels summed all rows in one go and
+// differed from the part kernels in the last bits: the same data gave another loss at another batch size (advisor).
+//   flux_com_parts_kernel           grid (P, B): the centre-of-mass sums of each part -> parts[b][v][0..2]       (P > 1 only)
+//   flux_crop_pixel_loss_fwd_kernel grid (P, B): [P == 1: the same sums first, in the workgroup] the four parts in part order
+//                                   -> the centre; crops and compares its parts' rows; per part (sum d^2, sum truth) and -
+//                                   when a backward pass will follow - the RESIDUAL d = crop - truth [B,Hh,W] and the two
+//                                   sums that make the gradient of the centre; [P == 1: loss and records written here]
+//   flux_crop_pixel_loss_final_kernel  one thread per bitmap adds the parts                                      (P > 1 only)
+//   backward                        flux_crop_bwd_tiled_kernel<true>: ONE pass over the residual (see there)
+// (A "last workgroup adds the parts" ticket was built first: its device-scope fences write back and invalidate the L2 of
+//  every XCD - 0.24 instead of 0.04 ms at 125 bitmaps.  Kernel boundaries carry the parts instead.)
 // ---------------------------------------------------------------------------------------------------
 constexpr int kLossParts = 4;
 constexpr int kMaxPartBitmaps = 512;
-struct PartScratch { double com[kMaxPartBitmaps][kLossParts][3]; double acc[kMaxPartBitmaps][kLossParts][2]; };
+struct PartScratch { double com[kMaxPartBitmaps][kLossParts][3]; double acc[kMaxPartBitmaps][kLossParts][4]; };
 
 __device__ __forceinline__ void part_rows(int Hh, int v, int& r0, int& r1)
 {
@@ -674,79 +565,143 @@ __device__ __forceinline__ void part_rows(int Hh, int v, int& r0, int& r1)
     r1 = (int)(((int64_t)Hh * (v + 1)) / kLossParts);
 }
 
+// (sum f, sum x f, sum y f) over the rows of part v of one bitmap, x / y in normalised coordinates; block-wide result
+__device__ __forceinline__ void com_part_sums(const float* __restrict__ f, int Hh, int W, int v, double* s_red, double& s, double& xs, double& ys)
+{
+    int r0, r1;
+    part_rows(Hh, v, r0, r1);
+    double a[3] = {0.0, 0.0, 0.0};
+    if ((W & 3) == 0) {
+        const int W4 = W >> 2;
+        const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f) + (int64_t)r0 * W4;
+        const int n = (r1 - r0) * W4;
+        int x4 = threadIdx.x % W4, y = r0 + threadIdx.x / W4;              // (no division in the loop)
+        const int dx = blockDim.x % W4, dy = blockDim.x / W4;
+#pragma unroll 4
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const float4 q = f4[k];
+            const int x = 4 * x4;
+            a[0] += (double)((q.x + q.y) + (q.z + q.w));
+            a[1] += (double)((lin11(x, W) * q.x + lin11(x + 1, W) * q.y) + (lin11(x + 2, W) * q.z + lin11(x + 3, W) * q.w));
+            a[2] += (double)(lin11(y, Hh) * ((q.x + q.y) + (q.z + q.w)));
+            x4 += dx; y += dy;
+            if (x4 >= W4) { x4 -= W4; ++y; }
+        }
+    } else {
+        const int n = (r1 - r0) * W;
+        int x = threadIdx.x % W, y = r0 + threadIdx.x / W;
+        const int dx = blockDim.x % W, dy = blockDim.x / W;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const float q = f[(int64_t)r0 * W + k];
+            a[0] += (double)q; a[1] += (double)(lin11(x, W) * q); a[2] += (double)(lin11(y, Hh) * q);
+            x += dx; y += dy;
+            if (x >= W) { x -= W; ++y; }
+        }
+    }
+    block_sum_n<3>(a, s_red);
+    s = a[0]; xs = a[1]; ys = a[2];
+}
+
 __global__ __launch_bounds__(kReduceBlock) void flux_com_parts_kernel(const float* __restrict__ flux, int Hh, int W, int parts_per_wg,
                                                                     PartScratch* __restrict__ ws)
 {
-    __shared__ double s_red[16];
+    __shared__ double s_red[16 * 4];
     const int b = blockIdx.y;
     const float* __restrict__ f = flux + (int64_t)b * Hh * W;
     for (int v = blockIdx.x * parts_per_wg; v < (int)(blockIdx.x + 1) * parts_per_wg; ++v) {
-        int r0, r1;
-        part_rows(Hh, v, r0, r1);
-        double s = 0.0, xs = 0.0, ys = 0.0;
-        if ((W & 3) == 0) {
-            const int W4 = W >> 2;
-            const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f) + (int64_t)r0 * W4;
-            const int n = (r1 - r0) * W4;
-#pragma unroll 4
-            for (int k = threadIdx.x; k < n; k += blockDim.x) {
-                const float4 q = f4[k];
-                const int y = r0 + k / W4, x = 4 * (k % W4);
-                s += (double)((q.x + q.y) + (q.z + q.w));
-                xs += (double)((lin11(x, W) * q.x + lin11(x + 1, W) * q.y) + (lin11(x + 2, W) * q.z + lin11(x + 3, W) * q.w));
-                ys += (double)(lin11(y, Hh) * ((q.x + q.y) + (q.z + q.w)));
-            }
-        } else {
-            const int n = (r1 - r0) * W;
-            for (int k = threadIdx.x; k < n; k += blockDim.x) {
-                const float q = f[(int64_t)r0 * W + k];
-                const int y = r0 + k / W, x = k % W;
-                s += (double)q; xs += (double)(lin11(x, W) * q); ys += (double)(lin11(y, Hh) * q);
-            }
-        }
-        s = block_sum(s, s_red); xs = block_sum(xs, s_red); ys = block_sum(ys, s_red);
+        double s, xs, ys;
+        com_part_sums(f, Hh, W, v, s_red, s, xs, ys);
         if (threadIdx.x == 0) { ws->com[b][v][0] = s; ws->com[b][v][1] = xs; ws->com[b][v][2] = ys; }
     }
 }
 
-// the centre of bitmap b from the four parts (part order); every workgroup of the bitmap computes the same three numbers
-__device__ __forceinline__ void com_from_parts(const PartScratch* __restrict__ ws, int b, float& xc, float& yc, float& S)
+// the centre of a bitmap from its four parts (part order); every workgroup of the bitmap computes the same three numbers
+__device__ __forceinline__ void com_from_parts(const double (*parts)[3], float& xc, float& yc, float& S)
 {
     double s = 0.0, xs = 0.0, ys = 0.0;
-    for (int v = 0; v < kLossParts; ++v) { s += ws->com[b][v][0]; xs += ws->com[b][v][1]; ys += ws->com[b][v][2]; }
+    for (int v = 0; v < kLossParts; ++v) { s += parts[v][0]; xs += parts[v][1]; ys += parts[v][2]; }
     S = (float)s + 1e-8f;
     xc = (float)(xs / (double)S); yc = (float)(ys / (double)S);
 }
 
-__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_parts_fwd_kernel(const float* __restrict__ flux,
-                                                                                     const float* __restrict__ dims,
-                                                                                     const float* __restrict__ truth, int Hh, int W,
-                                                                                     float crop_w, float crop_h, int parts_per_wg,
-                                                                                     PartScratch* ws)
+// loss, the record the backward pass reads and - with a residual - the centre's gradient per unit of 2 gl / sum(truth)
+__device__ __forceinline__ void loss_from_parts(const double (*acc)[4], float xc, float yc, float S, int b, int Hh, int W,
+                                                float* __restrict__ loss, float* __restrict__ com4, float* __restrict__ gunit)
 {
-    __shared__ double s_red[16];
+    double se = 0.0, sg = 0.0, gx = 0.0, gy = 0.0;
+    for (int v = 0; v < kLossParts; ++v) { se += acc[v][0]; sg += acc[v][1]; gx += acc[v][2]; gy += acc[v][3]; }
+    const float sgf = (float)sg;
+    loss[b] = (float)se / sgf;                              // loss.py:312-318
+    com4[4 * b] = xc; com4[4 * b + 1] = yc; com4[4 * b + 2] = S; com4[4 * b + 3] = sgf;
+    if (gunit) {
+        gunit[2 * b] = (float)(gx * (double)((float)(W - 1) / 2.0f));
+        gunit[2 * b + 1] = (float)(gy * (double)((float)(Hh - 1) / 2.0f));
+    }
+}
+
+template <bool WHOLE>       // WHOLE: one workgroup per bitmap does all four parts, the centre and the final sums itself
+__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(const float* __restrict__ flux,
+                                                                               const float* __restrict__ dims,
+                                                                               const float* __restrict__ truth, int Hh, int W,
+                                                                               float crop_w, float crop_h, int parts_per_wg,
+                                                                               PartScratch* ws, float* __restrict__ residual,
+                                                                               float* __restrict__ loss, float* __restrict__ com4,
+                                                                               float* __restrict__ gunit)
+{
+    __shared__ double s_red[16 * 4];
+    __shared__ double s_com[kLossParts][3], s_acc[kLossParts][4];
     const int b = blockIdx.y;
     const float* __restrict__ f = flux + (int64_t)b * Hh * W;
     const float* __restrict__ g = truth + (int64_t)b * Hh * W;
+    float* __restrict__ res = residual ? residual + (int64_t)b * Hh * W : nullptr;
     CropMap m;
     float S;
-    com_from_parts(ws, b, m.xc, m.yc, S);
+    if constexpr (WHOLE) {
+        for (int v = 0; v < kLossParts; ++v) {
+            double s, xs, ys;
+            com_part_sums(f, Hh, W, v, s_red, s, xs, ys);
+            if (threadIdx.x == 0) { s_com[v][0] = s; s_com[v][1] = xs; s_com[v][2] = ys; }
+        }
+        __syncthreads();
+        com_from_parts(s_com, m.xc, m.yc, S);
+    } else {
+        com_from_parts(ws->com[b], m.xc, m.yc, S);
+    }
     m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
     m.W = W; m.Hh = Hh;
     for (int v = blockIdx.x * parts_per_wg; v < (int)(blockIdx.x + 1) * parts_per_wg; ++v) {
         int r0, r1;
         part_rows(Hh, v, r0, r1);
-        double se = 0.0, sg = 0.0;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};             // sum d^2, sum truth, and the two sums of the centre's gradient
         if ((int)blockDim.x % W == 0) {                 // a thread owns one column
             const int j = threadIdx.x % W, di = blockDim.x / W;
             const CropColumn col = crop_column(m, j);
-#pragma unroll 4
-            for (int i = r0 + threadIdx.x / W; i < r1; i += di) {
-                float v00, v01, v10, v11, ty;
-                const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
-                const float t = g[i * W + j];
-                const float d = c - t;
-                se += (double)(d * d); sg += (double)t;
+            // four rows per step, every tap and the measured flux loaded BEFORE the first residual is stored: the loop is a chain
+            // of L2 round trips otherwise (a store between two rows' loads keeps the compiler from having them in flight together)
+            constexpr int kRows = 4;
+            for (int i0 = r0 + threadIdx.x / W; i0 < r1; i0 += kRows * di) {
+                float c[kRows], t[kRows], gxs[kRows], gys[kRows];
+#pragma unroll
+                for (int u = 0; u < kRows; ++u) {
+                    const int i = min(i0 + u * di, r1 - 1);                 // (a clamped row is loaded and not used)
+                    float v00, v01, v10, v11, ty;
+                    c[u] = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
+                    t[u] = g[i * W + j];
+                    gxs[u] = (v01 - v00) * (1.0f - ty) + (v11 - v10) * ty;
+                    gys[u] = (v10 - v00) * (1.0f - col.tx) + (v11 - v01) * col.tx;
+                }
+#pragma unroll
+                for (int u = 0; u < kRows; ++u) {
+                    const int i = i0 + u * di;
+                    if (i >= r1) break;
+                    const float d = c[u] - t[u];
+                    a[0] += (double)(d * d); a[1] += (double)t[u];
+                    if (res) {
+                        res[i * W + j] = d;
+                        a[2] += (double)(d * gxs[u]);
+                        a[3] += (double)(d * gys[u]);
+                    }
+                }
             }
         } else {
             for (int k = r0 * W + threadIdx.x; k < r1 * W; k += blockDim.x) {
@@ -755,91 +710,35 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_parts_fwd_k
                 const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
                 const float t = g[k];
                 const float d = c - t;
-                se += (double)(d * d); sg += (double)t;
+                a[0] += (double)(d * d); a[1] += (double)t;
+                if (res) {
+                    res[k] = d;
+                    a[2] += (double)(d * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
+                    a[3] += (double)(d * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
+                }
             }
         }
-        se = block_sum(se, s_red); sg = block_sum(sg, s_red);
-        if (threadIdx.x == 0) { ws->acc[b][v][0] = se; ws->acc[b][v][1] = sg; }
+        block_sum_n<4>(a, s_red);
+        if (threadIdx.x == 0) {
+            double* out = WHOLE ? s_acc[v] : ws->acc[b][v];
+            out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; out[3] = a[3];
+        }
+    }
+    if constexpr (WHOLE) {
+        if (threadIdx.x == 0) loss_from_parts(s_acc, m.xc, m.yc, S, b, Hh, W, loss, com4, gunit);     // (its own writes)
     }
 }
 
-// loss[b] and the record the backward pass reads, from the parts (part order): one thread per bitmap
-__global__ __launch_bounds__(256) void flux_crop_pixel_loss_parts_fwd_final_kernel(const PartScratch* __restrict__ ws, int B,
-                                                                                  float* __restrict__ loss, float* __restrict__ com4)
+// the parts of the bitmaps that were shared among workgroups -> loss and records: one thread per bitmap
+__global__ __launch_bounds__(256) void flux_crop_pixel_loss_final_kernel(const PartScratch* __restrict__ ws, int B, int Hh, int W,
+                                                                         float* __restrict__ loss, float* __restrict__ com4,
+                                                                         float* __restrict__ gunit)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float xc, yc, S;
-    com_from_parts(ws, b, xc, yc, S);
-    double se = 0.0, sg = 0.0;
-    for (int v = 0; v < kLossParts; ++v) { se += ws->acc[b][v][0]; sg += ws->acc[b][v][1]; }
-    const float sgf = (float)sg;
-    loss[b] = (float)se / sgf;                              // loss.py:312-318
-    com4[4 * b] = xc; com4[4 * b + 1] = yc; com4[4 * b + 2] = S; com4[4 * b + 3] = sgf;
-}
-
-__global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_parts_bwd_kernel(const float* __restrict__ flux,
-                                                                                     const float* __restrict__ dims,
-                                                                                     const float* __restrict__ truth,
-                                                                                     const float* __restrict__ com4,
-                                                                                     const float* __restrict__ grad_loss, int Hh, int W,
-                                                                                     float crop_w, float crop_h, int parts_per_wg,
-                                                                                     PartScratch* ws, float* __restrict__ grad_crop)
-{
-    __shared__ double s_red[16];
-    const int b = blockIdx.y;
-    const float* __restrict__ f = flux + (int64_t)b * Hh * W;
-    const float* __restrict__ g = truth + (int64_t)b * Hh * W;
-    float* __restrict__ gc = grad_crop + (int64_t)b * Hh * W;
-    CropMap m;
-    m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
-    m.xc = com4[4 * b]; m.yc = com4[4 * b + 1]; m.W = W; m.Hh = Hh;
-    const float sgf = com4[4 * b + 3], gl = grad_loss[b];
-    for (int v = blockIdx.x * parts_per_wg; v < (int)(blockIdx.x + 1) * parts_per_wg; ++v) {
-        int r0, r1;
-        part_rows(Hh, v, r0, r1);
-        double gx = 0.0, gy = 0.0;
-        if ((int)blockDim.x % W == 0) {
-            const int j = threadIdx.x % W, di = blockDim.x / W;
-            const CropColumn col = crop_column(m, j);
-#pragma unroll 4
-            for (int i = r0 + threadIdx.x / W; i < r1; i += di) {
-                float v00, v01, v10, v11, ty;
-                const float c = crop_sample_col(f, m, col, i, v00, v01, v10, v11, ty);
-                const int k = i * W + j;
-                const float go = gl * (2.0f * (c - g[k])) / sgf;
-                gc[k] = go;
-                gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
-                gy += (double)(go * ((v10 - v00) * (1.0f - col.tx) + (v11 - v01) * col.tx));
-            }
-        } else {
-            for (int k = r0 * W + threadIdx.x; k < r1 * W; k += blockDim.x) {
-                const int i = k / W, j = k - i * W;
-                float v00, v01, v10, v11, tx, ty;
-                const float c = crop_sample(f, m, i, j, v00, v01, v10, v11, tx, ty);
-                const float go = gl * (2.0f * (c - g[k])) / sgf;
-                gc[k] = go;
-                gx += (double)(go * ((v01 - v00) * (1.0f - ty) + (v11 - v10) * ty));
-                gy += (double)(go * ((v10 - v00) * (1.0f - tx) + (v11 - v01) * tx));
-            }
-        }
-        gx = block_sum(gx, s_red); gy = block_sum(gy, s_red);
-        if (threadIdx.x == 0) { ws->acc[b][v][0] = gx; ws->acc[b][v][1] = gy; }
-    }
-}
-
-// the gradient of the two centre coordinates from the parts (part order), and the centre in the layout the tiled kernel reads
-__global__ __launch_bounds__(256) void flux_crop_pixel_loss_parts_bwd_final_kernel(const PartScratch* __restrict__ ws,
-                                                                                  const float* __restrict__ com4, int B, int Hh, int W,
-                                                                                  float* __restrict__ com3, float* __restrict__ gcom)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double gx = 0.0, gy = 0.0;
-    for (int v = 0; v < kLossParts; ++v) { gx += ws->acc[b][v][0]; gy += ws->acc[b][v][1]; }
-    gcom[2 * b] = (float)(gx * (double)((float)(W - 1) / 2.0f));
-    gcom[2 * b + 1] = (float)(gy * (double)((float)(Hh - 1) / 2.0f));
-    com3[3 * b] = com4[4 * b]; com3[3 * b + 1] = com4[4 * b + 1]; com3[3 * b + 2] = com4[4 * b + 2];
+    com_from_parts(ws->com[b], xc, yc, S);
+    loss_from_parts(ws->acc[b], xc, yc, S, b, Hh, W, loss, com4, gunit);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1038,7 +937,8 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_kl_loss_bwd_kernel(con
 
 using namespace art;
 
-// Scratch of the part kernels: one PartScratch per (device, stream), allocated on first use and kept.  nullptr when the allocation fails: the callers fall back to one workgroup per bitmap.
+// Scratch of the part kernels: one PartScratch per (device, stream), allocated on first use and kept (every entry is written
+// before it is read: no initialisation).  nullptr when the allocation fails: the callers give a bitmap one workgroup.
 static PartScratch* flux_parts_scratch(hipStream_t stream)
 {
     struct Entry { int dev; hipStream_t stream; PartScratch* ws; };
@@ -1051,7 +951,6 @@ static PartScratch* flux_parts_scratch(hipStream_t stream)
         if (e.dev == dev && e.stream == stream) return e.ws;
     PartScratch* ws = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&ws), sizeof(PartScratch)) != hipSuccess) return nullptr;
-    if (hipMemset(ws, 0, sizeof(PartScratch)) != hipSuccess) { (void)hipFree(ws); return nullptr; }
     table.push_back({dev, stream, ws});
     return ws;
 }
@@ -1060,11 +959,10 @@ static PartScratch* flux_parts_scratch(hipStream_t stream)
 // (the passes are bound by what ONE CU's texture path delivers: two workgroups on a CU gain nothing and the extra launches
 // cost ~4 us each).  Measured, forward / backward in us (tools/flux_bench.py; 1, 2, 4 workgroups per bitmap): 64 bitmaps
 // 40 / 71, 35 / 57, 22 / 45; 125 bitmaps 42 / 84, 37 / 73, 37 / 74; 180 bitmaps 43 / 98, 63 / 112, 52 / 100; 250 bitmaps
-// 45 / 114, 64 / 128, 66 / 130.  ARTIST_HIP_LOSS_PARTS = 1 / 2 / 4 forces a value (1: the one-workgroup kernels).
+// 45 / 114, 64 / 128, 66 / 130.  (ARTIST_HIP_DEBUG=1 ARTIST_HIP_LOSS_PARTS = 1 / 2 / 4 forces a value: tests - the results are the same bits.)
 static int loss_workgroups_per_bitmap(int64_t B, int64_t Hh)
 {
-    const char* env = getenv("ARTIST_HIP_LOSS_PARTS");
-    const int forced = env ? atoi(env) : 0;
+    const int forced = debug_env_int("ARTIST_HIP_LOSS_PARTS", 0);
     if (B > kMaxPartBitmaps || Hh < kLossParts) return 1;
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     int cus = 256;
@@ -1105,10 +1003,10 @@ extern "C" int art_flux_crop_bwd(const float* flux, const float* target_dims, co
     if (B == 0) return ART_OK;
     hipLaunchKernelGGL(flux_crop_bwd_com_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims, centers,
                        grad_out, (int)Hh, (int)W, (float)crop_width, (float)crop_height, workspace);
-    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel,
+    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel<false>,
                        dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),
                        dim3(256), 0, stream, target_dims, centers, workspace, grad_out, (int)Hh, (int)W,
-                       (float)crop_width, (float)crop_height, grad_flux);
+                       (float)crop_width, (float)crop_height, grad_flux, (const float*)nullptr);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }
@@ -1129,54 +1027,41 @@ extern "C" int art_flux_loss(const float* prediction, const float* ground_truth,
 
 extern "C" int art_flux_crop_pixel_loss_fwd(const float* flux, const float* target_dims, const float* ground_truth, int64_t B,
                                             int64_t Hh, int64_t W, double crop_width, double crop_height, float* loss,
-                                            float* centers4, void* stream_)
+                                            float* centers4, float* residual, float* center_grad_unit, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!crop_args_ok(flux, target_dims, ground_truth, loss, B, Hh, W) || !centers4) return ART_EINVAL;
+    if (!crop_args_ok(flux, target_dims, ground_truth, loss, B, Hh, W) || !centers4 || (residual != nullptr) != (center_grad_unit != nullptr))
+        return ART_EINVAL;
     if (B == 0) return ART_OK;
     const int P = loss_workgroups_per_bitmap(B, Hh);
     PartScratch* ws = P > 1 ? flux_parts_scratch(stream) : nullptr;
     if (ws != nullptr) {
         hipLaunchKernelGGL(flux_com_parts_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux, (int)Hh, (int)W,
                            kLossParts / P, ws);
-        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_fwd_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux,
-                           target_dims, ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, kLossParts / P, ws);
-        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_fwd_final_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, ws, (int)B,
-                           loss, centers4);
+        hipLaunchKernelGGL(flux_crop_pixel_loss_fwd_kernel<false>, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux,
+                           target_dims, ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, kLossParts / P, ws, residual,
+                           loss, centers4, center_grad_unit);
+        hipLaunchKernelGGL(flux_crop_pixel_loss_final_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, ws, (int)B, (int)Hh,
+                           (int)W, loss, centers4, center_grad_unit);
     } else
-    hipLaunchKernelGGL(flux_crop_pixel_loss_fwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
-                       ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, loss, centers4);
+    hipLaunchKernelGGL(flux_crop_pixel_loss_fwd_kernel<true>, dim3(1u, (unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
+                       ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, kLossParts, (PartScratch*)nullptr, residual,
+                       loss, centers4, center_grad_unit);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }
 
-extern "C" int art_flux_crop_pixel_loss_bwd(const float* flux, const float* target_dims, const float* ground_truth,
-                                            const float* centers4, const float* grad_loss, int64_t B, int64_t Hh, int64_t W,
-                                            double crop_width, double crop_height, float* grad_flux, float* workspace,
-                                            void* stream_)
+extern "C" int art_flux_crop_pixel_loss_bwd(const float* target_dims, const float* centers4, const float* grad_loss,
+                                            const float* residual, const float* center_grad_unit, int64_t B, int64_t Hh, int64_t W,
+                                            double crop_width, double crop_height, float* grad_flux, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!crop_args_ok(flux, target_dims, ground_truth, centers4, B, Hh, W) || !grad_loss || !grad_flux || !workspace) return ART_EINVAL;
+    if (!crop_args_ok(residual, target_dims, center_grad_unit, centers4, B, Hh, W) || !grad_loss || !grad_flux) return ART_EINVAL;
     if (B == 0) return ART_OK;
-    float* grad_crop = workspace;                      // [B,Hh,W]
-    float* com3 = workspace + B * Hh * W;              // [B,3]
-    float* gcom = com3 + 3 * B;                        // [B,2]
-    const int P = loss_workgroups_per_bitmap(B, Hh);
-    PartScratch* ws = P > 1 ? flux_parts_scratch(stream) : nullptr;
-    if (ws != nullptr) {
-        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_bwd_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux,
-                           target_dims, ground_truth, centers4, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height,
-                           kLossParts / P, ws, grad_crop);
-        hipLaunchKernelGGL(flux_crop_pixel_loss_parts_bwd_final_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, ws,
-                           centers4, (int)B, (int)Hh, (int)W, com3, gcom);
-    } else
-    hipLaunchKernelGGL(flux_crop_pixel_loss_bwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
-                       ground_truth, centers4, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height, grad_crop, com3,
-                       gcom);
-    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel,
+    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel<true>,
                        dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),
-                       dim3(256), 0, stream, target_dims, com3, gcom, grad_crop, (int)Hh, (int)W, (float)crop_width,
-                       (float)crop_height, grad_flux);
+                       dim3(256), 0, stream, target_dims, centers4, center_grad_unit, residual, (int)Hh, (int)W, (float)crop_width,
+                       (float)crop_height, grad_flux, grad_loss);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }
@@ -1230,10 +1115,10 @@ extern "C" int art_flux_crop_kl_loss_bwd(const float* flux, const float* target_
     hipLaunchKernelGGL(flux_crop_kl_loss_bwd_kernel, dim3((unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
                        ground_truth, record8, grad_loss, (int)Hh, (int)W, (float)crop_width, (float)crop_height, grad_crop, com3,
                        gcom);
-    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel,
+    hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel<false>,
                        dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),
                        dim3(256), 0, stream, target_dims, com3, gcom, grad_crop, (int)Hh, (int)W, (float)crop_width,
-                       (float)crop_height, grad_flux);
+                       (float)crop_height, grad_flux, (const float*)nullptr);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

@@ -114,9 +114,10 @@ class _FluxLoss(torch.autograd.Function):
 
 
 class FluxCropPixelLoss(torch.autograd.Function):
-    """``PixelLoss()(crop_flux_distributions_around_center(flux, ...), ground_truth, reduction_dimensions=(1, 2))`` as one
-    pass per direction (``art_flux_crop_pixel_loss_fwd/bwd``): the same numbers, bit for bit, without the cropped
-    bitmaps' round trip through HBM.  Differentiable w.r.t. ``flux``."""
+    """``PixelLoss()(crop_flux_distributions_around_center(flux, ...), ground_truth, reduction_dimensions=(1, 2))`` fused
+    (``art_flux_crop_pixel_loss_fwd/bwd``): the same numbers up to the rounding of the sums (< 1e-6), the same bits for every
+    batch size, without the cropped bitmaps' round trip through HBM; when a gradient is wanted the forward pass keeps the
+    residual ``crop - ground_truth`` and the backward pass is one kernel over it.  Differentiable w.r.t. ``flux``."""
 
     @staticmethod
     def forward(ctx, flux, dims, ground_truth, crop_width, crop_height):
@@ -127,28 +128,31 @@ class FluxCropPixelLoss(torch.autograd.Function):
         B, Hh, W = flux.shape
         loss = torch.empty((B,), dtype=torch.float32, device=dev)
         centers = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        keep = bool(ctx.needs_input_grad[0])
+        residual = torch.empty_like(flux) if keep else None
+        unit = torch.empty((B, 2), dtype=torch.float32, device=dev) if keep else None
         with torch.cuda.device(dev):
             rc = _lib.lib().art_flux_crop_pixel_loss_fwd(flux.data_ptr(), dims.data_ptr(), ground_truth.data_ptr(), B, Hh, W,
-                                                         float(crop_width), float(crop_height), loss.data_ptr(),
-                                                         centers.data_ptr(), _stream(dev))
+                                                         float(crop_width), float(crop_height), loss.data_ptr(), centers.data_ptr(),
+                                                         residual.data_ptr() if keep else None, unit.data_ptr() if keep else None,
+                                                         _stream(dev))
         _lib.check(rc, "art_flux_crop_pixel_loss_fwd")
-        ctx.save_for_backward(flux, dims, ground_truth, centers)
+        if keep:
+            ctx.save_for_backward(dims, centers, residual, unit)
         ctx.crop = (float(crop_width), float(crop_height))
         return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, grad_loss):
-        flux, dims, ground_truth, centers = ctx.saved_tensors
-        dev = flux.device
-        B, Hh, W = flux.shape
+        dims, centers, residual, unit = ctx.saved_tensors
+        dev = residual.device
+        B, Hh, W = residual.shape
         grad_loss = _f32c(grad_loss)
-        grad_flux = torch.empty_like(flux)
-        workspace = torch.empty((B * Hh * W + 5 * B,), dtype=torch.float32, device=dev)
+        grad_flux = torch.empty_like(residual)
         with torch.cuda.device(dev):
-            rc = _lib.lib().art_flux_crop_pixel_loss_bwd(flux.data_ptr(), dims.data_ptr(), ground_truth.data_ptr(),
-                                                         centers.data_ptr(), grad_loss.data_ptr(), B, Hh, W, *ctx.crop,
-                                                         grad_flux.data_ptr(), workspace.data_ptr(), _stream(dev))
+            rc = _lib.lib().art_flux_crop_pixel_loss_bwd(dims.data_ptr(), centers.data_ptr(), grad_loss.data_ptr(), residual.data_ptr(),
+                                                         unit.data_ptr(), B, Hh, W, *ctx.crop, grad_flux.data_ptr(), _stream(dev))
         _lib.check(rc, "art_flux_crop_pixel_loss_bwd")
         return grad_flux, None, None, None, None
 

@@ -314,23 +314,24 @@ int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B,
 /* ---------------------------------------------------------------------------------------------
  * art_flux_crop_pixel_loss_fwd / _bwd - the two calls every surface-reconstruction epoch makes on the tracer's
  * bitmaps, crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246) followed by PixelLoss
- * (artist/optim/loss.py:251-318; surface_reconstructor.py:575-590, 664-676), as ONE pass per direction: the cropped
- * bitmaps never reach HBM.  Results are bit-identical to art_flux_crop_fwd + art_flux_loss(kind 0) and to their
- * backward calls when a bitmap has a workgroup of its own (B > half the GPU's CUs).  Smaller batches give a bitmap
- * two or four workgroups (its rows in four parts whose fp64 sums are added in part order): the same numbers up to
- * the last bits of those sums (< 1e-6 relative in the results), reproducible from run to run.
+ * (artist/optim/loss.py:251-318; surface_reconstructor.py:575-590, 664-676), fused: the cropped bitmaps never reach
+ * HBM, and the backward call is ONE pass over the residual the forward call kept.
+ * The same numbers as art_flux_crop_fwd + art_flux_loss(kind 0) and their backward calls up to the rounding of the sums
+ * (a bitmap's rows are always summed in four parts, whatever the batch size, and the parts added in order: < 1e-6 relative)
+ * - and the same BITS for every batch size and from run to run: small batches give a bitmap two or four workgroups, large
+ * ones a single workgroup, the arithmetic is the same (a rank's share of a field and the whole field agree bit for bit).
  *   flux [B,Hh,W], target_dims [B,2], ground_truth [B,Hh,W] (the measured, already cropped flux)
- *   loss [B] out; centers4 [B,4] out (centre of mass x, y, bitmap sum + 1e-8, sum of the measured flux): pass it
- *   back to the backward call.
- *   grad_loss [B]; grad_flux [B,Hh,W] out; workspace B*Hh*W + 5*B floats.
+ *   loss [B] out; centers4 [B,4] out (centre of mass x, y, bitmap sum + 1e-8, sum of the measured flux)
+ *   residual [B,Hh,W] out, center_grad_unit [B,2] out: crop - ground_truth and the gradient of the two centre coordinates
+ *   per unit of 2 grad_loss / sum(ground_truth) - what the backward call needs; both NULL for a forward-only call.
+ *   _bwd: grad_loss [B] -> grad_flux [B,Hh,W] (fully written).
  * ------------------------------------------------------------------------------------------- */
 int art_flux_crop_pixel_loss_fwd(const float *flux, const float *target_dims, const float *ground_truth, int64_t B,
                                  int64_t Hh, int64_t W, double crop_width, double crop_height, float *loss,
-                                 float *centers4, void *stream);
-int art_flux_crop_pixel_loss_bwd(const float *flux, const float *target_dims, const float *ground_truth,
-                                 const float *centers4, const float *grad_loss, int64_t B, int64_t Hh, int64_t W,
-                                 double crop_width, double crop_height, float *grad_flux, float *workspace,
-                                 void *stream);
+                                 float *centers4, float *residual, float *center_grad_unit, void *stream);
+int art_flux_crop_pixel_loss_bwd(const float *target_dims, const float *centers4, const float *grad_loss,
+                                 const float *residual, const float *center_grad_unit, int64_t B, int64_t Hh, int64_t W,
+                                 double crop_width, double crop_height, float *grad_flux, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * art_flux_crop_kl_loss_fwd / _bwd - crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246) followed by

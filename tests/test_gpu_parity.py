@@ -1326,16 +1326,17 @@ def test_flux_losses(golden):
 
 @pytest.mark.parametrize("parts", ["1", "2", "4", None])
 def test_fused_crop_pixel_loss(parts, monkeypatch):
-    """art_flux_crop_pixel_loss_fwd/bwd (crop + PixelLoss in one pass per direction) against the two separate ops the
-    reference's epoch calls (bitmap.py:121-246, loss.py:251-318), forward and gradient, incl. an empty bitmap, a spot cut by
-    the border and non-square resolutions.  With one workgroup per bitmap (ARTIST_HIP_LOSS_PARTS=1; large batches) the same
-    BITS; small batches share a bitmap among up to four workgroups (round 3: its rows in four parts, the parts' fp64 sums added
-    in part order), which moves the last bits of the sums: 1e-6 there, the same bits for 2 and 4 workgroups, and from run to run."""
+    """art_flux_crop_pixel_loss_fwd/bwd (crop + PixelLoss fused; the backward pass one kernel over the residual the forward pass
+    kept) against the two separate ops the reference's epoch calls (bitmap.py:121-246, loss.py:251-318), forward and gradient,
+    incl. an empty bitmap, a spot cut by the border and non-square resolutions: the same numbers to 1e-6 (a bitmap's rows are
+    summed in four parts added in part order, and the loss adjoint's factor 2 gl / sum(truth) multiplies the gathered residual
+    instead of every pixel of dL/dcrop), and the same BITS with one, two or four workgroups per bitmap - i.e. at every batch
+    size - and from run to run (round 3: one workgroup per bitmap summed differently from two or four; advisor finding)."""
     from artist_amd import PixelLoss
     from artist_amd.flux import FluxCrop, FluxCropPixelLoss
+    monkeypatch.setenv("ARTIST_HIP_DEBUG", "1")
     if parts is not None:
         monkeypatch.setenv("ARTIST_HIP_LOSS_PARTS", parts)
-    one_workgroup = parts == "1"
     gen = torch.Generator(device=DEV).manual_seed(4)
     for (B, Hh, W) in [(5, 256, 256), (3, 60, 100), (2, 33, 17)]:
         ys, xs = torch.meshgrid(torch.arange(Hh, device=DEV, dtype=torch.float32), torch.arange(W, device=DEV, dtype=torch.float32),
@@ -1355,27 +1356,26 @@ def test_fused_crop_pixel_loss(parts, monkeypatch):
         w = torch.rand(B, generator=gen, device=DEV)
         (loss_a * w).sum().backward()
         (loss_b * w).sum().backward()
-        if one_workgroup:
-            np.testing.assert_array_equal(n(loss_b), n(loss_a))
-            np.testing.assert_array_equal(n(b.grad), n(a.grad))
-        else:
-            np.testing.assert_allclose(n(loss_b), n(loss_a), rtol=1e-6, atol=0)
-            assert rel_l2(n(b.grad), n(a.grad)) < 1e-6, rel_l2(n(b.grad), n(a.grad))
-            c = flux.clone().requires_grad_(True)                # the same call again: the same bits
-            loss_c = FluxCropPixelLoss.apply(c, dims, truth, 6.0, 5.0)
-            (loss_c * w).sum().backward()
-            np.testing.assert_array_equal(n(loss_c), n(loss_b))
-            np.testing.assert_array_equal(n(c.grad), n(b.grad))
-            monkeypatch.setenv("ARTIST_HIP_LOSS_PARTS", "2" if parts != "2" else "4")      # ... and with another number of workgroups
+        np.testing.assert_allclose(n(loss_b), n(loss_a), rtol=1e-6, atol=0)
+        assert rel_l2(n(b.grad), n(a.grad)) < 1e-6, rel_l2(n(b.grad), n(a.grad))
+        with torch.no_grad():                                    # a forward-only call (no residual kept): the same loss bits
+            np.testing.assert_array_equal(n(FluxCropPixelLoss.apply(flux, dims, truth, 6.0, 5.0)), n(loss_b))
+        c = flux.clone().requires_grad_(True)                    # the same call again: the same bits
+        loss_c = FluxCropPixelLoss.apply(c, dims, truth, 6.0, 5.0)
+        (loss_c * w).sum().backward()
+        np.testing.assert_array_equal(n(loss_c), n(loss_b))
+        np.testing.assert_array_equal(n(c.grad), n(b.grad))
+        for other in ("1", "2", "4"):                            # ... and with every number of workgroups per bitmap
+            monkeypatch.setenv("ARTIST_HIP_LOSS_PARTS", other)
             e = flux.clone().requires_grad_(True)
             loss_e = FluxCropPixelLoss.apply(e, dims, truth, 6.0, 5.0)
             (loss_e * w).sum().backward()
             np.testing.assert_array_equal(n(loss_e), n(loss_b))
             np.testing.assert_array_equal(n(e.grad), n(b.grad))
-            if parts is not None:
-                monkeypatch.setenv("ARTIST_HIP_LOSS_PARTS", parts)
-            else:
-                monkeypatch.delenv("ARTIST_HIP_LOSS_PARTS")
+        if parts is not None:
+            monkeypatch.setenv("ARTIST_HIP_LOSS_PARTS", parts)
+        else:
+            monkeypatch.delenv("ARTIST_HIP_LOSS_PARTS")
 
 
 def test_flux_epilogue_full_size_properties():

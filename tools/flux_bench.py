@@ -43,11 +43,13 @@ cases = {
     "kl_loss_bwd": (lambda: lib.art_flux_loss(p(out), p(truth), B, Hh * W, 1, None, p(gl), p(gp), s), 3 * nbytes),
 }
 c4 = torch.empty(B, 4, device=dev)
-ws2 = torch.empty(B * Hh * W + 5 * B, device=dev)
-cases["crop_pixel_loss_fwd"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4), s),
+resid, unit = torch.empty_like(flux), torch.empty(B, 2, device=dev)
+cases["crop_pixel_loss_fwd"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4), None, None, s),
                                 2 * nbytes)
-cases["crop_pixel_loss_bwd"] = (lambda: lib.art_flux_crop_pixel_loss_bwd(p(flux), p(dims), p(truth), p(c4), p(gl), B, Hh, W, 6.0, 6.0,
-                                                                         p(gflux), p(ws2), s), 3 * nbytes)
+cases["crop_pixel_loss_fwd_keep"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4),
+                                                                              p(resid), p(unit), s), 3 * nbytes)
+cases["crop_pixel_loss_bwd"] = (lambda: lib.art_flux_crop_pixel_loss_bwd(p(dims), p(c4), p(gl), p(resid), p(unit), B, Hh, W, 6.0, 6.0,
+                                                                         p(gflux), s), 2 * nbytes)
 res = {}
 for name, (fn, alg) in cases.items():
     ms = timed(fn)
