@@ -8,8 +8,9 @@
 // Here: one elementwise kernel, one thread per 4 elements, the update rule of torch.optim.Adam / _single_tensor_adam
 // (torch/optim/adam.py) in fp32 with the bias corrections computed on the host in double from the host-side step count -
 // no device-side step tensor, no synchronisation.  Optional edge lock: the reference zeroes the gradient of the outer-edge
-// control points before the step (surface_reconstructor.py:779 via lock_control_points_on_outer_edges); with nu, nv > 0 the
-// kernel treats the gradient of the first / last row and column of every [nu,nv,3] net as zero (the moments still decay).
+// control points before the step (surface_reconstructor.py:779 via lock_control_points_on_outer_edges: their first two
+// components - the net keeps its outline, z stays free); with nu, nv > 0 the kernel treats those gradient components of the
+// first / last row and column of every [nu,nv,3] net as zero (the moments still decay).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -47,8 +48,10 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a)
         float gr = a.grad_sign * g[k];
         if (a.nu > 0) {
             const int64_t cell = (i0 + k) / 3;
+            const int comp = (int)((i0 + k) - 3 * cell);
             const int c = (int)(cell % a.nv), r = (int)((cell / a.nv) % a.nu);
-            if (r == 0 || r == a.nu - 1 || c == 0 || c == a.nv - 1) gr = 0.0f;
+            // surface_reconstructor.py:1212-1222: the edge control points keep their u and v (components 0, 1); z stays free
+            if (comp < 2 && (r == 0 || r == a.nu - 1 || c == 0 || c == a.nv - 1)) gr = 0.0f;
         }
         if (a.weight_decay != 0.0f) gr = gr + a.weight_decay * p[k];
         m[k] = m[k] + (gr - m[k]) * a.one_minus_beta1;                    // exp_avg.lerp_(grad, 1 - beta1)

@@ -18,9 +18,10 @@ __all__ = ["Adam"]
 class Adam(torch.optim.Optimizer):
     """``torch.optim.Adam`` on the gfx950 kernel ``art_adam_step`` (no amsgrad / capturable / differentiable modes).
 
-    ``lock_outer_edges`` (an addition): for parameters shaped ``[..., nu, nv, 3]`` treat the gradient of every net's first / last
-    row and column as zero, as ``SurfaceReconstructor.lock_control_points_on_outer_edges`` does before the reference's step
-    (surface_reconstructor.py:749-788) - without a pass over the gradient."""
+    ``lock_outer_edges`` (an addition): for parameters shaped ``[..., nu, nv, 3]`` treat the first two components of the gradient
+    of every net's first / last row and column as zero, as ``SurfaceReconstructor.lock_control_points_on_outer_edges`` does
+    before the reference's step (surface_reconstructor.py:1155-1224: the outline is kept, z stays free) - without a pass over
+    the gradient."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                  maximize: bool = False, lock_outer_edges: bool = False):

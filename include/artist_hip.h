@@ -258,9 +258,9 @@ int art_reflect(const float *incident, const float *normals, int64_t H, int64_t 
  * steps the control points (artist/optim/surface_reconstructor.py:452-455 creates the optimiser, :779 steps it) and the
  * kinematics deviations (artist/optim/kinematics_reconstructor.py).  `step` = number of this step (1 for the first): the
  * bias corrections are computed on the host from it, in double.  param, exp_avg, exp_avg_sq are updated in place.
- *   lock_nu, lock_nv > 0: the tensor is a batch of [nu,nv,3] control nets and the gradient of every net's outer edge counts
- *   as zero - SurfaceReconstructor.lock_control_points_on_outer_edges (surface_reconstructor.py:749-788) without a pass
- *   over the gradient; 0, 0: plain Adam.
+ *   lock_nu, lock_nv > 0: the tensor is a batch of [nu,nv,3] control nets and the first two components of the gradient of
+ *   every net's outer-edge control points count as zero - SurfaceReconstructor.lock_control_points_on_outer_edges
+ *   (surface_reconstructor.py:1155-1224: the outline is kept, z stays free) without a pass over the gradient; 0, 0: plain Adam.
  * ------------------------------------------------------------------------------------------- */
 int art_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int64_t step, int maximize, int64_t lock_nu, int64_t lock_nv,

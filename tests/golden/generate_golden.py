@@ -665,6 +665,163 @@ def save_interop_check():
     print(f"wrote {path.name}: {checks}")
 
 
+def surface_reconstructor_epochs(n_epochs=3, dtype=torch.float32):
+    """ONE real optimiser run of the reference: ``SurfaceReconstructor.reconstruct_surfaces`` (artist/optim/surface_reconstructor.py:
+    842-1152, unmodified) for a few epochs on a small synthetic scenario - three heliostats with two samples each (one training,
+    one test sample per heliostat after the reference's own train/test split), flat model surfaces against measured flux from
+    deflected ones.  The only stand-in is the calibration-data parser (``_parse_group_calibration_data`` reads PNG / JSON files
+    through PAINT's parser; it is handed the synthetic measurements instead) and the regulariser weights are zero.  Captured per
+    epoch, by wrapping the instance's own methods: control points at the start, orientation matrices of the training samples,
+    cropped predicted flux, per-sample flux loss, total loss, the control-point gradient after
+    ``_synchronize_and_lock_gradients``, the learning rate of the step and the control points after ``optimizer.step()``.
+    ``dtype=float64``: the same run in double precision on the SAME (fp32-sampled) ray distortions - the yardstick for the fp32
+    results of the first epoch (later epochs start from control points that differ in the last bits)."""
+    from artist.flux import bitmap
+    from artist.optim import SurfaceReconstructor
+    from artist.optim.loss import PixelLoss
+    from artist.util import constants
+
+    torch.manual_seed(7)
+    case = dict(n_heliostats=3, n_cp=(6, 6), degrees=(3, 3), n_eval=20, n_rays=6, resolution=[64, 64], z_noise=0.0,
+                positions=[[-12.0, 45.0, 0.0, 1.0], [4.0, 70.0, 0.0, 1.0], [20.0, 100.0, 0.0, 1.0]], **RECEIVER)
+    b = build(case, dtype)
+    scenario, group = b["scenario"], b["group"]
+    degrees, cp_flat, uv_full, canting_h, transl_h = b["nurbs_inputs"]
+    n_hel, res = 3, torch.tensor([64, 64])
+    if dtype != torch.float32:
+        sun = scenario.light_sources.light_source_list[0]
+
+        def f32_distortions(number_of_points, number_of_facets=4, number_of_active_heliostats=1, random_seed=7):
+            torch.manual_seed(random_seed)                              # artist/scene/sun.py:224-233 with float32 parameters
+            mvn = torch.distributions.MultivariateNormal(torch.zeros(2, dtype=torch.float32),
+                                                         torch.tensor([[4.3681e-06, 0.0], [0.0, 4.3681e-06]], dtype=torch.float32))
+            du, de = mvn.sample((number_of_active_heliostats, sun.number_of_rays, number_of_points)).permute(3, 0, 1, 2)
+            return du.to(dtype), de.to(dtype)
+
+        sun.get_distortions = f32_distortions
+    mask = torch.tensor([2, 2, 2], dtype=torch.int32)                  # two samples per heliostat
+    n_samples = int(mask.sum())
+    tix = torch.zeros(n_samples, dtype=torch.int64)
+    incident = torch.nn.functional.normalize(torch.tensor(
+        [[0.0, 1.0, 0.0, 0.0], [0.25, 0.9, -0.2, 0.0], [-0.1, 0.95, -0.1, 0.0], [0.0, 0.8, -0.6, 0.0], [0.15, 0.97, 0.0, 0.0],
+         [-0.3, 0.85, -0.3, 0.0]], dtype=torch.float32), dim=1).to(dtype)
+
+    # measured flux: the reference's own chain on the TRUE surfaces (flat nets + a smooth bump and a tilt per heliostat)
+    cp_true = cp_flat.clone()
+    x, y = cp_true[..., 0], cp_true[..., 1]
+    amp = torch.tensor([1.5e-3, -1.0e-3, 2.0e-3], dtype=torch.float32).to(dtype).view(3, 1, 1, 1)
+    tilt = torch.tensor([4e-4, -4e-4, 2e-4], dtype=torch.float32).to(dtype).view(3, 1, 1, 1)
+    cp_true[..., 2] = amp * (x ** 2 - 0.5 * y ** 2) + tilt * x
+
+    def measure(cp):
+        group.nurbs_control_points = cp
+        group.activate_heliostats(active_heliostats_mask=mask, device=CPU)
+        surf = NURBSSurfaces(degrees=degrees, control_points=group.active_nurbs_control_points, device=CPU)
+        pts, nrm = surf.calculate_surface_points_and_normals(
+            evaluation_points=uv_full.repeat_interleave(mask, dim=0), canting=group.active_canting,
+            facet_translations=group.active_facet_translations, device=CPU)
+        group.active_surface_points = pts.reshape(n_samples, -1, 4)
+        group.active_surface_normals = nrm.reshape(n_samples, -1, 4)
+        group.align_surfaces_with_incident_ray_directions(
+            aim_points=scenario.solar_tower.get_centers_of_target_areas(target_area_indices=tix, device=CPU),
+            incident_ray_directions=incident, active_heliostats_mask=mask, device=CPU)
+        rt = HeliostatRayTracer(scenario=scenario, heliostat_group=group, blocking_active=False, batch_size=100, random_seed=3,
+                                bitmap_resolution=res)
+        flux, _, _, _ = rt.trace_rays(incident_ray_directions=incident, active_heliostats_mask=mask, target_area_indices=tix, device=CPU)
+        return bitmap.crop_flux_distributions_around_center(flux_distributions=flux, solar_tower=scenario.solar_tower,
+                                                            target_area_indices=tix, device=CPU)
+
+    with torch.no_grad():
+        flux_measured = measure(cp_true).clone()
+    group.nurbs_control_points = cp_flat.clone()
+
+    optimizer_dict = {constants.initial_learning_rate: 2e-5, constants.tolerance: 0.0, constants.max_epoch: n_epochs - 1,
+                      constants.batch_size: 30, constants.log_step: 0, constants.early_stopping_delta: 1e-9,
+                      constants.early_stopping_patience: 100, constants.early_stopping_window: 10}
+    scheduler_dict = {constants.scheduler_type: constants.exponential, constants.gamma: 0.9}
+    constraint_dict = {constants.rho_flux_integral: 1.0, constants.energy_tolerance: 0.01, constants.weight_smoothness: 0.0,
+                       constants.weight_ideal_surface: 0.0}
+    config = {constants.optimization: optimizer_dict, constants.scheduler: scheduler_dict, constants.constraints: constraint_dict}
+    ddp = dict(device=CPU, is_distributed=False, is_nested=False, rank=0, world_size=1, process_subgroup=None,
+               groups_to_ranks_mapping={0: [0]}, heliostat_group_rank=0, heliostat_group_world_size=1, ranks_to_groups_mapping={0: [0]})
+    rec = SurfaceReconstructor(ddp_setup=ddp, scenario=scenario, data={constants.data_parser: None, constants.heliostat_data_mapping: []},
+                               optimization_configuration=config, number_of_surface_points=torch.tensor([20, 20]),
+                               bitmap_resolution=res, device=CPU)
+    rec._parse_group_calibration_data = lambda heliostat_group, device: (
+        flux_measured, torch.zeros(n_samples, 4), incident, torch.zeros(n_samples, 2), mask, tix)
+
+    log = dict(cp_start=[], cropped=[], orientation=[], loss_per_sample=[], grad_locked=[], lr=[], cp_after=[], train_idx=None)
+    predict = rec._predict_flux
+
+    def predict_wrapped(**kw):
+        log["cp_start"].append(npy(kw["heliostat_group"].nurbs_control_points).copy())
+        out = predict(**kw)
+        log["cropped"].append(npy(out[0]).copy())
+        log["train_idx"] = npy(kw["data_split"].train_indices)
+        # the orientation matrices the alignment used (heliostat_group_rigid_body.py:210-222: recomputed here, no_grad)
+        ds = kw["data_split"]
+        with torch.no_grad():
+            ori = kw["heliostat_group"].kinematics.incident_ray_directions_to_orientations(
+                incident_ray_directions=ds.incident_ray_directions_train,
+                aim_points=scenario.solar_tower.get_centers_of_target_areas(target_area_indices=ds.target_area_indices_train, device=CPU),
+                device=CPU)
+        log["orientation"].append(npy(ori).copy())
+        return out
+
+    rec._predict_flux = predict_wrapped
+    lock = rec._synchronize_and_lock_gradients
+
+    def lock_wrapped(optimizer, device):
+        lock(optimizer=optimizer, device=device)
+        prm = optimizer.param_groups[0]["params"][0]
+        log["grad_locked"].append(npy(prm.grad).copy())
+        log["lr"].append(float(optimizer.param_groups[0]["lr"]))
+
+    rec._synchronize_and_lock_gradients = lock_wrapped
+    setup = rec._setup_optimizer_scheduler_early_stopping
+
+    def setup_wrapped(heliostat_group):
+        optimizer, scheduler, stopper = setup(heliostat_group=heliostat_group)
+        step = optimizer.step
+
+        def step_wrapped(*a, **k):
+            r = step(*a, **k)
+            log["cp_after"].append(npy(optimizer.param_groups[0]["params"][0]).copy())
+            return r
+
+        optimizer.step = step_wrapped
+        return optimizer, scheduler, stopper
+
+    rec._setup_optimizer_scheduler_early_stopping = setup_wrapped
+
+    class RecordingLoss(PixelLoss):
+        def __call__(self, *a, **k):
+            out = super().__call__(*a, **k)
+            if out.requires_grad:                                       # (the validation calls run under no_grad)
+                log["loss_per_sample"].append(npy(out).copy())
+            return out
+
+    _, history = rec.reconstruct_surfaces(loss_definition=RecordingLoss(), device=CPU)
+    hist = history[0][0]
+    E = len(log["cp_after"])
+    assert E == n_epochs and len(log["cropped"]) == E and len(log["grad_locked"]) == E, (E, len(log["cropped"]))
+    train_idx = log["train_idx"]
+    out = dict(
+        degrees=npy(degrees), eval_points=npy(uv_full[:1]), canting=npy(canting_h), facet_translations=npy(transl_h),
+        positions=npy(group.positions), incident_train=npy(incident[train_idx]), target_idx_train=npy(tix[train_idx]),
+        train_indices=train_idx, flux_measured_train=npy(flux_measured[train_idx]), target_centers=npy(b["planar"].centers),
+        target_normals=npy(b["planar"].normals), target_dims=npy(b["planar"].dimensions), resolution=npy(res),
+        n_rays=np.int64(case["n_rays"]), seed=np.int64(0), covariance=np.float64(4.3681e-06), reflectivity=np.float64(0.935),
+        extinction=np.float64(0.0), ray_magnitude=np.float64(1.0), number_of_train_samples=np.int64(1),
+        rho_flux_integral=np.float64(1.0), energy_tolerance=np.float64(0.01), epsilon=np.float64(1e-12),
+        cp_start=np.stack(log["cp_start"]), orientation=np.stack(log["orientation"]), cropped_flux=np.stack(log["cropped"]),
+        flux_loss_per_sample=np.stack(log["loss_per_sample"][:E]), grad_locked=np.stack(log["grad_locked"]), lr=np.asarray(log["lr"]),
+        cp_after=np.stack(log["cp_after"]), total_loss=np.asarray(hist["total_loss"][:E], dtype=np.float64),
+        flux_loss=np.asarray(hist["flux_loss"][:E], dtype=np.float64))
+    print("  total loss per epoch:", out["total_loss"], " |grad| per epoch:", [float(np.linalg.norm(g)) for g in out["grad_locked"]])
+    return out
+
+
 def save(name, arrays):
     path = OUT_DIR / f"{name}.npz"
     np.savez_compressed(path, **arrays)
@@ -1132,6 +1289,15 @@ def main():
         save_interop_check()
     if only is None or "kinematics" in only:
         kinematics_fixture()
+    if only is None or "surface_reconstructor_epochs" in only:
+        a32 = surface_reconstructor_epochs(dtype=torch.float32)
+        a64 = surface_reconstructor_epochs(dtype=torch.float64)
+        # fp64 run, first epoch (same start, same rays): the yardstick; the measured flux of the fp64 run differs from the fp32
+        # run's in the last digits, so its loss and gradient are those of (almost) the same problem
+        for key in ("cropped_flux", "flux_loss_per_sample", "grad_locked", "cp_after", "total_loss"):
+            a32[key + "_f64_epoch0"] = a64[key][0]
+        torch.set_default_dtype(torch.float32)
+        save("surface_reconstructor_epochs", a32)
     # config 1 / config 2: inputs regenerate from the recipe (seeded torch CPU RNG); store outputs only.
     keep = {"flux", "intercept", "on_target", "blocking", "per_target", "control_points", "orientation",
             "aligned_points", "aligned_normals", "incident", "target_idx", "target_centers", "target_normals",

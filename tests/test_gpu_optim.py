@@ -50,7 +50,8 @@ def test_adam_equals_torch_adam(shape, kw):
 
 
 def test_adam_edge_lock_equals_the_reference_recipe():
-    """surface_reconstructor.py:749-788: the gradient of every net's outer-edge control points is zeroed, then Adam steps."""
+    """surface_reconstructor.py:1155-1224 + :779: the u and v components of the gradient of every net's outer-edge control points are
+    zeroed, then Adam steps."""
     from artist_amd.optim import Adam
     shape = (9, 4, 7, 5, 3)
     p0 = torch.randn(shape, generator=torch.Generator().manual_seed(4)).to(DEV)
@@ -59,11 +60,13 @@ def test_adam_edge_lock_equals_the_reference_recipe():
     for g in _grads(shape, 5, 5):
         a.grad = g.clone()
         locked = g.clone()
-        locked[:, :, 0], locked[:, :, -1], locked[:, :, :, 0], locked[:, :, :, -1] = 0, 0, 0, 0
+        for edge in (locked[:, :, 0], locked[:, :, -1], locked[:, :, :, 0], locked[:, :, :, -1]):
+            edge[..., :2] = 0                                     # u and v of the edge control points; z stays free
         b.grad = locked
         ours.step(); ref.step()
         assert torch.equal(a.detach(), b.detach())
-    assert torch.equal(a.detach()[:, :, 0], p0[:, :, 0]) and torch.equal(a.detach()[:, :, :, -1], p0[:, :, :, -1])
+    assert torch.equal(a.detach()[:, :, 0, :, :2], p0[:, :, 0, :, :2]) and torch.equal(a.detach()[:, :, :, -1, :2], p0[:, :, :, -1, :2])
+    assert not torch.equal(a.detach()[:, :, 0, :, 2], p0[:, :, 0, :, 2])
     assert not torch.equal(a.detach()[:, :, 1:-1, 1:-1], p0[:, :, 1:-1, 1:-1])
 
 
