@@ -31,55 +31,21 @@ __global__ __launch_bounds__(kAlignBlock) void align_fwd_kernel(const float4* __
     out_normals[i] = apply_mt(normals[i], M);
 }
 
-// WITH_GM: also accumulate dL/dM[j][k] = sum_p (gP_j xP_k + gN_j xN_k) (wave shuffle tree, LDS across
-// the 4 waves, 16 global atomics per workgroup into the pre-zeroed [H,4,4]).
-template <bool WITH_GM>
-__global__ __launch_bounds__(kAlignBlock) void align_bwd_kernel(const float4* __restrict__ points,
-                                                                 const float4* __restrict__ normals,
-                                                                 const float* __restrict__ orientation,
+// g_points = g_out_points @ M, g_normals = g_out_normals @ M (the gradient of the matrix itself: align_gm_kernel below; the
+// variant of this kernel that added it up with float atomics was dead code since round 2 and is gone)
+__global__ __launch_bounds__(kAlignBlock) void align_bwd_kernel(const float* __restrict__ orientation,
                                                                  const float4* __restrict__ g_out_points,
                                                                  const float4* __restrict__ g_out_normals, int P, int n_tiles,
                                                                  float4* __restrict__ g_points,
-                                                                 float4* __restrict__ g_normals,
-                                                                 float* __restrict__ g_orientation)
+                                                                 float4* __restrict__ g_normals)
 {
-    __shared__ float s_part[kAlignBlock / 64][16];
     const int h = blockIdx.x / n_tiles;
     const int p = (blockIdx.x % n_tiles) * kAlignBlock + threadIdx.x;
+    if (p >= P) return;
     const float* M = orientation + (int64_t)h * 16;
     const int64_t i = (int64_t)h * P + p;
-    float gm[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) gm[k] = 0.0f;
-    if (p < P) {
-        const float4 gp = g_out_points[i], gn = g_out_normals[i];
-        g_points[i] = apply_m(gp, M);
-        g_normals[i] = apply_m(gn, M);
-        if constexpr (WITH_GM) {
-            const float4 xp = points[i], xn = normals[i];
-            const float g4[4] = {gp.x, gp.y, gp.z, gp.w}, h4[4] = {gn.x, gn.y, gn.z, gn.w};
-            const float x4[4] = {xp.x, xp.y, xp.z, xp.w}, y4[4] = {xn.x, xn.y, xn.z, xn.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) gm[4 * j + k] = g4[j] * x4[k] + h4[j] * y4[k];
-        }
-    }
-    if constexpr (WITH_GM) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float v = wave_sum_f32(gm[k]);
-            if (lane == 0) s_part[wave][k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            float v = 0.0f;
-#pragma unroll
-            for (int w = 0; w < kAlignBlock / 64; ++w) v += s_part[w][threadIdx.x];
-            atomicAdd(g_orientation + (int64_t)h * 16 + threadIdx.x, v);
-        }
-    }
+    g_points[i] = apply_m(g_out_points[i], M);
+    g_normals[i] = apply_m(g_out_normals[i], M);
 }
 
 // dL/dM[j][k] = sum_p (gP_j xP_k + gN_j xN_k) of ONE heliostat per workgroup, summed in a fixed order (thread-strided
@@ -188,12 +154,9 @@ extern "C" int art_align_bwd(const float* points, const float* normals, const fl
     if (H == 0) return ART_OK;
     const int n_tiles = (int)((P + kAlignBlock - 1) / kAlignBlock);
     const dim3 grid((unsigned)(H * n_tiles));
-    hipLaunchKernelGGL(align_bwd_kernel<false>, grid, dim3(kAlignBlock), 0, stream,
-                       reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals),
-                       orientation, reinterpret_cast<const float4*>(grad_out_points),
-                       reinterpret_cast<const float4*>(grad_out_normals), (int)P, n_tiles,
-                       reinterpret_cast<float4*>(grad_points), reinterpret_cast<float4*>(grad_normals),
-                       grad_orientation);
+    hipLaunchKernelGGL(align_bwd_kernel, grid, dim3(kAlignBlock), 0, stream, orientation,
+                       reinterpret_cast<const float4*>(grad_out_points), reinterpret_cast<const float4*>(grad_out_normals),
+                       (int)P, n_tiles, reinterpret_cast<float4*>(grad_points), reinterpret_cast<float4*>(grad_normals));
     if (grad_orientation)
         hipLaunchKernelGGL(align_gm_kernel, dim3((unsigned)H), dim3(kGmBlock), 0, stream,
                            reinterpret_cast<const float4*>(points), reinterpret_cast<const float4*>(normals),

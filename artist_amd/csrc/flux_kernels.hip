@@ -300,22 +300,7 @@ __device__ __forceinline__ void tap_range(float scale, float centre, int n, int 
 // of a row by its 64 pixels - they are computed once per tile into LDS - and the sum factorises into a horizontal
 // pass (4 global loads per output row and column, kept in LDS) and a vertical pass (4 LDS reads per pixel).  A bitmap
 // whose crop scale needs more than four taps per axis (scale < ~0.6) takes the per-pixel form.
-#ifndef ART_COM_UNROLL         // float4 loads in flight per thread in the centre-of-mass pass / rows in flight in the crop passes
-#define ART_COM_UNROLL 4
-#endif
-#ifndef ART_CROP_UNROLL
-#define ART_CROP_UNROLL 4
-#endif
-#ifndef ART_CROP_TILE_Y        // (build-time knobs of the A/B builds: tools/build_obj_variant.sh)
-#define ART_CROP_TILE_Y 32
-#endif
-#ifndef ART_CROP_TILE_ROWS
-#define ART_CROP_TILE_ROWS 64
-#endif
-#ifndef ART_CROP_ROW_UNROLL
-#define ART_CROP_ROW_UNROLL 4
-#endif
-constexpr int kTileX = 64, kTileY = ART_CROP_TILE_Y, kTaps = 4, kTileRows = ART_CROP_TILE_ROWS, kRowUnroll = ART_CROP_ROW_UNROLL;
+constexpr int kTileX = 64, kTileY = 32, kTaps = 4, kTileRows = 64, kRowUnroll = 4;
 // LOSS = true: the fused crop + PixelLoss adjoint.  grad_out is then the RESIDUAL crop - truth that the forward pass kept, gcom
 // the gradient of the two centre coordinates per unit of 2 gl / sum(truth), and the whole pixel is scaled by that factor at
 // the end (everything here is linear in it): dL/dflux in ONE pass over the residual - no second sampling of the crop, no

@@ -22,11 +22,15 @@ extern thread_local int g_last_hip_error;
 // Diagnostic knobs (launch geometry, A/B paths; results are the same bits or within the documented rounding for every value):
 // the library reads ARTIST_HIP_* variables ONLY when ARTIST_HIP_DEBUG=1 is set - a caller's environment cannot change what the
 // product launches (tests and tools/ set both).
-static inline int debug_env_int(const char* name, int dflt)
+static inline const char* debug_env_str(const char* name)       // nullptr unless ARTIST_HIP_DEBUG=1 and the variable is set
 {
     const char* dbg = getenv("ARTIST_HIP_DEBUG");
-    if (dbg == nullptr || dbg[0] != '1') return dflt;
-    const char* v = getenv(name);
+    if (dbg == nullptr || dbg[0] != '1') return nullptr;
+    return getenv(name);
+}
+static inline int debug_env_int(const char* name, int dflt)
+{
+    const char* v = debug_env_str(name);
     return (v && *v) ? atoi(v) : dflt;
 }
 

@@ -8,7 +8,7 @@
 //    are computed once per grid ROW and COLUMN (Mu + Mv evaluations of A2.3 with its divisions instead of 2 Mu Mv), stage 1
 //    contracts the control net with the row bases (temp[i][c] = sum_r Nu_i[r] CP[su_i-p+r][c], and the same with Du), stage 2
 //    contracts with the column bases per point.  The sums run in the reference's order (r, then s, from a zero
-//    accumulator, no FMA contraction), so points are bit-identical to the scattered scheme, the oracle and the reference.
+//    accumulator, no FMA contraction), so points are bit-identical to the scattered scheme and to the reference.
 //    The backward is the adjoint of the two stages with every output element owned by ONE thread that adds its terms in
 //    index order - no atomics of any kind, control-point gradients are bit-reproducible.  The workgroup discovers the grid
 //    itself (row length = index of the first point whose u differs from point 0's; then every point is compared with

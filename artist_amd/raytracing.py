@@ -188,12 +188,10 @@ class HeliostatRayTracer:
         self._owner_cache = None                       # (keyed on `idx`: rebuilt with it)
         return idx, du, de
 
-    def trace_rays(self, incident_ray_directions: torch.Tensor, active_heliostats_mask: torch.Tensor,
-                   target_area_indices: torch.Tensor, ray_extinction_factor: float = 0.0,
-                   mirror_reflectivity: float = 0.935, device: torch.device | None = None
-                   ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-        """Heliostat ray tracing (:220-508).  Returns ``(flux [H,res_u,res_e], intercept_factor [H],
-        on_target_factor [H], blocking_factor [H])`` for the heliostat samples owned by this rank."""
+    def _trace(self, incident_ray_directions, active_heliostats_mask, target_area_indices, ray_extinction_factor,
+               mirror_reflectivity, device, per_target: bool):
+        """The one place that assembles a trace call: alignment check, the rank's rows of every per-heliostat tensor, the
+        tower's tables, the blocking rectangles.  ``per_target``: splat into the targets' bitmaps instead of the heliostats'."""
         group = self.heliostat_group
         # (the same tensor object needs no device comparison: one host-device synchronisation less per epoch)
         assert group.active_heliostats_mask is active_heliostats_mask or \
@@ -202,7 +200,7 @@ class HeliostatRayTracer:
 
         points, normals = group.active_surface_points, group.active_surface_normals
         device = points.device if device is None else torch.device(device)
-        if self.publish_reflection_directions:
+        if self.publish_reflection_directions and not per_target:
             with torch.no_grad():
                 group.preferred_reflection_directions = reflect(incident_ray_directions.unsqueeze(1), normals)
 
@@ -214,17 +212,24 @@ class HeliostatRayTracer:
             incident_ray_directions = incident_ray_directions.index_select(0, idx)
             target_area_indices = target_area_indices.index_select(0, idx)
 
-        ray_magnitude = float(self.ray_magnitude)
         width, height = self._resolution_host
-        planar = _planar_tables(tower, points.device)
         flux, factors, flags = ops.TraceRays.apply(
-            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
-            ray_magnitude, float(ray_extinction_factor), float(mirror_reflectivity), width, height, False,
+            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *_planar_tables(tower, points.device),
+            float(self.ray_magnitude), float(ray_extinction_factor), float(mirror_reflectivity), width, height, bool(per_target),
             _cylinder_tables(tower), *(self._blocking_arguments(idx, active_heliostats_mask) or (None, None, None, None, -1.0, True)),
             self._points_per_facet(points))
         if self.blocking_active:
             self._filter_flags, self._filtered = flags, None       # (indices on demand: nonzero() waits for the device)
         return flux, factors[0], factors[1], factors[2]
+
+    def trace_rays(self, incident_ray_directions: torch.Tensor, active_heliostats_mask: torch.Tensor,
+                   target_area_indices: torch.Tensor, ray_extinction_factor: float = 0.0,
+                   mirror_reflectivity: float = 0.935, device: torch.device | None = None
+                   ) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Heliostat ray tracing (:220-508).  Returns ``(flux [H,res_u,res_e], intercept_factor [H],
+        on_target_factor [H], blocking_factor [H])`` for the heliostat samples owned by this rank."""
+        return self._trace(incident_ray_directions, active_heliostats_mask, target_area_indices, ray_extinction_factor,
+                           mirror_reflectivity, device, per_target=False)
 
     @property
     def filtered_blocking_primitive_indices(self):
@@ -253,7 +258,7 @@ class HeliostatRayTracer:
     def _points_per_facet(self, points) -> int:
         """The group's surface tensors are facet-major ``[H, F * M, 4]`` (heliostat_group.py:26-63): tell the kernels M, so
         that a block of points never holds two facets' images (a layout hint - results do not depend on it)."""
-        if os.environ.get("ARTIST_AMD_FACET_HINT", "1") == "0":      # A/B switch
+        if os.environ.get("ARTIST_HIP_DEBUG") == "1" and os.environ.get("ARTIST_AMD_FACET_HINT", "1") == "0":      # A/B switch (debug only)
             return 0
         facets = int(getattr(self.heliostat_group, "number_of_facets_per_heliostat", 0) or 0)
         n_points = int(points.shape[1])
@@ -310,30 +315,8 @@ class HeliostatRayTracer:
         heliostat's rays are splatted straight into its target's bitmap (``[T,res_u,res_e]``, planar areas
         first, cylindrical second).  Extension of the reference API for field-scale flux prediction
         (configs 3 and 5)."""
-        group = self.heliostat_group
-        # (the same tensor object needs no device comparison: one host-device synchronisation less per epoch)
-        assert group.active_heliostats_mask is active_heliostats_mask or \
-            torch.equal(group.active_heliostats_mask, active_heliostats_mask), \
-            "Some heliostats were not aligned and cannot be raytraced."
-        points, normals = group.active_surface_points, group.active_surface_normals
-        device = points.device if device is None else torch.device(device)
-        tower = self.scenario.solar_tower
-        self._validate_targets(target_area_indices, tower)
-        idx, dist_u, dist_e = self._local_rows(device)
-        if idx is not None:
-            points, normals = points.index_select(0, idx), normals.index_select(0, idx)
-            incident_ray_directions = incident_ray_directions.index_select(0, idx)
-            target_area_indices = target_area_indices.index_select(0, idx)
-        width, height = self._resolution_host
-        planar = _planar_tables(tower, points.device)
-        flux, factors, flags = ops.TraceRays.apply(
-            points, normals, incident_ray_directions, dist_u, dist_e, target_area_indices, *planar,
-            float(self.ray_magnitude), float(ray_extinction_factor), float(mirror_reflectivity), width, height, True,
-            _cylinder_tables(tower), *(self._blocking_arguments(idx, active_heliostats_mask) or (None, None, None, None, -1.0, True)),
-            self._points_per_facet(points))
-        if self.blocking_active:
-            self._filter_flags, self._filtered = flags, None       # (indices on demand: nonzero() waits for the device)
-        return flux, factors[0], factors[1], factors[2]
+        return self._trace(incident_ray_directions, active_heliostats_mask, target_area_indices, ray_extinction_factor,
+                           mirror_reflectivity, device, per_target=True)
 
     def get_bitmaps_per_target(self, bitmaps_per_heliostat: torch.Tensor, target_area_indices: torch.Tensor,
                                device: torch.device | None = None) -> torch.Tensor:

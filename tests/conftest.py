@@ -15,6 +15,11 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = ROOT / "tests" / "golden"
 
+# The library reads its ARTIST_HIP_* knobs (launch geometry, A/B bodies: the tests that show results do not depend on them
+# set them) only in debug mode; tests/test_gpu_boundary.py::test_knobs_are_ignored_outside_debug_mode covers the other case.
+import os  # noqa: E402
+os.environ.setdefault("ARTIST_HIP_DEBUG", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

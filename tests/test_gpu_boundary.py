@@ -368,3 +368,36 @@ def test_launch_event_recorder_brackets_the_trace_calls(golden):
     for pairs in rec.values():
         for start, end in pairs:
             assert 0.0 < start.elapsed_time(end) < 1e3
+
+
+def test_knobs_are_ignored_outside_debug_mode(golden, monkeypatch, capfd):
+    """The launch-geometry / A-B knobs of the library (ARTIST_HIP_*) are read only when ARTIST_HIP_DEBUG=1: a caller's environment
+    cannot change what the product launches (round-3 review: 25 variables were read unconditionally).  Shown with the knob that
+    is visible from outside, ARTIST_HIP_PRINT_GEOMETRY (one line on stderr per trace call), and with ARTIST_HIP_FWD=global,
+    which selects another kernel (results differ in the last bits from the windowed one)."""
+    from test_gpu_parity import n, trace_inputs
+
+    from artist_amd import trace_rays
+    inp = trace_inputs(golden("mid_256"))
+    monkeypatch.setenv("ARTIST_HIP_DEBUG", "1")
+    monkeypatch.delenv("ARTIST_HIP_PRINT_GEOMETRY", raising=False)
+    monkeypatch.delenv("ARTIST_HIP_FWD", raising=False)
+    base = n(trace_rays(**inp)[0])
+    torch.cuda.synchronize()
+    capfd.readouterr()
+    monkeypatch.setenv("ARTIST_HIP_PRINT_GEOMETRY", "1")
+    monkeypatch.setenv("ARTIST_HIP_FWD", "global")
+    debug = n(trace_rays(**inp)[0])
+    torch.cuda.synchronize()
+    capfd.readouterr()
+    monkeypatch.setenv("ARTIST_HIP_FWD", "lds")
+    trace_rays(**inp)
+    torch.cuda.synchronize()
+    assert "art_trace_fwd:" in capfd.readouterr().err                     # debug mode: the knob is honoured
+    monkeypatch.setenv("ARTIST_HIP_FWD", "global")
+    monkeypatch.setenv("ARTIST_HIP_DEBUG", "0")
+    plain = n(trace_rays(**inp)[0])
+    torch.cuda.synchronize()
+    assert "art_trace_fwd:" not in capfd.readouterr().err                 # product mode: ignored
+    np.testing.assert_array_equal(plain, base)                             # ... the windowed kernel ran, not the global-atomic one
+    assert np.abs(debug - base).max() <= 1e-5 * np.abs(base).max()

@@ -9,8 +9,8 @@ if [ "$1" = build ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; defs=$(echo ${v#*:} | tr ',' ' ')
     ( cd artist_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize \
-        $defs -c trace_kernels.hip -o /tmp/abl_$name.o &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/libabl_$name.so /tmp/abl_$name.o blocking_kernels.o flux_kernels.o nurbs_kernels.o align_kernels.o kinematics_kernels.o capi.o ) &
+        $defs -I. -c ../../tools/diag/trace_kernels_diag.hip -o /tmp/abl_$name.o &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/bin/libabl_$name.so /tmp/abl_$name.o blocking_kernels.o flux_kernels.o nurbs_kernels.o align_kernels.o kinematics_kernels.o optim_kernels.o capi.o ) &
   done
   wait
   exit 0

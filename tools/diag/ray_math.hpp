@@ -389,7 +389,11 @@ __device__ __forceinline__ CylHit cyl_hit(const Cyl& cy, const CylPoint& p, floa
     h.b = 2.0f * (p.ox * h.dx + p.oy * h.dy);                                    // :319
     const float disc = h.b * h.b - (4.0f * h.a) * p.c;                           // :322
     const bool mask = (disc >= 0.0f) && (fabsf(h.a) > 1e-8f);                    // :326
+#ifdef ART_CYL_IEEE_SQRT             // A/B build: the generic sequence
+    h.sq = sqrtf(disc * (mask ? 1.0f : 0.0f) + 1e-12f);                          // :336
+#else
     h.sq = sqrt_noscale(disc * (mask ? 1.0f : 0.0f) + 1e-12f);                   // :336
+#endif
     const float two_a = 2.0f * h.a;
     // (the quotients of this function are div_noscale: the IEEE quotient bit for bit while operands and quotient stay in the
     //  normal range - metres over metres here; a ray (almost) parallel to the axis, whose quotient may leave it, is masked by
@@ -400,7 +404,9 @@ __device__ __forceinline__ CylHit cyl_hit(const Cyl& cy, const CylPoint& p, floa
     // it - skips the second IEEE division.  Where it is computed it is the reference's value; elsewhere "+inf" selects the near
     // root exactly as the real value would.
     float tf = __builtin_inff();
+#ifndef ART_CYL_BOTH_ROOTS          // A/B build
     if (wave_any(!(tn > 0.0f)))
+#endif
         tf = div_noscale(-h.b + h.sq, two_a);
     tn = tn > 0.0f ? tn : __builtin_inff();                                      // :351-355
     tf = tf > 0.0f ? tf : __builtin_inff();
@@ -411,12 +417,24 @@ __device__ __forceinline__ CylHit cyl_hit(const Cyl& cy, const CylPoint& p, floa
     h.t = t;
     h.x = p.ox + t * h.dx; h.y = p.oy + t * h.dy;                                // :374-381
     float z = p.oz + t * h.dz;
+#ifdef ART_CYL_IEEE_SQRT
+    h.rho = sqrtf(h.x * h.x + h.y * h.y);                                        // :384-385
+#else
     h.rho = sqrt_noscale(h.x * h.x + h.y * h.y);                                 // :384-385
+#endif
+#ifdef ART_CYL_IEEE_DIV              // A/B build: the generic division sequence
+    h.nx = h.x / h.rho; h.ny = h.y / h.rho;
+#else
     h.nx = div_noscale(h.x, h.rho); h.ny = div_noscale(h.y, h.rho);
+#endif
     const float dot = (-h.dx) * h.nx + (-h.dy) * h.ny;                           // :388-390 (z term is +-0)
     h.abi = dot < 0.0f ? 0.0f : dot;                                             // clamp(min=0); NaN passes through
     z = z + cy.half_height;                                                      // :397
+#ifdef ART_CYL_LIBM_ATAN2            // A/B build
+    const float ang = atan2f(h.y, h.x) - cy.ang0;                                // :399-405
+#else
     const float ang = atan2_poly(h.y, h.x) - cy.ang0;                            // :399-405
+#endif
     const bool on = (z >= 0.0f) && (z <= cy.height) && (ang >= 0.0f) && (ang <= cy.opening);   // :407-412
     h.ok = on && hit;
     const float m = h.ok ? 1.0f : 0.0f;
@@ -543,7 +561,11 @@ __device__ __forceinline__ bool soft_plane(const Prim& q, float ox, float oy, fl
     const float num = have_num ? num_in : soft_plane_num(q, ox, oy, oz);
     // (the IEEE quotient without the generic sequence's range scaling: |den_safe| >= 1e-12 and |num| is a distance in
     //  metres, so neither operand nor quotient leaves the normal range - bit-identical, see div_noscale)
+#ifdef ART_OLD_SOFT_DIV
+    s.d = num / s.den_safe;
+#else
     s.d = div_noscale(num, s.den_safe);
+#endif
     return s.d > kBlockOffset - kBlockMargin;
 }
 
@@ -555,8 +577,13 @@ __device__ __forceinline__ void soft_uv(const Prim& q, float ox, float oy, float
     s.pv = (s.offx * q.svx + s.offy * q.svy) + s.offz * q.svz;
     // (division by a per-rectangle constant whose correctly rounded reciprocal is in the table: the IEEE quotient, bit for
     //  bit, in three instructions - div_const)
+#ifdef ART_OLD_SOFT_DIV
+    s.u = (s.pu * q.svv - s.pv * q.suv) / q.det_safe;
+    s.v = (s.pv * q.suu - s.pu * q.suv) / q.det_safe;
+#else
     s.u = div_const(s.pu * q.svv - s.pv * q.suv, q.det_safe, q.inv_det);
     s.v = div_const(s.pv * q.suu - s.pu * q.suv, q.det_safe, q.inv_det);
+#endif
     // NaN coordinates (degenerate rectangle) fail the comparisons and are skipped; the reference would carry NaN
     s.near = in_front && s.u > -kBlockMargin && s.u < 1.0f + kBlockMargin && s.v > -kBlockMargin &&
              s.v < 1.0f + kBlockMargin;
@@ -649,6 +676,9 @@ __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ pri
 {
     float sum = 0.0f;
     near = 0u;
+#ifdef ART_ABLATE_BLOCK_STAGE0
+    wave_mask = 0u;
+#endif
     [[maybe_unused]] int it = 0;
     for (unsigned m = wave_mask; m != 0u; m &= m - 1u) {
         const int k = __builtin_ctz(m);
@@ -660,8 +690,14 @@ __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ pri
             ++it;
         } else
         in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s) && ((mask >> k) & 1u);
+#ifdef ART_ABLATE_BLOCK_STAGE1
+        sum += in_front ? 1e-30f : 0.0f; continue;
+#endif
         if (!wave_any(in_front)) continue;
         soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, s);
+#ifdef ART_ABLATE_BLOCK_STAGE2
+        sum += s.near ? 1e-30f : 0.0f; continue;
+#endif
         if (!wave_any(s.near)) continue;
         SoftSig g;
         const float sg = soft_sigma(s, g);

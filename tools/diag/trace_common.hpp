@@ -98,6 +98,10 @@ template <bool INTERLEAVED>
 __device__ __forceinline__ void load_dist_row(const float* __restrict__ row_u, const float* __restrict__ row_e,
                                               int lane_off, float& u, float& e)
 {
+#ifdef ART_ABLATE_NO_LOADS   // diagnostic build: synthesise angles in registers, no HBM stream
+    u = 1e-6f * (float)(lane_off & 1023); e = -1e-6f * (float)((lane_off >> 3) & 1023);
+    return;
+#endif
     if constexpr (INTERLEAVED) {
         const float2 v = *reinterpret_cast<const float2*>(row_u + lane_off);
         u = v.x; e = v.y;
@@ -112,17 +116,29 @@ template <bool INTERLEAVED>
 __device__ __forceinline__ void load_dist_stream(const float* __restrict__ row_u, const float* __restrict__ row_e,
                                                  int lane_off, float& u, float& e)
 {
+#ifdef ART_ABLATE_NO_LOADS
+    u = 1e-6f * (float)(lane_off & 1023); e = -1e-6f * (float)((lane_off >> 3) & 1023);
+    return;
+#endif
     typedef float v2f __attribute__((ext_vector_type(2)));
     // scalar base + zero-extended 32-bit byte offset: the form `global_load ... v_off, s[base:base+1]` takes without any
     // 64-bit vector arithmetic (lane_off >= 0: an element offset inside one heliostat's row)
     const unsigned byte_off = (unsigned)lane_off * 4u;
     const char* pu = reinterpret_cast<const char*>(row_u) + byte_off;
     if constexpr (INTERLEAVED) {
+#ifdef ART_STREAM_PLAIN_LOADS
+        const v2f v = *reinterpret_cast<const v2f*>(pu);
+#else
         const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(pu));
+#endif
         u = v.x; e = v.y;
     } else {
         const char* pe = reinterpret_cast<const char*>(row_e) + byte_off;
+#ifdef ART_STREAM_PLAIN_LOADS
+        u = *reinterpret_cast<const float*>(pu); e = *reinterpret_cast<const float*>(pe);
+#else
         u = __builtin_nontemporal_load(reinterpret_cast<const float*>(pu)); e = __builtin_nontemporal_load(reinterpret_cast<const float*>(pe));
+#endif
     }
 }
 
@@ -164,9 +180,10 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
 
 // Largest angle between a scattered ray and its point's chief ray: the two rotations of rotate_distortions compose
 // to at most sqrt(2) x the larger angle (+ slack).  A negative bound = unknown: the per-point cone test accepts all.
+static inline int env_int(const char* name, int dflt);
 static inline void set_cone(TraceArgs& a, double max_scatter_angle)
 {
-    a.slab_cull = debug_env_int("ARTIST_HIP_BLOCK_SLABS", 1) != 0;     // 0: sphere test only (diagnostic; same results)
+    a.slab_cull = env_int("ARTIST_HIP_BLOCK_SLABS", 1) != 0;     // 0: sphere test only (diagnostic; same results)
     if (max_scatter_angle < 0.0) { a.cone_cos = a.cone_sin = 0.0f; return; }
     double theta = 1.4143 * max_scatter_angle * 1.001 + 1e-4;
     if (theta > 1.5) { a.cone_cos = a.cone_sin = 0.0f; return; }
@@ -180,6 +197,11 @@ static inline bool interleaved_layout(const TraceArgs& a)
 }
 
 
+static inline int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 
 // Device status word: 4 bytes of mapped host memory per GPU, allocated on the first trace call and kept.  Kernels set

@@ -417,6 +417,18 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
 }
 
 // Blocking rectangles of one heliostat in LDS (empty when the kernel is instantiated without blocking).
+#ifdef ART_DEBUG_TIMELINE   // diagnostic build (tools/timeline.sh): phase time stamps of every forward workgroup
+constexpr int kTimelineSlots = 16384;
+__device__ unsigned long long g_timeline[8 * kTimelineSlots];
+__device__ __forceinline__ void timeline_mark(int slot, int k)
+{
+    if (threadIdx.x == 0 && slot < kTimelineSlots) g_timeline[8 * slot + k] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+}
+#define ART_TIMELINE(k) timeline_mark(bid, k)
+#else
+#define ART_TIMELINE(k)
+#endif
+
 // (grad is DOUBLE: on gfx950 ds_add_f64 retires a wave instruction in ~25 cycles, ds_add_f32 in ~193 - tools/lds_atomic_bench.hip)
 // (GRAD = false: the forward items - no gradient sums, 3 KB less static LDS: room for 4 KB more window)
 template <bool BLOCKING, bool GRAD = true> struct PrimTable { Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; double grad[GRAD ? kMaxCand * 12 : 1]; };
@@ -601,6 +613,15 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
     // ---- phase 1: window ---------------------------------------------------------------------
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |   // XCC_ID
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                         // HW_ID
+#endif
+    ART_TIMELINE(1);
+#ifdef ART_DEBUG_TIMELINE
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();       // shader clock
+#endif
     if (tid < 3) s_cnt[tid] = 0;
     // This thread's first point and its first distortion sample are requested before anything else, and the tile is
     // cleared while they are in flight: a CU holds ONE workgroup (the window fills its LDS), so every microsecond of
@@ -619,6 +640,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     const int n_prims = load_prims<BLOCKING, false>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
+    ART_TIMELINE(2);
     // (an empty window - no chief ray reaches the target - must hold no ray: bounds of 0, not of (unsigned)-1)
     const unsigned twm1 = (unsigned)max(win.tw - 1, 0), uthm1 = (unsigned)max(win.th - 1, 0);
     const int dummy = a.tile_cap;                    // two spare cells: [tile_cap], [tile_cap + 1]
@@ -641,6 +663,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
         for (int i = tid; i < npx; i += blockDim.x) tile[i] = 0u;
         __syncthreads();
     }
+    ART_TIMELINE(3);
 
     // ---- phase 2: trace ----------------------------------------------------------------------
     // Every ray issues its four LDS adds unconditionally: rays that are off the bitmap or outside the
@@ -731,15 +754,23 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
             ps.q1 = cvt_nearest_u32(cle * chu * Is); ps.q2 = cvt_nearest_u32(che * chu * Is);
             ps.q3 = cvt_nearest_u32(che * clu * Is); ps.q4 = cvt_nearest_u32(cle * clu * Is);
             ps.ie = ie; ps.iu = iu;
+#ifdef ART_ABLATE_NO_LDS_ATOMICS   // diagnostic build: keep the operands alive, skip the LDS traffic
+            asm volatile("" ::"v"(cell_hi), "v"(cell_lo), "v"(ps.q1), "v"(ps.q2), "v"(ps.q3), "v"(ps.q4));
+#else
             ps.o1 = atomicAdd(tile + cell_hi, ps.q1);
             ps.o2 = atomicAdd(tile + cell_hi + 1, ps.q2);
             ps.o3 = atomicAdd(tile + cell_lo + 1, ps.q3);
             ps.o4 = atomicAdd(tile + cell_lo, ps.q4);
+#endif
             if (__builtin_expect((m_valid & ~m_inwin) != 0ull, 0)) {
                 // valid but not in this pass's band: another band's ray, the last pixel row/column
                 // (heliostat_ray_tracer.py:723-728), or a stray of the union window -> global atomics, once
                 const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
                 const bool in_union = (unsigned)le < twm1 && (unsigned)(iu - win.u0) < uthm1;
+#ifdef ART_DEBUG_COUNT_STRAYS    // diagnostic build: factors row 2 = share of stray rays
+                if (first) n_free += __popcll(__builtin_amdgcn_ballot_w64(valid && on && !in_union));
+#endif
+#ifndef ART_ABLATE_NO_STRAYS   // diagnostic build drops the stray rays (wrong bitmap) to price them
                 if (first && valid && on && !in_union) {
                     unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
                     unsigned long long* row_lo = row_hi + a.W;
@@ -747,6 +778,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
                     atomicAdd(row_hi, cell_to_accum(cle * chu * Iss)); atomicAdd(row_hi + 1, cell_to_accum(che * chu * Iss));
                     atomicAdd(row_lo + 1, cell_to_accum(che * clu * Iss)); atomicAdd(row_lo, cell_to_accum(cle * clu * Iss));
                 }
+#endif
             }
         };
         // Distortion stream, software-prefetched in groups of four samples: the loads of group g+1 are issued
@@ -763,6 +795,9 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
         load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(2, nr - 1) * a.sr, be_ + (int64_t)min(2, nr - 1) * a.sr, lane_off, cu2, ce2);
         load_dist_row<INTERLEAVED>(bu_ + (int64_t)min(3, nr - 1) * a.sr, be_ + (int64_t)min(3, nr - 1) * a.sr, lane_off, cu3, ce3);
         for (int k = 0; k < nr; k += 4) {
+#ifdef ART_DEBUG_TIMELINE
+            if (k == 4 && p == p0 && tid == 0) { asm volatile("s_waitcnt vmcnt(0)"); ART_TIMELINE(4); }   // first group traced
+#endif
             float nu0, ne0, nu1, ne1, nu2, ne2, nu3, ne3;
             const int64_t o4 = (int64_t)min(k + 4, nr - 1) * a.sr, o5 = (int64_t)min(k + 5, nr - 1) * a.sr;
             const int64_t o6 = (int64_t)min(k + 6, nr - 1) * a.sr, o7 = (int64_t)min(k + 7, nr - 1) * a.sr;
@@ -791,9 +826,14 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
     resolve_carries(ps, acc, a.W, a.Hh, win.shift);
     if (first && lane == 0) {                                                           // wave totals
         atomicAdd(&s_cnt[0], lean ? n_valid : n_int); atomicAdd(&s_cnt[1], n_valid);
+#ifdef ART_DEBUG_COUNT_STRAYS
+        atomicAdd(&s_cnt[2], n_free);
+#else
         if constexpr (BLOCKING) atomicAdd(&s_cnt[2], n_free);
+#endif
     }
     __syncthreads();
+    ART_TIMELINE(5);
     // the next work item is requested now and published after the flush: the counter's round trip hides behind it
     unsigned next_item = 0u;
     if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
@@ -804,11 +844,19 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
         const unsigned* trow = tile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) {
             const unsigned q = trow[c];
+#ifdef ART_ABLATE_NO_FLUSH      // diagnostic build: price the global atomics of the flush (wrong bitmap)
+            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (unsigned long long)q << win.shift);
+#else
             if (q != 0u) atomicAdd(g + c, (unsigned long long)q << win.shift);
+#endif
         }
     }
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();   // the band is flushed before the next pass re-zeroes the tile
+    ART_TIMELINE(6);
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots) g_timeline[8 * bid + 7] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
   }
     if (tid < 3 && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
@@ -916,10 +964,14 @@ __device__ __forceinline__ void pack_edge_points(const TraceArgs& a, const Plane
     }
 }
 
-// ring depth = 8: forward: 2 / 4 / 6 / 8 slots (4 costs the forward 4 %)
-// ring depth bwd = 2: backward: same-box sweep 8 / 6 / 4 / 2 slots = 3.76 / 3.71 / 3.67 / 3.65 ms (125 heliostats: 0.517 -> 0.489):
-// with twelve waves of 0.7 us ray steps the stream's latency is covered anyway, and a stray's
-// vmcnt(0) has less to wait for
+#ifndef ART_RING_DEPTH
+#define ART_RING_DEPTH 8       // forward: 2 / 4 / 6 / 8 slots (4 costs the forward 4 %)
+#endif
+#ifndef ART_RING_DEPTH_BWD
+#define ART_RING_DEPTH_BWD 2   // backward: same-box sweep 8 / 6 / 4 / 2 slots = 3.76 / 3.71 / 3.67 / 3.65 ms (125 heliostats: 0.517 -> 0.489):
+                               // with twelve waves of 0.7 us ray steps the stream's latency is covered anyway, and a stray's
+                               // vmcnt(0) has less to wait for
+#endif
 // BLOCKING: the same item with the soft blocking mask (blocking.py:212-354) of the heliostat's candidate rectangles in every
 // ray - the launch of a split call that owns the heliostats WITH candidates.  What changes against the plain lean item: the
 // rectangle tables in LDS, a bitmask per point of the rectangles its scatter cone can touch, `keep` = 1 - blocked in the ray's
@@ -960,6 +1012,15 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
     // ---- phase 1: window (as in the generic item) ------------------------------------------------
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+    ART_TIMELINE(1);
+#ifdef ART_DEBUG_TIMELINE
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();       // shader clock
+#endif
     if (tid < 3) s_cnt[tid] = 0;
     const int pf = (a.win_sample != 0 && p1 - p0 > (int)blockDim.x) ? window_sample_point(p0, p1) : p0 + tid;
     FirstPoint fp = {{0.0f, 0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f, 0.0f}, 0.0f, 0.0f};
@@ -975,6 +1036,13 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const int n_prims = load_prims<BLOCKING, false>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
+    ART_TIMELINE(2);
+#ifdef ART_DEBUG_TIMELINE      // (lean items: slots 3, 4 hold the item's stray rays | un-park events, and its window (tw, th, npass))
+    __shared__ unsigned s_dbg[2];
+    if (tid < 2) s_dbg[tid] = 0u;
+    unsigned dbg_strays = 0u, dbg_unparks = 0u;
+    if (tid == 0 && bid < kTimelineSlots) g_timeline[8 * bid + 4] = ((unsigned long long)win.npass << 40) | ((unsigned long long)win.tw << 20) | (unsigned)win.th;
+#endif
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     // (Packing the edge points into the block's last waves, which takes 8 % off the backward kernel, was measured here too:
     //  3.25 -> 3.32 ... 3.43 ms for margins of 1/4 ... 3/4 of the scatter pad - a stray costs this kernel its atomics, which
@@ -1029,8 +1097,13 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 const float wa = chu * Is, wb = clu * Is;                                      // the same integers reach the bitmap
                 unsigned long long* row_hi = acc + (int64_t)(a.Hh - 2 - (int)tbu) * a.W + (int)tbe;   // flat row iu + 1, flipped
                 unsigned long long* row_lo = row_hi + a.W;
+#ifdef ART_ABLATE_NO_STRAY_ATOMICS     // diagnostic build (wrong bitmap): everything but the four atomics
+                unsigned long long q1 = cell_to_accum(cle * wa), q2 = cell_to_accum(che * wa), q3 = cell_to_accum(che * wb), q4 = cell_to_accum(cle * wb);
+                asm volatile("" ::"v"(row_hi), "v"(row_lo), "v"(q1), "v"(q2), "v"(q3), "v"(q4));
+#else
                 atomicAdd(row_hi, cell_to_accum(cle * wa)); atomicAdd(row_hi + 1, cell_to_accum(che * wa));
                 atomicAdd(row_lo + 1, cell_to_accum(che * wb)); atomicAdd(row_lo, cell_to_accum(cle * wb));
+#endif
             }
         }
         m_parked = 0ull;
@@ -1108,7 +1181,11 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             const float lef = tbe - e0f, luf = tbu - pu0f;                     // window coordinates of the low pixel
             const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
             if constexpr (!CYL) n_valid += __popcll(m_valid);
+#ifdef ART_CLAMP_MASKED_RAYS          // A/B build: round 2's address rule (masked rays clamped onto the window's first / last cell)
+            const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
+#else
             const float af = select_mask(m_in, fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), own_cell_f);
+#endif
             const unsigned addr_lo = (unsigned)af;
             const unsigned addr_up = addr_lo + tw4p;                           // flat row iu + 1
             float ahk = ah;                                                    // the direction cosine, attenuated by the blocking mask
@@ -1119,7 +1196,11 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 float blocked = 0.0f, keep = 1.0f;
                 if (wmask != 0u) {
                     unsigned near;
+#ifdef ART_BLOCK_NUM_PER_RAY       // A/B build
+                    blocked = 1.0f - soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
+#else
                     blocked = 1.0f - soft_transmittance<true>(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1);
+#endif
                     keep = 1.0f - blocked;
                 }
                 n_free += __popcll(ballot64(blocked < 1e-3f) & live);
@@ -1135,10 +1216,21 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             ptbe = tbe; ptbu = tbu;
             lds_u32* up = (lds_u32*)(size_t)addr_up;
             lds_u32* lo = (lds_u32*)(size_t)addr_lo;
+#ifdef ART_ABLATE_NO_LDS_ATOMICS   // diagnostic build: keep the operands alive, skip the LDS traffic
+            asm volatile("" ::"v"(up), "v"(lo), "v"(pq1), "v"(pq2), "v"(pq3), "v"(pq4));
+#else
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(ART_EXP_SETPRIO);
+#endif
             po1 = __hip_atomic_fetch_add(up, pq1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             po2 = __hip_atomic_fetch_add(up + 1, pq2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             po3 = __hip_atomic_fetch_add(lo + 1, pq3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             po4 = __hip_atomic_fetch_add(lo, pq4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
+#ifndef ART_ABLATE_NO_STRAYS       // diagnostic build drops the stray rays (wrong bitmap) to price them
             // Valid rays outside this pass's window: strays of the union window (or, when the footprint is swept in
             // bands, rays of another band; or rays on the last pixel row / column, heliostat_ray_tracer.py:723-728).
             // A stray lane PARKS its ray - pixel coordinates and direction cosine, three registers - and the wave moves
@@ -1150,12 +1242,16 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 if (!first) m_out = 0ull;
                 else if (win.npass > 1)                         // banded sweep: only what no band holds
                     m_out &= ~(win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(tbu - u0f) <= uthm2_bits));
+#ifdef ART_DEBUG_TIMELINE
+                if (lane == 0) { dbg_strays += __popcll(m_out); dbg_unparks += (m_out & m_parked) ? 1u : 0u; }
+#endif
                 if (m_out & m_parked) unpark();
                 pk_be = select_mask(m_out, be, pk_be); pk_bu = select_mask(m_out, bu, pk_bu); pk_ah = select_mask(m_out, ahk, pk_ah);
                 m_parked |= m_out;
             }
+#endif
         };
-        // The distortion stream: a ring of 8 (8) samples per thread, each slot re-requested the moment its value
+        // The distortion stream: a ring of ART_RING_DEPTH (8) samples per thread, each slot re-requested the moment its value
         // has been read, so that seven loads (3.5 KB per wave, 56 KB per CU) are in flight at every instant.  The ablation
         // builds (tools/ablate.sh) showed what round 1 missed: with the loads of a group of four issued only one group
         // ahead, the waves waited for this stream 40 % of the forward and 60 % of the backward kernel's time.
@@ -1171,32 +1267,48 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
             const int64_t step = next_r + 1 < nr ? a.sr : 0;
             bu_ += step; be_ += step; ++next_r;
         };
+#ifdef ART_LEAN_NO_RING          // A/B build: every sample requested where it is used
+        if (false) {
+#else
         if (nr >= 8) {
+#endif
             // Every step of a round runs unconditionally (no control flow re-defines a slot: a conditional step made the
             // compiler copy freshly requested slots around and wait for them at once); the rays that pad the last round
             // re-read sample nr - 1 and are masked out.
             [[maybe_unused]] float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
             request(0, su0, se0); request(1, su1, se1);
+#if ART_RING_DEPTH >= 4
             request(2, su2, se2); request(3, su3, se3);
+#endif
+#if ART_RING_DEPTH >= 6
             request(4, su4, se4); request(5, su5, se5);
+#endif
+#if ART_RING_DEPTH >= 8
             request(6, su6, se6); request(7, su7, se7);
+#endif
 #define ART_RING_STEP(j)                                                            \
             {                                                                       \
                 /* the slot's value moves to registers of its own first, so that the new request can land in the */ \
                 /* SAME registers: otherwise the slots rotate and the loop's back-edge has to copy (= wait for) all of them */ \
                 float u, e;                                                         \
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(u), "=v"(e) : "v"(su##j), "v"(se##j) : "memory"); \
-                request(k + j + 8, su##j, se##j);                      \
+                request(k + j + ART_RING_DEPTH, su##j, se##j);                      \
                 trace_one(u, e, k + j < nr ? ~0ull : 0ull);                          \
                 /* a ray's arithmetic stays inside its step: hoisting the next step's head above it made the */ \
                 /* compiler spill the ray's live values around the hoisted code */   \
                 __builtin_amdgcn_sched_barrier(0);                                  \
             }
-            for (int k = 0; k < nr; k += 8) {
+            for (int k = 0; k < nr; k += ART_RING_DEPTH) {
                 ART_RING_STEP(0) ART_RING_STEP(1)
+#if ART_RING_DEPTH >= 4
                 ART_RING_STEP(2) ART_RING_STEP(3)
+#endif
+#if ART_RING_DEPTH >= 6
                 ART_RING_STEP(4) ART_RING_STEP(5)
+#endif
+#if ART_RING_DEPTH >= 8
                 ART_RING_STEP(6) ART_RING_STEP(7)
+#endif
             }
 #undef ART_RING_STEP
         } else {
@@ -1220,6 +1332,9 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     __syncthreads();
     unsigned next_item = 0u;
     if (tid == 0 && pass == win.npass - 1) next_item = fetch_work_item(work_counter, a);
+#ifdef ART_DEBUG_TIMELINE       // (lean items: slot 7 = start of the flush)
+    if (first) ART_TIMELINE(7);
+#endif
 
     // ---- phase 3: flush ------------------------------------------------------------------------
     for (int row = wave; row < pth; row += nwaves) {
@@ -1227,13 +1342,25 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
         const unsigned* trow = tile + row * win.tw;
         for (int c = lane; c < win.tw; c += 64) {
             const unsigned q = trow[c];
+#ifdef ART_ABLATE_NO_FLUSH
+            if (q == 0xFFFFFFFFu) atomicAdd(g + c, (unsigned long long)q << win.shift);
+#else
             if (q != 0u) atomicAdd(g + c, (unsigned long long)q << win.shift);
+#endif
         }
     }
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();
   }
-       // (diagnostic build: the flush is not stamped apart from the trace here)
+    ART_TIMELINE(6);       // (diagnostic build: the flush is not stamped apart from the trace here)
+#ifdef ART_DEBUG_TIMELINE
+    if (lane == 0) { atomicAdd(&s_dbg[0], dbg_strays); atomicAdd(&s_dbg[1], dbg_unparks); }
+    __syncthreads();
+    if (tid == 0 && bid < kTimelineSlots) {
+        g_timeline[8 * bid + 3] = ((unsigned long long)s_dbg[1] << 32) | s_dbg[0];
+        g_timeline[8 * bid + 5] = __builtin_amdgcn_s_memtime() - clk0;             // shader clocks of the item
+    }
+#endif
     if (tid < (BLOCKING ? 3 : 2) && s_cnt[tid]) atomicAdd(&counts[tid * a.H + h], s_cnt[tid]);
 }
 
@@ -1372,7 +1499,11 @@ __device__ __forceinline__ void trace_fwd_item_field(const TraceArgs& a, unsigne
                     const unsigned long long m_valid = m_front & ballot64(f32_bits(be0) <= wm1_bits) & ballot64(f32_bits(bu) <= hm1_bits);
                     const unsigned long long m_in = m_front & win_ok & ballot64(f32_bits(lef) <= twm2_bits) & ballot64(f32_bits(luf) <= thm2_bits);
                     n_valid += __popcll(m_valid);
+#ifdef ART_CLAMP_MASKED_RAYS
+                    const float af = __builtin_amdgcn_fmed3f(fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), lds_base, addr_hi_f);
+#else
                     const float af = select_mask(m_in, fmaf(luf, tw4f, fmaf(lef, 4.0f, lds_base)), own_cell_f);
+#endif
                     const unsigned addr_lo = (unsigned)af;
                     const unsigned addr_up = addr_lo + tw4;
                     const float Is = select_or_zero(m_in, fabsf(ah) * kS);
@@ -1438,12 +1569,21 @@ struct FwdLaunch { TraceArgs a; float* flux; unsigned int* counts; unsigned int*
 constexpr bool kBlockingPersistentFwd = false, kBlockingPersistentBwd = true;
 constexpr bool kCylPersistentBwd = false;       // (measured neutral: 18.57 vs 18.43 ms)
 
-constexpr int kLeanFwdThreads = 1024;
-constexpr int kLeanBlockFwdThreads = 768;   // the lean body + the soft mask: 168 registers instead of 128
+#ifndef ART_LEAN_FWD_THREADS
+#define ART_LEAN_FWD_THREADS 1024
+#endif
+constexpr int kLeanFwdThreads = ART_LEAN_FWD_THREADS;
+#ifndef ART_LEAN_BLOCK_FWD_THREADS
+#define ART_LEAN_BLOCK_FWD_THREADS 768
+#endif
+constexpr int kLeanBlockFwdThreads = ART_LEAN_BLOCK_FWD_THREADS;   // the lean body + the soft mask: 168 registers instead of 128
 // the lean body + the cylinder hit: four waves per SIMD with 88 B of spills beat three without (same box, tools/cylinder_bench.py,
 // forward / forward + backward: 640 threads 6.86 / 14.2 ms, 768 5.61 / 12.6, 896 5.52 / 12.5, 1024 5.40 / 12.3; the blocking body:
 // 8.33, 7.26, 7.44, 7.18 ms forward - within the noise of the box from 768 on)
-constexpr int kLeanCylFwdThreads = 1024;
+#ifndef ART_LEAN_CYL_FWD_THREADS
+#define ART_LEAN_CYL_FWD_THREADS 1024
+#endif
+constexpr int kLeanCylFwdThreads = ART_LEAN_CYL_FWD_THREADS;
 constexpr int kCylFwdThreads = 1024;             // (768: within the noise of the box, 512: 17 % slower)
 // LEAN: 0 the generic item, 1 trace_fwd_item_lean, 2 trace_fwd_item_field (groups of heliostats, see there)
 template <bool INTERLEAVED, bool CYL, bool BLOCKING, int LEAN = 0>
@@ -1452,9 +1592,13 @@ __global__ __launch_bounds__(LEAN ? (BLOCKING ? kLeanBlockFwdThreads : (CYL ? kL
     static_assert(!LEAN || ((LEAN == 1 || (!BLOCKING && !CYL)) && !(BLOCKING && CYL)),
                   "the lean body serves planes, planes with blocking, or cylinders; the field item is planar without blocking");
     __shared__ int s_next, s_reverse;
+#ifdef ART_FWD_SINGLE_ITEM   // diagnostic build: one workgroup per item, no loop (A/B against the persistent form)
+    constexpr bool single_item = true;
+#else
     // The cylinder and blocking instantiations keep more values alive per ray; inside the persistent loop they spill
     // enough to lose 5-9 % (tools/blocking_bench.py, same-box A/B), so they take one item per workgroup.
     constexpr bool single_item = (CYL && LEAN == 0) || (BLOCKING && LEAN == 0 && !kBlockingPersistentFwd);
+#endif
     if constexpr (single_item) {
         int item = (int)blockIdx.x;
         if (item >= work_item_count(launch.a)) return;
@@ -1538,6 +1682,9 @@ __global__ void finalize_factors_kernel(float* factors, int H, float rays_per_he
     factors[h] = (float)n_int / rays_per_heliostat;
     factors[H + h] = (float)n_on / rays_per_heliostat;
     // blocking off: blocked == 0 everywhere
+#ifdef ART_DEBUG_COUNT_STRAYS
+    blocking = 1;
+#endif
     // (split launches: a heliostat with an empty candidate list went through the lean kernel, which does not count free rays)
     if (unblocked_if_empty != nullptr && unblocked_if_empty[h] == 0) blocking = 0;
     factors[2 * H + h] = (blocking ? (float)n_free : rays_per_heliostat) / rays_per_heliostat;
@@ -1701,6 +1848,7 @@ __device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSum
             out.ray.ox += g.ox; out.ray.oy += g.oy; out.ray.oz += g.oz;
             out.ray.rx += g.rx; out.ray.ry += g.ry; out.ray.rz += g.rz;
         }
+#ifndef ART_ABLATE_NO_BLOCK_ATOMICS
         // (lanes without a gradient contribute exact zeros - selected, not multiplied)
         const float part[12] = {on ? g.c0[0] : 0.f, on ? g.c0[1] : 0.f, on ? g.c0[2] : 0.f, on ? g.su[0] : 0.f, on ? g.su[1] : 0.f,
                                 on ? g.su[2] : 0.f, on ? g.sv[0] : 0.f, on ? g.sv[1] : 0.f, on ? g.sv[2] : 0.f, on ? g.n[0] : 0.f,
@@ -1711,15 +1859,21 @@ __device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSum
                 for (int c = 0; c < 12; ++c) point.v[c] += part[c];
                 continue;
             }
+#ifndef ART_ADJOINT_ONE_SLOT        // (A/B build: only the first rectangle)
             if (slot == 1) {
 #pragma unroll
                 for (int c = 0; c < 12; ++c) point2.v[c] += part[c];
                 continue;
             }
+#endif
         }
         const bool lo = lane == 2 * k, hi = lane == 2 * k + 1;
         const unsigned long long m_on = __builtin_amdgcn_ballot_w64(on);
+#ifdef ART_PRIM_TREE_ONLY
+        if (false) {
+#else
         if (__popcll(m_on) <= 4) {
+#endif
             // the usual case - one or two rays of the wave sit in this rectangle's soft edge: their twelve values are handed to
             // the owner lanes one ray after the other, in lane order (v_readlane: no reduction network)
             for (unsigned long long mm = m_on; mm != 0ull; mm &= mm - 1ull) {
@@ -1738,6 +1892,7 @@ __device__ __forceinline__ AdjointOut block_adjoint_body(LdsPrims prims, PrimSum
                 out.sums.v[c] += lo ? a_lo : (hi ? a_hi : 0.0f);
             }
         }
+#endif
     }
     return out;
 }
@@ -1847,9 +2002,18 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
+#ifdef ART_DEBUG_TIMELINE
+    const int bid = item.h * a.n_pblocks * a.n_rchunks + item.pblock * a.n_rchunks + item.r0 / max(a.r_chunk, 1);
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
+    ART_TIMELINE(1);
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
+    ART_TIMELINE(2);
     unsigned next_item = 0u;
     PrimSums prim_sums = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};               // this wave's rectangle gradients (see block_adjoint)
   for (int pass = 0; pass < win.npass; ++pass) {
@@ -1865,10 +2029,42 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     // waiting for memory.
     {
         const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;      // flat row k sits at gbase - k W
+#ifndef ART_STAGE_THROUGH_VGPRS
         stage_grad_window(G + gbase, a.W, win.tw, pth, gtile, wave, lane, nwaves);    // (round 3: LDS-direct loads, see there)
+#else
+        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+        const int64_t dg = (int64_t)nwaves * a.W;
+        const int dt = nwaves * win.tw;
+        const int tw4 = win.tw & ~3;                                         // columns covered by whole 16-byte loads
+        int rb = wave;
+        for (; rb + 3 * nwaves < pth; rb += 4 * nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = 4 * lane; c < tw4; c += 256) {
+                const F4 v0 = *reinterpret_cast<const F4*>(g0 + c), v1 = *reinterpret_cast<const F4*>(g0 + c - dg);
+                const F4 v2 = *reinterpret_cast<const F4*>(g0 + c - 2 * dg), v3 = *reinterpret_cast<const F4*>(g0 + c - 3 * dg);
+                float* t = t0 + c;
+                t[0] = v0.x; t[1] = v0.y; t[2] = v0.z; t[3] = v0.w;
+                t[dt] = v1.x; t[dt + 1] = v1.y; t[dt + 2] = v1.z; t[dt + 3] = v1.w;
+                t[2 * dt] = v2.x; t[2 * dt + 1] = v2.y; t[2 * dt + 2] = v2.z; t[2 * dt + 3] = v2.w;
+                t[3 * dt] = v3.x; t[3 * dt + 1] = v3.y; t[3 * dt + 2] = v3.z; t[3 * dt + 3] = v3.w;
+            }
+            if (lane < 4 * (win.tw - tw4)) {                                  // the last 1-3 columns of the four rows
+                const int q = lane / (win.tw - tw4), c = tw4 + lane % (win.tw - tw4);
+                t0[q * dt + c] = g0[c - q * dg];
+            }
+        }
+        for (; rb < pth; rb += nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = lane; c < win.tw; c += 64) t0[c] = g0[c];
+        }
+#endif
     }
     if (tid < 2) gtile[a.tile_cap + tid] = 0.0f;
     __syncthreads();
+    ART_TIMELINE(3);
+    ART_TIMELINE(4);
 
     const float kI = (a.mag * a.k_ext) * a.k_refl;
     float sx = 0.0f, sz = 0.0f;
@@ -1918,7 +2114,11 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
             auto mask_adjoint = [&]() {
                 if constexpr (BLOCKING) {
                     // only rays inside some rectangle's mask that still carry light have a gradient through it
+#ifdef ART_ABLATE_NO_BLOCK_ADJ
+                    const bool adj = false;
+#else
                     const bool adj = lane_live && near != 0u && g_keep != 0.0f && trans > 1e-30f;
+#endif
                     if (wave_any(adj)) {
                         const AdjointOut ao = block_adjoint((LdsPrims)s_tab.prim, prim_sums, wmask, adj ? near : 0u, o.x, o.y,
                                                             o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
@@ -1958,6 +2158,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
             if (__builtin_expect((__builtin_amdgcn_ballot_w64(valid) & ~__builtin_amdgcn_ballot_w64(inwin)) != 0ull, 0)) {
                 const bool on = (tbe + 1.0f < Wf) && (tbu + 1.0f < Hf);
                 const bool in_union = (unsigned)le < twm1 && (unsigned)(iu - win.u0) < uthm1;
+#ifndef ART_ABLATE_NO_STRAYS
                 if (first && valid && on && !in_union) {              // stray: global gather, once
                     const float* g_hi = G + (int64_t)(a.Hh - 2 - iu) * a.W + ie;
                     const float* g_lo = g_hi + a.W;
@@ -1966,6 +2167,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
                     asm volatile("" : "+v"(g1), "+v"(g2), "+v"(g3), "+v"(g4));
                     use = true;
                 }
+#endif
             }
             if constexpr (CYL) {
                 if (use) {     // divergent, but a masked ray's intermediates are not finite: no zero-weight trick here
@@ -2075,6 +2277,11 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
     }
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();   // every wave is done with this band before it is overwritten
+    ART_TIMELINE(5);
+    ART_TIMELINE(6);
+#ifdef ART_DEBUG_TIMELINE
+    if (tid == 0 && bid < kTimelineSlots) g_timeline[8 * bid + 7] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
   }
     if (win.npass < 1 && tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));   // (never: npass >= 1)
     if constexpr (BLOCKING) {
@@ -2157,9 +2364,17 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
+#ifdef ART_DEBUG_TIMELINE
+    const int bid = item.h * a.n_pblocks * a.n_rchunks + item.pblock * a.n_rchunks + item.r0 / max(a.r_chunk, 1);
+    if (tid == 0 && bid < kTimelineSlots)
+        g_timeline[8 * bid] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
+    ART_TIMELINE(1);
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
+    ART_TIMELINE(2);
     unsigned next_item = 0u;
     [[maybe_unused]] PrimSums prim_sums = {{0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};   // (blocking) this wave's rectangle gradients
     const float kI = (a.mag * a.k_ext) * a.k_refl;
@@ -2177,7 +2392,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const bool packed = !CYL && a.pack_edge != 0 && win.npass == 1 && n_pts <= kPackPoints && n_pts <= kPackTrips * (int)blockDim.x &&
                         win.tw >= 2 && win.th >= 2;
     if (packed) pack_edge_points(a, pl, inc, org, nrm, p0, n_pts, win, a.pack_edge, s_edge, perm);
-         // (diagnostic build: end of the edge partition; slot 5 is read out of order by tools/timeline_report.py)
+    ART_TIMELINE(5);         // (diagnostic build: end of the edge partition; slot 5 is read out of order by tools/timeline_report.py)
     [[maybe_unused]] const unsigned wm1_bits = f32_bits(pl.wm1), hm1_bits = f32_bits(pl.hm1);
     const float lds_base = (float)(unsigned)(size_t)(lds_f32*)gtile;
     const float e0f = (float)win.e0, tw4f = (float)(4 * win.tw), u0f = (float)win.u0;
@@ -2192,7 +2407,37 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         //  tools/timeline.sh; eight rows measured 3.65 against 3.53 ms for the kernel, twelve 4.4 - the batch's registers are
         //  allocated on top of the ray loop's)
         const int64_t gbase = (int64_t)(a.Hh - 1 - pu0) * a.W + win.e0;
+#ifndef ART_STAGE_THROUGH_VGPRS
         stage_grad_window(G + gbase, a.W, win.tw, pth, gtile, wave, lane, nwaves);
+#else
+        struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+        const int64_t dg = (int64_t)nwaves * a.W;
+        const int dt = nwaves * win.tw;
+        const int tw4c = win.tw & ~3;
+        int rb = wave;
+        for (; rb + 3 * nwaves < pth; rb += 4 * nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = 4 * lane; c < tw4c; c += 256) {
+                const F4 v0 = *reinterpret_cast<const F4*>(g0 + c), v1 = *reinterpret_cast<const F4*>(g0 + c - dg);
+                const F4 v2 = *reinterpret_cast<const F4*>(g0 + c - 2 * dg), v3 = *reinterpret_cast<const F4*>(g0 + c - 3 * dg);
+                float* tt_ = t0 + c;
+                tt_[0] = v0.x; tt_[1] = v0.y; tt_[2] = v0.z; tt_[3] = v0.w;
+                tt_[dt] = v1.x; tt_[dt + 1] = v1.y; tt_[dt + 2] = v1.z; tt_[dt + 3] = v1.w;
+                tt_[2 * dt] = v2.x; tt_[2 * dt + 1] = v2.y; tt_[2 * dt + 2] = v2.z; tt_[2 * dt + 3] = v2.w;
+                tt_[3 * dt] = v3.x; tt_[3 * dt + 1] = v3.y; tt_[3 * dt + 2] = v3.z; tt_[3 * dt + 3] = v3.w;
+            }
+            if (lane < 4 * (win.tw - tw4c)) {
+                const int q = lane / (win.tw - tw4c), c = tw4c + lane % (win.tw - tw4c);
+                t0[q * dt + c] = g0[c - q * dg];
+            }
+        }
+        for (; rb < pth; rb += nwaves) {
+            const float* __restrict__ g0 = G + gbase - (int64_t)rb * a.W;
+            float* t0 = gtile + rb * win.tw;
+            for (int c = lane; c < win.tw; c += 64) t0[c] = g0[c];
+        }
+#endif
     }
     // an empty window (no chief ray of the block reaches the target; or a degenerate one of a single row / column) holds no
     // ray: every valid ray is then a stray.  Its masked rays still READ two cells - clamped onto cells 0 and 1, see addr_hi_f -
@@ -2200,9 +2445,11 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     // the CU's previous workgroup left in its LDS may look like a NaN (0 x NaN = NaN in every gradient of the block: the
     // rare, box-dependent failure of tests/test_gpu_parity.py::test_random_scenes_split_calls[8-12-77-17-*] in round 3).
     const unsigned long long win_ok = (win.tw >= 2 && pth >= 2) ? ~0ull : 0ull;
+#ifndef ART_NO_EMPTY_WINDOW_FIX     // (diagnostic build: shows that tests/test_gpu_boundary.py::test_results_do_not_depend_on_what_the_lds_held_before fails without it)
     if (win_ok == 0ull && tid < 2) gtile[tid] = 0.0f;
+#endif
     __syncthreads();
-    if (first) { }      // (diagnostic build: window + edge partition | staging | trace)
+    if (first) { ART_TIMELINE(3); ART_TIMELINE(4); }      // (diagnostic build: window + edge partition | staging | trace)
 
     const float pu0f = (float)pu0;
     const unsigned thm2_bits = f32_bits((float)(pth - 2));
@@ -2233,6 +2480,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 wmask = wave_or_mask(pmask, n_prims);
             }
         }
+#ifndef ART_BLOCK_NUM_PER_RAY       // the plane numerators of the mask once per point, as in the forward item (A/B build: per ray)
         [[maybe_unused]] float bnum0 = 0.0f, bnum1 = 0.0f;
         if constexpr (BLOCKING) {
             if (wmask != 0u) {
@@ -2241,6 +2489,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 if (rest != 0u) bnum1 = soft_plane_num(s_tab.prim[__builtin_ctz(rest)], o.x, o.y, o.z);
             }
         }
+#endif
         auto trace_one = [&](const float u, const float e, const unsigned long long live) {
             // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
             // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
@@ -2281,8 +2530,15 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             const unsigned addr_lo = (unsigned)af;
             const lds_f32* lo = (const lds_f32*)(size_t)addr_lo;
             const lds_f32* up = (const lds_f32*)(size_t)(addr_lo + tw4);
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(ART_EXP_SETPRIO);
+#endif
             float g1 = up[0], g2 = up[1], g3 = lo[1], g4 = lo[0];
+#ifdef ART_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             unsigned long long m_use = m_in;
+#ifndef ART_ABLATE_NO_STRAYS
             if (__builtin_expect((m_valid & ~m_in) != 0ull, 0)) {
                 // valid, outside this pass's window: a stray of the union window gathers from global memory, once
                 const bool valid = (m_valid >> lane) & 1ull, inwin = (m_in >> lane) & 1ull;
@@ -2301,6 +2557,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 }
                 m_use |= ballot64(stray);
             }
+#endif
             if constexpr (CYL) {
                 if ((m_use >> lane) & 1ull) {     // divergent: a masked ray's intermediates are not finite, so no zero-weight trick here
 #pragma clang fp contract(fast)
@@ -2323,7 +2580,11 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 [[maybe_unused]] unsigned near = 0u;
                 if constexpr (BLOCKING) {
                     if (wmask != 0u) {
+#ifndef ART_BLOCK_NUM_PER_RAY
                         trans = soft_transmittance<true>(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1);
+#else
+                        trans = soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
+#endif
                         g_keep_scale = kIm * (-ah);                           // dI / d(keep) = mag (-a) k_ext k_refl for a ray in use
                         kIm *= 1.0f - (1.0f - trans);                         // keep, with the reference's rounding (blocked = 1 - trans)
                     }
@@ -2352,9 +2613,22 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                     const float g_keep = gI * g_keep_scale;
                     const bool adj = lane_live && near != 0u && g_keep != 0.0f && trans > 1e-30f;
                     if (wave_any(adj)) {
+#if defined(ART_ADJOINT_CALL)               // A/B builds: the round-3 call / the inlined body with every rectangle handed over ray by ray
+                        const AdjointOut ao = block_adjoint((LdsPrims)s_tab.prim, prim_sums, wmask, adj ? near : 0u, o.x, o.y, o.z, rx, ry,
+                                                            rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+#elif defined(ART_ADJOINT_PER_RAY)
+                        const AdjointOut ao = block_adjoint_body<false>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
+                                                                        o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+#else
+#ifndef ART_BLOCK_NUM_PER_RAY
                         const AdjointOut ao = block_adjoint_body<true>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
                                                                        o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f, bnum0, bnum1);
+#else
+                        const AdjointOut ao = block_adjoint_body<false>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
+                                                                        o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
+#endif
                         point_touched = true;
+#endif
                         prim_sums = ao.sums;
                         bgx += ao.ray.ox; bgy += ao.ray.oy; bgz += ao.ray.oz;
                         gdx += m.cu * ao.ray.rx + m.m10 * ao.ray.ry + m.m20 * ao.ray.rz;
@@ -2380,18 +2654,36 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         if (nr >= 8) {                                // the distortion ring of trace_fwd_item_lean
             [[maybe_unused]] float su0, se0, su1, se1, su2, se2, su3, se3, su4, se4, su5, se5, su6, se6, su7, se7;
             request(0, su0, se0); request(1, su1, se1);
+#if ART_RING_DEPTH_BWD >= 4
+            request(2, su2, se2); request(3, su3, se3);
+#endif
+#if ART_RING_DEPTH_BWD >= 6
+            request(4, su4, se4); request(5, su5, se5);
+#endif
+#if ART_RING_DEPTH_BWD >= 8
+            request(6, su6, se6); request(7, su7, se7);
+#endif
 #define ART_RING_STEP(j)                                                            \
             {                                                                       \
                 float u, e;                                                         \
                 asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(u), "=v"(e) : "v"(su##j), "v"(se##j) : "memory"); \
-                request(k + j + 2, su##j, se##j);                      \
+                request(k + j + ART_RING_DEPTH_BWD, su##j, se##j);                      \
                 trace_one(u, e, k + j < nr ? ~0ull : 0ull);                          \
                 /* a ray's arithmetic stays inside its step: hoisting the next step's head above it made the */ \
                 /* compiler spill the ray's live values around the hoisted code */   \
                 __builtin_amdgcn_sched_barrier(0);                                  \
             }
-            for (int k = 0; k < nr; k += 2) {
+            for (int k = 0; k < nr; k += ART_RING_DEPTH_BWD) {
                 ART_RING_STEP(0) ART_RING_STEP(1)
+#if ART_RING_DEPTH_BWD >= 4
+                ART_RING_STEP(2) ART_RING_STEP(3)
+#endif
+#if ART_RING_DEPTH_BWD >= 6
+                ART_RING_STEP(4) ART_RING_STEP(5)
+#endif
+#if ART_RING_DEPTH_BWD >= 8
+                ART_RING_STEP(6) ART_RING_STEP(7)
+#endif
             }
 #undef ART_RING_STEP
         } else {
@@ -2411,6 +2703,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                     const float a_lo = wave_reduce<kSum>(point_sums.v[c]), a_hi = wave_reduce<kSum>(point_sums.v[6 + c]);
                     prim_sums.v[c] += lane == 2 * k0 ? a_lo : (lane == 2 * k0 + 1 ? a_hi : 0.0f);
                 }
+#ifndef ART_ADJOINT_ONE_SLOT        // (A/B build: only the first rectangle)
                 const unsigned rest = wmask & (wmask - 1u);
                 if (rest != 0u) {
                     const int k1 = __builtin_ctz(rest);
@@ -2420,6 +2713,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                         prim_sums.v[c] += lane == 2 * k1 ? a_lo : (lane == 2 * k1 + 1 ? a_hi : 0.0f);
                     }
                 }
+#endif
             }
         }
         const float gdn = gdx * n.x + gdy * n.y + gdz * n.z;
@@ -2450,6 +2744,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     if (tid == 0 && pass == win.npass - 1) *s_next = (int)(gridDim.x + next_item);
     __syncthreads();
   }
+    ART_TIMELINE(6);
     if constexpr (BLOCKING) {          // the waves' rectangle gradients in wave order, then this item's slab (see trace_bwd_item)
         for (int w = 0; w < nwaves; ++w) {
             if (wave == w && lane < 2 * n_prims) {
@@ -2470,12 +2765,15 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
 // take 1024 - 3.61 -> 3.38 ms on the metric field, same box, interleaved -, smaller items
 // (one of eight ranks' share: 1250 points = 768 + 482) stay at 768 (0.512 against 0.529 ms).  The block GEOMETRY is always
 // computed for 768 threads, so the items - and with them every bit of the results - do not depend on the choice.
-constexpr int kLeanBwdThreads = 1024;       // launch bound
+#ifndef ART_LEAN_BWD_THREADS
+#define ART_LEAN_BWD_THREADS 1024
+#endif
+constexpr int kLeanBwdThreads = ART_LEAN_BWD_THREADS;       // launch bound
 constexpr int kLeanBwdGeometryThreads = 768;
 constexpr int kLeanBwdWidePoints = 2048;
 static int lean_bwd_threads(int p_block)
 {
-    const int forced = debug_env_int("ARTIST_HIP_BWD_THREADS", 0);       // (tests, A/B: 768 or 1024)
+    const int forced = env_int("ARTIST_HIP_BWD_THREADS", 0);       // (tests, A/B: 768 or 1024)
     if (forced == 768 || forced == 1024) return std::min(forced, kLeanBwdThreads);
     return std::min(p_block >= kLeanBwdWidePoints ? 1024 : 768, kLeanBwdThreads);
 }
@@ -2488,8 +2786,14 @@ constexpr int kLeanBwdPoints = 2560;
 // (768-thread workgroups for the cylinder adjoint and the planar blocking instantiation: they keep ~60 more values alive per
 //  ray than the plain body, and three waves per SIMD with a few spills beat two without - same-box, tools/cylinder_bench.py:
 //  512 -> 768 threads 18.6 -> 17.0 ms forward + backward, 1024 threads 17.9; tools/blocking_bench.py exact mode 30.5 -> 29.0)
-constexpr int kCylBwdThreads = 768, kBlockingBwdThreads = 768;
-constexpr int kLeanBlockBwdThreads = 768;     // the lean backward item with the mask and its inlined adjoint
+#ifndef ART_CYL_BWD_THREADS
+#define ART_CYL_BWD_THREADS 768
+#endif
+constexpr int kCylBwdThreads = ART_CYL_BWD_THREADS, kBlockingBwdThreads = 768;
+#ifndef ART_LEAN_BLOCK_BWD_THREADS
+#define ART_LEAN_BLOCK_BWD_THREADS 768
+#endif
+constexpr int kLeanBlockBwdThreads = ART_LEAN_BLOCK_BWD_THREADS;     // the lean backward item with the mask and its inlined adjoint
 // static LDS the rectangle tables add to the lean backward kernel (PrimTable<true>: rectangles, cull data, fp64 gradient sums)
 constexpr int kLeanBlockBwdStatic = (int)sizeof(PrimTable<true>);
 template <bool INTERLEAVED, bool ATOMIC_OUT, bool CYL, bool BLOCKING, bool LEAN = false>
@@ -2661,8 +2965,7 @@ static void choose_chunks(TraceArgs& a, int target_blocks, int min_chunk)
 }
 
 // Launch geometry of the forward kernel.  Defaults are the tuned MI355X values; the environment
-// overrides exist for A/B measurements and tests only and are read ONLY when ARTIST_HIP_DEBUG=1 (debug_env_int: a caller's
-// environment does not change what the product launches; ARTIST_HIP_FWD=global selects the plain global-atomic
+// overrides exist for A/B measurements only (ARTIST_HIP_FWD=global selects the plain global-atomic
 // kernel, ARTIST_HIP_FWD_BLOCK / _TILE_KB / _BLOCKS / _MINCHUNK the geometry).
 struct FwdConfig {
     int variant;        // 0 = LDS window, 1 = global atomics
@@ -2682,31 +2985,31 @@ struct FwdConfig {
 static FwdConfig fwd_config()
 {
     FwdConfig c;
-    const char* v = debug_env_str("ARTIST_HIP_FWD");
+    const char* v = getenv("ARTIST_HIP_FWD");
     c.variant = (v && v[0] == 'g') ? 1 : 0;
-    c.block = debug_env_int("ARTIST_HIP_FWD_BLOCK", 1024);
+    c.block = env_int("ARTIST_HIP_FWD_BLOCK", 1024);
     if (c.block < 64 || c.block > 1024 || (c.block % 64) != 0) c.block = 1024;
-    int kb = debug_env_int("ARTIST_HIP_FWD_TILE_KB", 158);
+    int kb = env_int("ARTIST_HIP_FWD_TILE_KB", 158);
     if (kb < 4) kb = 4;
     if (kb > 158) kb = 158;   // 160 KB per CU minus < 1 KB of static LDS (the blocking instantiations cap it further)
     c.tile_cap = kb * 256;   // 4-byte fixed-point cells
-    c.target_blocks = debug_env_int("ARTIST_HIP_FWD_BLOCKS", 512);
-    c.min_chunk = debug_env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
-    c.min_rays = debug_env_int("ARTIST_HIP_FWD_MINRAYS", 100000);
+    c.target_blocks = env_int("ARTIST_HIP_FWD_BLOCKS", 512);
+    c.min_chunk = env_int("ARTIST_HIP_FWD_MINCHUNK", 4);
+    c.min_rays = env_int("ARTIST_HIP_FWD_MINRAYS", 100000);
     // A footprint larger than the window: up to this multiple of the capacity the window keeps the densest part and the
     // tails stray; beyond it the footprint is swept in several passes.  Round 1 set 2 (a stray then cost ~30 window rays);
     // with parked (forward) and packed (backward) strays trimming wins much further out - metric field with shrunken
     // windows, forward / backward ms: 80 KB (footprint ~4x) 34.8 / 11.9 swept vs 12.5 / 4.4 trimmed; 40 KB (~8x) 71 / 21 vs
     // 39.5 / 5.5.
-    c.multipass_ratio = debug_env_int("ARTIST_HIP_FWD_MULTIPASS", 8);
+    c.multipass_ratio = env_int("ARTIST_HIP_FWD_MULTIPASS", 8);
     if (c.multipass_ratio < 1) c.multipass_ratio = 1;
-    c.p_block_fixed = debug_env_str("ARTIST_HIP_FWD_PBLOCK") != nullptr;
-    c.p_block_bwd_fixed = debug_env_str("ARTIST_HIP_BWD_PBLOCK") != nullptr;
-    c.p_block = debug_env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
+    c.p_block_fixed = getenv("ARTIST_HIP_FWD_PBLOCK") != nullptr;
+    c.p_block_bwd_fixed = getenv("ARTIST_HIP_BWD_PBLOCK") != nullptr;
+    c.p_block = env_int("ARTIST_HIP_FWD_PBLOCK", 1024);
     if (c.p_block < 64) c.p_block = 64;
-    c.exact_pblock = debug_env_int("ARTIST_HIP_PBLOCK_EXACT", 1) != 0;   // balanced blocks; a partial trip costs what its active waves issue
+    c.exact_pblock = env_int("ARTIST_HIP_PBLOCK_EXACT", 1) != 0;   // balanced blocks; a partial trip costs what its active waves issue
     c.facet_points = 0;
-    c.p_block_bwd = debug_env_int("ARTIST_HIP_BWD_PBLOCK", 2048);
+    c.p_block_bwd = env_int("ARTIST_HIP_BWD_PBLOCK", 2048);
     if (c.p_block_bwd < 64) c.p_block_bwd = 64;
     return c;
 }
@@ -2791,7 +3094,7 @@ static SideStream* side_stream()
     constexpr int kMaxDevices = 64;
     thread_local SideStream s[kMaxDevices];          // one side stream + two events per host thread AND device
     int d = 0;
-    if (debug_env_int("ARTIST_HIP_BLOCKING_CONCURRENT", 1) == 0 || hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
+    if (env_int("ARTIST_HIP_BLOCKING_CONCURRENT", 1) == 0 || hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return nullptr;
     return &s[d];
 }
 
@@ -2806,7 +3109,7 @@ static int resident_workgroups()
             cus <= 0)
             cus = 256;
         n = cus;
-        const int cap = debug_env_int("ARTIST_HIP_WORKGROUPS", 0);      // (diagnostic: fewer persistent workgroups than CUs, tools/timeline.sh)
+        const int cap = env_int("ARTIST_HIP_WORKGROUPS", 0);      // (diagnostic: fewer persistent workgroups than CUs, tools/timeline.sh)
         if (cap > 0 && cap < n) n = cap;
     }
     return n;
@@ -2864,7 +3167,7 @@ static int64_t host_item_count(const TraceArgs& a)
 static void set_queue_tail(TraceArgs& a, int min_points)
 {
     a.tail_h = 0; a.tail_bpf = a.blocks_per_facet; a.tail_pblock = a.p_block; a.tail_npb = a.n_pblocks;
-    const int mode = debug_env_int("ARTIST_HIP_TAIL", 1);
+    const int mode = env_int("ARTIST_HIP_TAIL", 1);
     if (mode == 0 || a.n_rchunks != 1 || a.h_group > 1 || a.n_pblocks < 1) return;
     const bool forward = min_points >= 512;
     if (mode == 2) min_points = 64;                                   // (tests: also in the backward kernel, any field size)
@@ -2914,7 +3217,7 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     a.n_pblocks = (a.P + unit - 1) / unit * a.blocks_per_facet;
     a.tile_cap = cfg.tile_cap;
     a.multipass_ratio = cfg.multipass_ratio;
-    a.win_sample = debug_env_int("ARTIST_HIP_WINDOW_SAMPLE", 1) != 0;
+    a.win_sample = env_int("ARTIST_HIP_WINDOW_SAMPLE", 1) != 0;
     const int64_t base = (int64_t)a.H * a.n_pblocks;
     int64_t want = (cfg.target_blocks + base - 1) / base;
     if (want < 1) want = 1;
@@ -2923,8 +3226,8 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
     if (chunk > a.R) chunk = a.R;
     a.r_chunk = chunk;
     a.n_rchunks = (a.R + chunk - 1) / chunk;
-    a.reverse_bwd = debug_env_int("ARTIST_HIP_BWD_REVERSE", 0);
-    a.reverse_items = debug_env_int("ARTIST_HIP_REVERSE", -1);       // -1: decided on the device (farther_end_is_last)
+    a.reverse_bwd = env_int("ARTIST_HIP_BWD_REVERSE", 0);
+    a.reverse_items = env_int("ARTIST_HIP_REVERSE", -1);       // -1: decided on the device (farther_end_is_last)
 }
 
 // The geometry of art_trace_bwd's MAIN launch - decided in ONE place for art_trace_bwd and for the two entry points that
@@ -2940,12 +3243,12 @@ static size_t bwd_main_geometry(TraceArgs& a, FwdConfig& cfg, bool lean, bool le
     if (lean || lean_block) {
         cfg.block = lean_block ? kLeanBlockBwdThreads : kLeanBwdGeometryThreads;
         cfg.exact_pblock = true;
-        if (lean || debug_env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {
+        if (lean || env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {
             cfg.facet_points = (int)facet_points;      // (lean kernels only: see art_trace_fwd)
             if (!cfg.p_block_bwd_fixed) cfg.p_block_bwd = kLeanBwdPoints;
         }
         // edge points packed into the block's last waves (trace_bwd_item_lean): the permutation lives behind the window
-        a.pack_edge = std::min(std::max(debug_env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
+        a.pack_edge = std::min(std::max(env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
         if (a.pack_edge != 0) {
             perm_bytes = 2 * kPackPoints;
             cfg.tile_cap = std::min<int>(cfg.tile_cap, (int)((160 * 1024 - 1408 - (lean_block ? kLeanBlockBwdStatic : 0) - perm_bytes - 8) / 4) / 64 * 64);
@@ -2969,10 +3272,10 @@ static BwdScratch bwd_scratch_need(const TraceArgs& a, bool blocking, int64_t Cm
     return n;
 }
 
-static bool bwd_uses_lean(bool blocking, int64_t T, int64_t Tc) { return !blocking && debug_env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0; }
+static bool bwd_uses_lean(bool blocking, int64_t T, int64_t Tc) { return !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0; }
 static bool bwd_uses_lean_block(bool blocking, int64_t T, int64_t Tc)
 {
-    return blocking && debug_env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0 && debug_env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
+    return blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && T > 0 && Tc == 0 && env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
 }
 
 }  // namespace art
@@ -3042,7 +3345,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     if (cfg.variant == 0) {
         // the lean ray body (trace_fwd_item_lean): planar receivers, no blocking, positive and sanely scaled intensity
         // factors - then a valid ray is known to carry intensity and one counter serves both factors
-        const bool lean_ok = debug_env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
+        const bool lean_ok = env_int("ARTIST_HIP_LEAN", 1) != 0 && a.mag >= 1e-6f && a.k_ext >= 1e-6f && a.k_refl >= 1e-6f &&
                              a.mag <= 1e6f && a.k_ext <= 1e6f && a.k_refl <= 1e6f;
         const bool lean = !blocking && lean_ok;
         // Blocking on: the heliostats with an empty candidate list (with the reference's tree, almost all of them) go through
@@ -3051,7 +3354,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // its own geometry, for the heliostats that aim at a plane (the others skip themselves), the cylinder launch below.
         const bool mixed_split = !blocking && lean_ok && T > 0 && Tc > 0;
         bool planar_done = false;
-        if ((mixed_split || (blocking && lean_ok && T > 0 && Tc == 0)) && debug_env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
+        if ((mixed_split || (blocking && lean_ok && T > 0 && Tc == 0)) && env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
             TraceArgs al = a;
             al.split = mixed_split ? 0 : 1;
             FwdConfig cl = fwd_config();
@@ -3063,7 +3366,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             set_queue_tail(al, 512);
             const int64_t items_l = host_item_count(al);
             if (items_l > 2147483647LL - 65536) return ART_EINVAL;
-            const int64_t blocks_l = (debug_env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
+            const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
             const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(unsigned);
             const FwdLaunch launch = {al, flux, counts, work_counters[2]};
             const bool il_l = interleaved_layout(al);
@@ -3105,11 +3408,11 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         }
         // Blocking on, planar receivers: the heliostats WITH candidate rectangles take the lean ray body with the soft mask
         // (trace_fwd_item_lean<.., BLOCKING>; 768-thread persistent workgroups) instead of the generic item.
-        const bool lean_block = blocking && lean_ok && T > 0 && Tc == 0 && debug_env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
+        const bool lean_block = blocking && lean_ok && T > 0 && Tc == 0 && env_int("ARTIST_HIP_BLOCK_LEAN", 1) != 0;
         // Cylindrical receivers (no blocking): the lean item with the cylinder hit in place of the plane's (trace_fwd_item_lean<..,
         // false, true>; 768-thread persistent workgroups, facet-sized items) instead of the generic one-item workgroups.  On a mixed
         // tower this is the cylinder launch beside the planes' lean launch (a.split == 3: the receiver type decides who skips).
-        const bool lean_cyl = !blocking && lean_ok && Tc > 0 && debug_env_int("ARTIST_HIP_CYL_LEAN", 1) != 0;
+        const bool lean_cyl = !blocking && lean_ok && Tc > 0 && env_int("ARTIST_HIP_CYL_LEAN", 1) != 0;
         if (lean_cyl) {
             cfg.block = kLeanCylFwdThreads;
             cfg.exact_pblock = true;
@@ -3119,7 +3422,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         if (lean_block) {
             cfg.block = kLeanBlockFwdThreads;
             cfg.exact_pblock = true;
-            if (debug_env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {       // (facet-sized items: slower with the generic body, faster here)
+            if (env_int("ARTIST_HIP_BLOCK_FACETS", 1) != 0) {       // (facet-sized items: slower with the generic body, faster here)
                 cfg.facet_points = (int)facet_points;
                 if (!cfg.p_block_fixed) cfg.p_block = cfg.facet_points > 0 ? kLeanFwdPoints : kLeanBlockFwdThreads;
             }
@@ -3131,7 +3434,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         // ~1.5e3 per heliostat for its share of the window phase and its counters).
         bool field_groups = false;
         if (lean && T > 0 && Tc == 0 && mode == 1 && a.R < 8 && a.n_pblocks == 1 && a.n_rchunks == 1 && a.H > 1) {
-            int K = debug_env_int("ARTIST_HIP_FIELD_GROUP", -1);                   // -1: chosen here; 0 / 1: off
+            int K = env_int("ARTIST_HIP_FIELD_GROUP", -1);                   // -1: chosen here; 0 / 1: off
             if (K < 0) {
                 double best = 0.0;
                 K = 1;
@@ -3145,14 +3448,18 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             if (K > 1) { a.h_group = std::min(K, a.H); a.n_groups = (a.H + a.h_group - 1) / a.h_group; field_groups = true; }
         }
         if (lean && T > 0 && Tc == 0) set_queue_tail(a, 512);
-        if (debug_env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
+        if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
             fprintf(stderr, "art_trace_fwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d group %d tail %d x %d\n",
                     a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean,
                     a.h_group, a.tail_h, a.tail_npb);
         const int64_t items = host_item_count(a);
         if (items > 2147483647LL - 65536) return ART_EINVAL;
         // persistent: one workgroup per CU (ARTIST_HIP_PERSISTENT bit 0 cleared: one workgroup per item, for A/B runs)
-        const int64_t persistent_blocks = (debug_env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items, resident_workgroups()) : items;
+#ifdef ART_FWD_SINGLE_ITEM
+        const int64_t persistent_blocks = items;
+#else
+        const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items, resident_workgroups()) : items;
+#endif
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(unsigned);
         // one launch per receiver type present in the tables; a workgroup whose heliostat aims at the other type
         // exits at once (the type is only known on the device)
@@ -3216,6 +3523,15 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                        (int)H, (float)(R * P), blocking ? 1 : 0, a.split == 2 ? a.cand_count : nullptr,
                        blocking ? a.cand_count : nullptr, a.Cmax);
     ART_HIP(hipGetLastError());
+#ifdef ART_DEBUG_TIMELINE
+    if (const char* out = getenv("ART_TIMELINE_OUT")) {     // the last call's records: [blocks][8] u64, raw
+        const int64_t n = std::min<int64_t>((int64_t)a.H * a.n_pblocks * a.n_rchunks, kTimelineSlots);
+        std::vector<unsigned long long> host(8 * n);
+        ART_HIP(hipStreamSynchronize(stream));
+        ART_HIP(hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * n));
+        if (FILE* f = fopen(out, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
+    }
+#endif
     return ART_OK;
 }
 
@@ -3280,7 +3596,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             perm_bytes = bwd_main_geometry(a, cfg, lean, lean_block, facet_points, true);
             need = bwd_scratch_need(a, blocking, Cmax);
         }
-        if (debug_env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
+        if (env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
             fprintf(stderr, "art_trace_bwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d\n",
                     a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, lean ? lean_bwd_threads(a.p_block) : cfg.block, (int)lean);
         const bool atomic_out = a.n_rchunks > 1;      // (round 1's name: today the chunks write slabs, nothing is atomic)
@@ -3300,8 +3616,8 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         // (a tower with planar and cylindrical receivers, no blocking, is split the same way: see art_trace_fwd)
         const bool mixed_split = !blocking && T > 0 && Tc > 0;
         bool planar_done = false;
-        if ((mixed_split || (blocking && Tc == 0)) && !atomic_out && T > 0 && debug_env_int("ARTIST_HIP_LEAN", 1) != 0 &&
-            debug_env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
+        if ((mixed_split || (blocking && Tc == 0)) && !atomic_out && T > 0 && env_int("ARTIST_HIP_LEAN", 1) != 0 &&
+            env_int("ARTIST_HIP_BLOCKING_SPLIT", 1) != 0) {
             TraceArgs al = a;
             al.split = mixed_split ? 0 : 1;
             FwdConfig cl = fwd_config();
@@ -3310,7 +3626,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             cl.facet_points = (int)facet_points;
             if (!cl.p_block_bwd_fixed) cl.p_block_bwd = kLeanBwdPoints;
             size_t perm_l = 0;
-            al.pack_edge = std::min(std::max(debug_env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
+            al.pack_edge = std::min(std::max(env_int("ARTIST_HIP_BWD_PACK", 32), 0), 256);
             if (al.pack_edge != 0) {
                 perm_l = 2 * kPackPoints;
                 cl.tile_cap = std::min<int>(cl.tile_cap, (int)((160 * 1024 - 1408 - perm_l - 8) / 4) / 64 * 64);
@@ -3320,7 +3636,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                 set_queue_tail(al, 384);
                 const int64_t items_l = host_item_count(al);
                 if (items_l > 2147483647LL - 65536) return ART_EINVAL;
-                const int64_t blocks_l = (debug_env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
+                const int64_t blocks_l = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
                 const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(float) + perm_l;
                 unsigned* wc = stream_work_counters(stream);
                 if (wc == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
@@ -3352,7 +3668,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         if (lean) cfg.block = lean_bwd_threads(a.p_block);       // (the geometry is fixed by now)
         const int64_t items = host_item_count(a);
         if (items > 2147483647LL - 65536) return ART_EINVAL;
-        const int64_t persistent_blocks = (debug_env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
+        const int64_t persistent_blocks = (env_int("ARTIST_HIP_PERSISTENT", 3) & 2) ? std::min<int64_t>(items, resident_workgroups()) : items;
         const size_t lds = ((size_t)a.tile_cap + 2) * sizeof(float) + perm_bytes;
         if (atomic_out) {
             go = reinterpret_cast<float4*>(grad_scratch);
@@ -3387,9 +3703,18 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         if (T > 0 && !planar_done) ART_LAUNCH_BWD_TYPE(false);
         if (planar_done) a.split = 3;
         // cylinders without blocking: the lean item with the cylinder hit (persistent 768-thread workgroups on the work queue)
-        if (Tc > 0 && !blocking && debug_env_int("ARTIST_HIP_LEAN", 1) != 0 && debug_env_int("ARTIST_HIP_CYL_LEAN", 1) != 0) ART_LAUNCH_BWD_BL(true, false, true);
+        if (Tc > 0 && !blocking && env_int("ARTIST_HIP_LEAN", 1) != 0 && env_int("ARTIST_HIP_CYL_LEAN", 1) != 0) ART_LAUNCH_BWD_BL(true, false, true);
         else
         if (Tc > 0) ART_LAUNCH_BWD_TYPE(true);
+#ifdef ART_DEBUG_TIMELINE
+        if (const char* out = getenv("ART_TIMELINE_OUT_BWD")) {
+            const int64_t n = std::min<int64_t>(items, kTimelineSlots);
+            std::vector<unsigned long long> host(8 * n);
+            ART_HIP(hipStreamSynchronize(stream));
+            ART_HIP(hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 8 * n));
+            if (FILE* f = fopen(out, "wb")) { fwrite(host.data(), sizeof(unsigned long long), host.size(), f); fclose(f); }
+        }
+#endif
 #undef ART_LAUNCH_BWD_TYPE
 #undef ART_LAUNCH_BWD_BL
 #undef ART_LAUNCH_BWD

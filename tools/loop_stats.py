@@ -26,7 +26,10 @@ SRC = (ROOT / "artist_amd" / "csrc" / "trace_kernels.hip").read_text()
 
 
 def ring_depth(macro):
-    m = re.search(r"#define\s+" + macro + r"\s+(\d+)", SRC)
+    """The ring depth of the shipped source: tools/strip_variants.py left it as a comment, "// ring depth = 8: ..." /
+    "// ring depth bwd = 2: ..." (the instrumented copy under tools/diag/ still has the #define)."""
+    words = macro[4:].lower().replace("_", " ")
+    m = re.search(r"//\s*" + words + r"\s*=\s*(\d+)", SRC) or re.search(r"#define\s+" + macro + r"\s+(\d+)", SRC)
     return int(m.group(1)) if m else 8
 
 

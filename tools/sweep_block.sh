@@ -1,4 +1,5 @@
 #!/bin/bash
+export ARTIST_HIP_DEBUG=1   # the library reads its ARTIST_HIP_* knobs only in debug mode
 # Workgroup size / point-block sweep of the windowed trace kernels on the metric field (same box, back to back).
 # usage (GPU box): bash tools/sweep_block.sh > gpurun_out/sweep_block.txt
 cd "$(dirname "$0")/.."

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ARTIST_HIP_DEBUG=1   # the library reads its ARTIST_HIP_* knobs only in debug mode
 # Where does a forward workgroup's time go?  Builds a diagnostic library (-DART_DEBUG_TIMELINE: every forward workgroup
 # stamps its phases with the 100 MHz real-time counter), runs one forward trace of the metric field on the GPU box and
 # prints per-phase medians + the gap a CU leaves between two workgroups.
@@ -6,9 +7,9 @@
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
-( cd artist_amd/csrc && for f in trace_kernels blocking_kernels flux_kernels nurbs_kernels align_kernels kinematics_kernels capi; do
+( cd artist_amd/csrc && for f in trace_kernels blocking_kernels flux_kernels nurbs_kernels align_kernels kinematics_kernels optim_kernels capi; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize \
-      -DART_DEBUG_TIMELINE $ART_EXTRA_DEFS -c $f.hip -o /tmp/tl_$f.o; done
+      -DART_DEBUG_TIMELINE $ART_EXTRA_DEFS -I. -c $( [ $f = trace_kernels ] && echo ../../tools/diag/trace_kernels_diag.hip || echo $f.hip ) -o /tmp/tl_$f.o; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libtimeline.so /tmp/tl_*.o )
 exit 0
 fi
