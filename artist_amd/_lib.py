@@ -34,7 +34,7 @@ SIGNATURES = {
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_dbl,
                       _c_dbl, _c_dbl, _c_dbl, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int,
-                      _ptr, _ptr, _ptr, _ptr],
+                      _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_async_status": [_ptr, _c_int],
     "art_trace_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr, _ptr, _ptr,
                       _ptr, _ptr, _ptr, _ptr, _ptr, _ptr,
@@ -46,7 +46,7 @@ SIGNATURES = {
     "art_flux_crop_fwd": [_ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],
     "art_flux_crop_bwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr],
     "art_flux_loss": [_ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr],
-    "art_flux_crop_pixel_loss_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr],
+    "art_flux_crop_pixel_loss_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
     "art_flux_crop_pixel_loss_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr],
     "art_flux_crop_kl_loss_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],
     "art_flux_crop_kl_loss_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],

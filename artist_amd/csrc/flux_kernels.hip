@@ -16,19 +16,12 @@
 #include <vector>
 
 #include "launch_common.hpp"
+#include "flux_moments.hpp"
 
 namespace art {
 
 constexpr int kFluxBlock = 256;
-constexpr int kReduceBlock = 1024;     // per-bitmap reductions: one workgroup per bitmap, 16 waves to hide latency
-
-// torch.linspace(-1, 1, n)[k]: the first half is filled from the start, the second half from the end
-__device__ __forceinline__ float lin11(int k, int n)
-{
-    if (n == 1) return -1.0f;
-    const float step = 2.0f / (float)(n - 1);
-    return k < n / 2 ? -1.0f + step * (float)k : 1.0f - step * (float)(n - 1 - k);
-}
+constexpr int kReduceBlock = kMomentsBlock;     // per-bitmap reductions: one workgroup per bitmap, 16 waves to hide latency
 
 __device__ __forceinline__ double block_sum(double v, double* s_red)
 {
@@ -41,29 +34,6 @@ __device__ __forceinline__ double block_sum(double v, double* s_red)
     double r = 0.0;
     for (int w = 0; w < nw; ++w) r += s_red[w];
     return r;
-}
-
-// N sums at once, each with block_sum's tree (xor-shuffle inside a wave, then the waves in order): one pair of barriers for
-// all of them.  s_red: 16 * N doubles.
-template <int N>
-__device__ __forceinline__ void block_sum_n(double (&v)[N], double* s_red)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-    __syncthreads();
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < N; ++k) s_red[wave * N + k] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        double r = 0.0;
-        for (int w = 0; w < nw; ++w) r += s_red[w * N + k];
-        v[k] = r;
-    }
 }
 
 struct CropMap {       // pixel j of the output samples input coordinate ix(j); same arithmetic in every kernel
@@ -540,52 +510,8 @@ __device__ __forceinline__ float crop_sample_col(const float* __restrict__ f, co
 // (A "last workgroup adds the parts" ticket was built first: its device-scope fences write back and invalidate the L2 of
 //  every XCD - 0.24 instead of 0.04 ms at 125 bitmaps.  Kernel boundaries carry the parts instead.)
 // ---------------------------------------------------------------------------------------------------
-constexpr int kLossParts = 4;
 constexpr int kMaxPartBitmaps = 512;
 struct PartScratch { double com[kMaxPartBitmaps][kLossParts][3]; double acc[kMaxPartBitmaps][kLossParts][4]; };
-
-__device__ __forceinline__ void part_rows(int Hh, int v, int& r0, int& r1)
-{
-    r0 = (int)(((int64_t)Hh * v) / kLossParts);
-    r1 = (int)(((int64_t)Hh * (v + 1)) / kLossParts);
-}
-
-// (sum f, sum x f, sum y f) over the rows of part v of one bitmap, x / y in normalised coordinates; block-wide result
-__device__ __forceinline__ void com_part_sums(const float* __restrict__ f, int Hh, int W, int v, double* s_red, double& s, double& xs, double& ys)
-{
-    int r0, r1;
-    part_rows(Hh, v, r0, r1);
-    double a[3] = {0.0, 0.0, 0.0};
-    if ((W & 3) == 0) {
-        const int W4 = W >> 2;
-        const float4* __restrict__ f4 = reinterpret_cast<const float4*>(f) + (int64_t)r0 * W4;
-        const int n = (r1 - r0) * W4;
-        int x4 = threadIdx.x % W4, y = r0 + threadIdx.x / W4;              // (no division in the loop)
-        const int dx = blockDim.x % W4, dy = blockDim.x / W4;
-#pragma unroll 4
-        for (int k = threadIdx.x; k < n; k += blockDim.x) {
-            const float4 q = f4[k];
-            const int x = 4 * x4;
-            a[0] += (double)((q.x + q.y) + (q.z + q.w));
-            a[1] += (double)((lin11(x, W) * q.x + lin11(x + 1, W) * q.y) + (lin11(x + 2, W) * q.z + lin11(x + 3, W) * q.w));
-            a[2] += (double)(lin11(y, Hh) * ((q.x + q.y) + (q.z + q.w)));
-            x4 += dx; y += dy;
-            if (x4 >= W4) { x4 -= W4; ++y; }
-        }
-    } else {
-        const int n = (r1 - r0) * W;
-        int x = threadIdx.x % W, y = r0 + threadIdx.x / W;
-        const int dx = blockDim.x % W, dy = blockDim.x / W;
-        for (int k = threadIdx.x; k < n; k += blockDim.x) {
-            const float q = f[(int64_t)r0 * W + k];
-            a[0] += (double)q; a[1] += (double)(lin11(x, W) * q); a[2] += (double)(lin11(y, Hh) * q);
-            x += dx; y += dy;
-            if (x >= W) { x -= W; ++y; }
-        }
-    }
-    block_sum_n<3>(a, s_red);
-    s = a[0]; xs = a[1]; ys = a[2];
-}
 
 __global__ __launch_bounds__(kReduceBlock) void flux_com_parts_kernel(const float* __restrict__ flux, int Hh, int W, int parts_per_wg,
                                                                     PartScratch* __restrict__ ws)
@@ -631,7 +557,7 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(
                                                                                float crop_w, float crop_h, int parts_per_wg,
                                                                                PartScratch* ws, float* __restrict__ residual,
                                                                                float* __restrict__ loss, float* __restrict__ com4,
-                                                                               float* __restrict__ gunit)
+                                                                               float* __restrict__ gunit, const double* __restrict__ moments)
 {
     __shared__ double s_red[16 * 4];
     __shared__ double s_com[kLossParts][3], s_acc[kLossParts][4];
@@ -641,7 +567,9 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(
     float* __restrict__ res = residual ? residual + (int64_t)b * Hh * W : nullptr;
     CropMap m;
     float S;
-    if constexpr (WHOLE) {
+    if (moments != nullptr) {          // the sums came with the bitmaps (the trace's conversion pass formed them: flux_moments.hpp)
+        com_from_parts(reinterpret_cast<const double(*)[3]>(moments + (int64_t)b * kLossParts * 3), m.xc, m.yc, S);
+    } else if constexpr (WHOLE) {
         for (int v = 0; v < kLossParts; ++v) {
             double s, xs, ys;
             com_part_sums(f, Hh, W, v, s_red, s, xs, ys);
@@ -717,12 +645,12 @@ __global__ __launch_bounds__(kReduceBlock) void flux_crop_pixel_loss_fwd_kernel(
 // the parts of the bitmaps that were shared among workgroups -> loss and records: one thread per bitmap
 __global__ __launch_bounds__(256) void flux_crop_pixel_loss_final_kernel(const PartScratch* __restrict__ ws, int B, int Hh, int W,
                                                                          float* __restrict__ loss, float* __restrict__ com4,
-                                                                         float* __restrict__ gunit)
+                                                                         float* __restrict__ gunit, const double* __restrict__ moments)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float xc, yc, S;
-    com_from_parts(ws->com[b], xc, yc, S);
+    com_from_parts(moments ? reinterpret_cast<const double(*)[3]>(moments + (int64_t)b * kLossParts * 3) : ws->com[b], xc, yc, S);
     loss_from_parts(ws->acc[b], xc, yc, S, b, Hh, W, loss, com4, gunit);
 }
 
@@ -1012,7 +940,8 @@ extern "C" int art_flux_loss(const float* prediction, const float* ground_truth,
 
 extern "C" int art_flux_crop_pixel_loss_fwd(const float* flux, const float* target_dims, const float* ground_truth, int64_t B,
                                             int64_t Hh, int64_t W, double crop_width, double crop_height, float* loss,
-                                            float* centers4, float* residual, float* center_grad_unit, void* stream_)
+                                            float* centers4, float* residual, float* center_grad_unit, const double* moments,
+                                            void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (!crop_args_ok(flux, target_dims, ground_truth, loss, B, Hh, W) || !centers4 || (residual != nullptr) != (center_grad_unit != nullptr))
@@ -1021,17 +950,18 @@ extern "C" int art_flux_crop_pixel_loss_fwd(const float* flux, const float* targ
     const int P = loss_workgroups_per_bitmap(B, Hh);
     PartScratch* ws = P > 1 ? flux_parts_scratch(stream) : nullptr;
     if (ws != nullptr) {
-        hipLaunchKernelGGL(flux_com_parts_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux, (int)Hh, (int)W,
-                           kLossParts / P, ws);
+        if (moments == nullptr)
+            hipLaunchKernelGGL(flux_com_parts_kernel, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux, (int)Hh, (int)W,
+                               kLossParts / P, ws);
         hipLaunchKernelGGL(flux_crop_pixel_loss_fwd_kernel<false>, dim3((unsigned)P, (unsigned)B), dim3(kReduceBlock), 0, stream, flux,
                            target_dims, ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, kLossParts / P, ws, residual,
-                           loss, centers4, center_grad_unit);
+                           loss, centers4, center_grad_unit, moments);
         hipLaunchKernelGGL(flux_crop_pixel_loss_final_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, ws, (int)B, (int)Hh,
-                           (int)W, loss, centers4, center_grad_unit);
+                           (int)W, loss, centers4, center_grad_unit, moments);
     } else
     hipLaunchKernelGGL(flux_crop_pixel_loss_fwd_kernel<true>, dim3(1u, (unsigned)B), dim3(kReduceBlock), 0, stream, flux, target_dims,
                        ground_truth, (int)Hh, (int)W, (float)crop_width, (float)crop_height, kLossParts, (PartScratch*)nullptr, residual,
-                       loss, centers4, center_grad_unit);
+                       loss, centers4, center_grad_unit, moments);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

@@ -119,6 +119,8 @@ class FluxCropPixelLoss(torch.autograd.Function):
     batch size, without the cropped bitmaps' round trip through HBM; when a gradient is wanted the forward pass keeps the
     residual ``crop - ground_truth`` and the backward pass is one kernel over it.  Differentiable w.r.t. ``flux``."""
 
+    calls_with_moments = 0          # (tests: how often the bitmaps came with their centre-of-mass sums)
+
     @staticmethod
     def forward(ctx, flux, dims, ground_truth, crop_width, crop_height):
         dev = _require_cuda(flux, dims, ground_truth)
@@ -131,11 +133,16 @@ class FluxCropPixelLoss(torch.autograd.Function):
         keep = bool(ctx.needs_input_grad[0])
         residual = torch.empty_like(flux) if keep else None
         unit = torch.empty((B, 2), dtype=torch.float32, device=dev) if keep else None
+        from .ops import bitmap_moments
+        moments = bitmap_moments(flux)              # bitmaps straight from the tracer bring their centre-of-mass sums along
+        if moments is not None and (moments.shape[0] != B or moments.device != dev):
+            moments = None
+        FluxCropPixelLoss.calls_with_moments += moments is not None
         with torch.cuda.device(dev):
             rc = _lib.lib().art_flux_crop_pixel_loss_fwd(flux.data_ptr(), dims.data_ptr(), ground_truth.data_ptr(), B, Hh, W,
                                                          float(crop_width), float(crop_height), loss.data_ptr(), centers.data_ptr(),
                                                          residual.data_ptr() if keep else None, unit.data_ptr() if keep else None,
-                                                         _stream(dev))
+                                                         None if moments is None else moments.data_ptr(), _stream(dev))
         _lib.check(rc, "art_flux_crop_pixel_loss_fwd")
         if keep:
             ctx.save_for_backward(dims, centers, residual, unit)

@@ -10,6 +10,8 @@ import collections
 import contextlib
 import math
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -196,6 +198,21 @@ def check_async_errors(device=None, clear: bool = True) -> None:
     _lib.check(rc, "art_async_status")
 
 
+# Centre-of-mass sums that came with a traced bitmap tensor: data pointer -> (weak reference to the tensor object, sums).  An
+# entry serves exactly the tensor OBJECT the trace returned, at the version it returned it with (an in-place edit, a copy or a
+# slice of the bitmaps is another tensor or another version: the crop then forms the sums itself).
+_MOMENTS: dict = {}
+
+
+def bitmap_moments(flux: torch.Tensor):
+    """The sums ``art_trace_fwd`` left for ``flux`` (``[n_maps,4,3]`` float64) if ``flux`` is an untouched output of
+    :func:`trace_rays` / ``HeliostatRayTracer.trace_rays``, else None."""
+    entry = _MOMENTS.get(flux.data_ptr())
+    if entry is None or entry[0]() is not flux or flux._version != 0:
+        return None
+    return entry[1]
+
+
 class TraceRays(torch.autograd.Function):
     """reflect -> scatter -> plane / cylinder intersection -> (blocking mask) -> bilinear splat (+ factors), fused.
 
@@ -266,12 +283,17 @@ class TraceRays(torch.autograd.Function):
         flux = torch.empty((n_maps, height, width), dtype=torch.float32, device=dev)
         factors = torch.empty((3, H), dtype=torch.float32, device=dev)
         accum = _accumulators(dev, n_maps * height * width)
+        # the bitmaps' centre-of-mass sums, left behind by the pass that converts the accumulators (include/artist_hip.h): the
+        # crop + loss op that follows in a reconstruction epoch starts from them (artist_amd.flux: bitmap_moments)
+        moments = None
+        if height >= 4 and (height * width) % 2 == 0 and 0 < n_maps <= 65535:
+            moments = torch.empty((n_maps, 4, 3), dtype=torch.float64, device=dev)
         with _launch("art_trace_fwd", dev):
             rc = _lib.lib().art_trace_fwd(
                 *geometry, *block_ptrs, Cmax, float(max_scatter_angle), float(ray_magnitude), float(extinction),
                 float(reflectivity),
                 H, R, P, points_per_facet, T, Tc, width, height, 1 if per_target else 0, flux.data_ptr(), factors.data_ptr(),
-                accum.data_ptr(), _stream(dev))
+                accum.data_ptr(), None if moments is None else moments.data_ptr(), _stream(dev))
         if rc != 0:
             _ACCUM.clear()
         if rc == -2:
@@ -290,6 +312,11 @@ class TraceRays(torch.autograd.Function):
                        Cmax, N, float(max_scatter_angle), points_per_facet)
         ctx.mark_non_differentiable(factors, flags)
         ctx.set_materialize_grads(False)            # no zero tensors (one fill kernel each) for outputs nobody differentiates
+        if moments is not None:
+            _MOMENTS[flux.data_ptr()] = (weakref.ref(flux), moments)
+            if len(_MOMENTS) > 64:
+                for key in [k for k, v in _MOMENTS.items() if v[0]() is None]:
+                    del _MOMENTS[key]
         return flux, factors, flags
 
     @staticmethod

@@ -98,6 +98,11 @@ int art_last_hip_error(void);
  *                     pixel: the flux does not depend on the order in which workgroups finish - two calls with the
  *                     same inputs give the same bits (the reference needs torch.use_deterministic_algorithms for
  *                     that, tests/conftest.py:109).  `flux` itself needs no initialisation.
+ *   moments           NULL, or output [n_maps,4,3] fp64: per bitmap and quarter of its rows (sum f, sum x f, sum y f) with
+ *                     x, y = torch.linspace(-1, 1, W / Hh) - the sums crop_flux_distributions_around_center starts from
+ *                     (artist/flux/bitmap.py:165-182), left behind by the conversion pass, which streams every pixel
+ *                     anyway; art_flux_crop_pixel_loss_fwd takes them.  Formed when Hh >= 4, Hh * W is even and
+ *                     n_maps <= 65535; all-NaN otherwise (and for a heliostat whose blocking candidates overflowed).
  * Device memory: every buffer is the caller's, except 4 KB pages that the library allocates on first use and keeps
  * (work counters of its persistent workgroups: 32 bytes per stream that has made a trace call, see Conventions; the
  * first trace call on a stream must therefore not be made while that stream is being captured into a graph)
@@ -112,7 +117,7 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
                   const float *prim_normals, const int32_t *cand, const int32_t *cand_count, int64_t Cmax,
                   double max_scatter_angle, double ray_magnitude, double extinction, double reflectivity,
                   int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t W, int64_t Hh,
-                  int mode, float *flux, float *factors, uint64_t *accum, void *stream);
+                  int mode, float *flux, float *factors, uint64_t *accum, double *moments, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * art_async_status - the entry points are asynchronous, so what only the DEVICE can find out is reported here:
@@ -324,11 +329,14 @@ int art_flux_loss(const float *prediction, const float *ground_truth, int64_t B,
  *   loss [B] out; centers4 [B,4] out (centre of mass x, y, bitmap sum + 1e-8, sum of the measured flux)
  *   residual [B,Hh,W] out, center_grad_unit [B,2] out: crop - ground_truth and the gradient of the two centre coordinates
  *   per unit of 2 grad_loss / sum(ground_truth) - what the backward call needs; both NULL for a forward-only call.
+ *   moments [B,4,3] fp64 or NULL: the bitmaps' centre-of-mass sums as art_trace_fwd leaves them (see there); with them the
+ *   call does not read the bitmaps a second time for the centre (same sums, same bits, as when it forms them itself).
  *   _bwd: grad_loss [B] -> grad_flux [B,Hh,W] (fully written).
  * ------------------------------------------------------------------------------------------- */
 int art_flux_crop_pixel_loss_fwd(const float *flux, const float *target_dims, const float *ground_truth, int64_t B,
                                  int64_t Hh, int64_t W, double crop_width, double crop_height, float *loss,
-                                 float *centers4, float *residual, float *center_grad_unit, void *stream);
+                                 float *centers4, float *residual, float *center_grad_unit, const double *moments,
+                                 void *stream);
 int art_flux_crop_pixel_loss_bwd(const float *target_dims, const float *centers4, const float *grad_loss,
                                  const float *residual, const float *center_grad_unit, int64_t B, int64_t Hh, int64_t W,
                                  double crop_width, double crop_height, float *grad_flux, void *stream);

@@ -44,10 +44,10 @@ cases = {
 }
 c4 = torch.empty(B, 4, device=dev)
 resid, unit = torch.empty_like(flux), torch.empty(B, 2, device=dev)
-cases["crop_pixel_loss_fwd"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4), None, None, s),
+cases["crop_pixel_loss_fwd"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4), None, None, None, s),
                                 2 * nbytes)
 cases["crop_pixel_loss_fwd_keep"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4),
-                                                                              p(resid), p(unit), s), 3 * nbytes)
+                                                                              p(resid), p(unit), None, s), 3 * nbytes)
 cases["crop_pixel_loss_bwd"] = (lambda: lib.art_flux_crop_pixel_loss_bwd(p(dims), p(c4), p(gl), p(resid), p(unit), B, Hh, W, 6.0, 6.0,
                                                                          p(gflux), s), 2 * nbytes)
 res = {}
