@@ -18,6 +18,8 @@ extern "C" const char* art_strerror(int code)
         case ART_ELAUNCH: return "HIP runtime/launch error (see art_last_hip_error)";
         case ART_EUNSUPPORTED: return "unsupported configuration";
         case ART_ECANDIDATES: return "a heliostat has more blocking rectangles inside its ray cone than the kernels hold";
+        case ART_EQUEUE: return "a work counter of this stream was not zero when a trace call started: an earlier launch on the stream ended "
+                                "abnormally (the counters were reset; results of that earlier call are not valid)";
         default: return "unknown error";
     }
 }

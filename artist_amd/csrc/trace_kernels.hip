@@ -1511,13 +1511,22 @@ __global__ __launch_bounds__(LEAN ? (BLOCKING ? kLeanBlockFwdThreads : (CYL ? kL
     }
 }
 
+constexpr int kCountersPerStream = 8;      // work counters per (device, stream): see stream_work_counters
 // What a forward call zeroes before its kernels start - the three ray counters per heliostat (they alias `factors`) and the
 // work counters of its (at most two) launches - in ONE launch: three memsets were three 5 us kernels, a tenth of the
 // forward pass of a 16-heliostat field.
-__global__ void trace_fwd_prep_kernel(unsigned* __restrict__ counts, int n)
+// It also looks at the stream's work counters (kCountersPerStream of them): a counter is zero whenever no launch is using it - the
+// last fetch of a launch resets it - and the launches of a stream are ordered, so a non-zero counter here means that an earlier
+// launch on this stream did not make all its fetches (a fault, an abort).  Every later launch would silently skip or repeat
+// items; instead the counters are put back to zero and the status word says so (bit 2: ART_EQUEUE).
+__global__ void trace_fwd_prep_kernel(unsigned* __restrict__ counts, int n, unsigned* __restrict__ work_counters, unsigned* __restrict__ status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) counts[i] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < kCountersPerStream && work_counters[threadIdx.x] != 0u) {
+        work_counters[threadIdx.x] = 0u;
+        if (status != nullptr) atomicOr(status, 4u);
+    }
 }
 
 // counts (uint32, rows 0,1 of factors) -> fractions (heliostat_ray_tracer.py:498-506).
@@ -2757,7 +2766,6 @@ static void window_geometry_for(TraceArgs& a, const FwdConfig& cfg, int p_block_
 // on first use and keeps.  A counter is zero whenever no launch is using it: the launch's last fetch resets it
 // (fetch_work_item), and launches that share a counter are ordered by their stream.  So there is no per-launch memset, and no
 // bound on how many launches may be queued (round 2 took the next of 1024 slots per launch, unguarded).
-constexpr int kCountersPerStream = 8;
 static unsigned* stream_work_counters(hipStream_t stream)
 {
     struct Entry { int dev; hipStream_t stream; unsigned* base; };
@@ -3047,6 +3055,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     const StatusWord status = status_word();
     if (status.host != nullptr && (*status.host & 1u)) return ART_ETARGET;     // an earlier launch met a bad target index
     if (status.host != nullptr && (*status.host & 2u)) return ART_ECANDIDATES; // ... or more candidate rectangles than the tables hold
+    if (status.host != nullptr && (*status.host & 4u)) return ART_EQUEUE;      // ... or a work counter that an aborted launch left behind
     a.status = status.dev;
     const bool blocking = prim_corners != nullptr;
     if (blocking) {
@@ -3064,7 +3073,10 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         return ART_ELAUNCH;
     }
     unsigned* work_counters[3] = {wc_base, wc_base + 1, wc_base + 2};
-    hipLaunchKernelGGL(trace_fwd_prep_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, stream, counts, (int)(3 * H));
+    if (debug_env_int("ARTIST_HIP_CORRUPT_COUNTER", 0) != 0)          // (tests: what an aborted launch leaves behind)
+        ART_HIP(hipMemsetAsync(wc_base, 0x07, sizeof(unsigned), stream));
+    hipLaunchKernelGGL(trace_fwd_prep_kernel, dim3((unsigned)((3 * H + 255) / 256)), dim3(256), 0, stream, counts, (int)(3 * H), wc_base,
+                       status.dev);
     FwdConfig cfg = fwd_config();
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return ART_EINVAL;
     if (blocking && cfg.tile_cap > 154 * 256) cfg.tile_cap = 154 * 256;   // room for the rectangle tables in LDS (no gradient sums here: 4.2 KB + 1 KB of static LDS)
@@ -3296,6 +3308,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         const StatusWord status = status_word();
         if (status.host != nullptr && (*status.host & 1u)) return ART_ETARGET;
         if (status.host != nullptr && (*status.host & 2u)) return ART_ECANDIDATES;
+        if (status.host != nullptr && (*status.host & 4u)) return ART_EQUEUE;
         a.status = status.dev;
     }
     const bool blocking = prim_corners != nullptr;
@@ -3522,5 +3535,5 @@ extern "C" int art_async_status(void* stream_, int clear)
     ART_HIP(hipStreamSynchronize(stream));
     const unsigned word = *status.host;
     if (clear) *status.host = 0u;
-    return (word & 1u) ? ART_ETARGET : ((word & 2u) ? ART_ECANDIDATES : ART_OK);
+    return (word & 1u) ? ART_ETARGET : ((word & 2u) ? ART_ECANDIDATES : ((word & 4u) ? ART_EQUEUE : ART_OK));
 }

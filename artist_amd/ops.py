@@ -195,6 +195,8 @@ def check_async_errors(device=None, clear: bool = True) -> None:
     if rc == -5:
         raise _lib.ArtistHipError(f"a heliostat has more than {BLOCKING_CANDIDATES} blocking rectangles inside its ray cone "
                                   "(found by art_blocking_filter: art_async_status); its blocking would be incomplete")
+    if rc == -6:
+        _ACCUM.clear()              # (a launch that ended abnormally may have left pixel accumulators behind)
     _lib.check(rc, "art_async_status")
 
 

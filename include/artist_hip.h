@@ -40,6 +40,7 @@ extern "C" {
 #define ART_ETARGET -2     /* a target index was outside [0, T + Tc): found on the DEVICE (art_async_status) */
 #define ART_ELAUNCH -3     /* HIP launch or runtime error (see art_last_hip_error) */
 #define ART_EUNSUPPORTED -4
+#define ART_EQUEUE -6      /* a work counter of this stream was not zero at the start of a call: an earlier launch on it ended abnormally (art_async_status) */
 #define ART_ECANDIDATES -5 /* a heliostat has more blocking rectangles inside its ray cone than Cmax: found on the DEVICE (art_async_status) */
 
 /* Library / ABI version (bumped when a signature changes). */

@@ -401,3 +401,29 @@ def test_knobs_are_ignored_outside_debug_mode(golden, monkeypatch, capfd):
     assert "art_trace_fwd:" not in capfd.readouterr().err                 # product mode: ignored
     np.testing.assert_array_equal(plain, base)                             # ... the windowed kernel ran, not the global-atomic one
     assert np.abs(debug - base).max() <= 1e-5 * np.abs(base).max()
+
+
+def test_a_work_counter_left_behind_is_reset_and_reported(golden, monkeypatch):
+    """The persistent kernels pull their work items from counters that the launch's last fetch puts back to zero (no memset per
+    launch).  A launch that ends abnormally would leave a counter behind and every later launch on that stream would skip or repeat
+    items - silently (advisor, round 3).  Now the call's first kernel checks the stream's counters, puts them back to zero and
+    raises the sticky status (ART_EQUEUE): shown by corrupting a counter the way an aborted launch would
+    (ARTIST_HIP_CORRUPT_COUNTER, debug mode): the call that meets it still computes the right bitmaps, the status is reported,
+    later trace calls refuse to start until it is cleared, and then all is well."""
+    from test_gpu_parity import n, trace_inputs
+
+    from artist_amd import ArtistHipError, ops, trace_rays
+    inp = trace_inputs(golden("mid_256"))
+    base = n(trace_rays(**inp)[0])
+    ops.check_async_errors()
+    monkeypatch.setenv("ARTIST_HIP_DEBUG", "1")
+    monkeypatch.setenv("ARTIST_HIP_CORRUPT_COUNTER", "1")
+    hit = n(trace_rays(**inp)[0])
+    monkeypatch.delenv("ARTIST_HIP_CORRUPT_COUNTER")
+    np.testing.assert_array_equal(hit, base)                   # the counter was reset before the trace kernel fetched from it
+    with pytest.raises(ArtistHipError, match="work counter"):
+        trace_rays(**inp)                                      # sticky: nothing is launched on top of a suspect state
+    with pytest.raises(ArtistHipError, match="work counter"):
+        ops.check_async_errors()                               # ... reported (and cleared) here
+    np.testing.assert_array_equal(n(trace_rays(**inp)[0]), base)
+    ops.check_async_errors()
