@@ -38,7 +38,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 HBM_PEAK_FILE = ROOT / "profiles" / "r02_hbm_peak.json"       # tools/hbm_peak.hip on this pool's MI355X (float4 copy / read / write)
-HBM_TRAFFIC_FILE = ROOT / "profiles" / "r03_hbm_traffic.json"  # rocprofv3 --pmc passes of this command (tools/pmc_hbm.sh)
+HBM_TRAFFIC_FILE = ROOT / "profiles" / "r04_hbm_traffic.json"  # rocprofv3 --pmc passes of this command (tools/pmc_hbm.sh)
 
 
 def parse():
