@@ -822,6 +822,128 @@ def surface_reconstructor_epochs(n_epochs=3, dtype=torch.float32):
     return out
 
 
+def kinematics_reconstructor_epochs(n_epochs=3, dtype=torch.float32):
+    """ONE real run of the reference's ``KinematicsReconstructor`` in its flux-driven mode
+    (artist/optim/kinematics_reconstructor.py:886-1065, unmodified): the reference's own scenario file test_blocking.h5 (six
+    heliostats with rigid-body kinematics and linear actuators; heliostat_3 stands behind the target and is left out), two
+    calibration samples per heliostat (one training, one test sample after the reference's split), measured flux = the reference's
+    own chain with the TRUE rotation deviations and the motor positions the true kinematics drives to; the model starts from
+    perturbed deviations and Adam steps them through kinematics -> alignment -> trace -> FocalSpotLoss -> median per heliostat ->
+    mean.  The calibration-data parser is the only stand-in.  Captured per epoch: the rotation deviations at the start, per-sample
+    loss, total loss, their gradient, the learning rate, the deviations after the step."""
+    import h5py     # the stand-in installed by _import_reference()
+    from artist.optim import KinematicsReconstructor
+    from artist.optim.loss import FocalSpotLoss
+    from artist.util import constants
+
+    torch.set_default_dtype(dtype)
+    torch.manual_seed(7)
+    with h5py.File(pathlib.Path(REFERENCE) / "tests/data/scenarios" / "test_blocking.h5", "r") as scenario_file:
+        scenario = Scenario.load_scenario_from_hdf5(
+            scenario_file=scenario_file, number_of_surface_points_per_facet=torch.tensor([12, 12]), device=CPU)
+    scenario.set_number_of_rays(number_of_rays=10)
+    group = scenario.heliostat_field.heliostat_groups[0]
+    kin = group.kinematics
+    res = torch.tensor([64, 64])
+    names = [n_ for n_ in group.names if n_ != "heliostat_3"]
+    suns = [[0.1, 1.0, -0.2, 0.0], [-0.25, 0.9, -0.35, 0.0]]
+    mapping = [(n_, "target_3", torch.nn.functional.normalize(torch.tensor(d_, dtype=torch.float32), dim=0).to(dtype))
+               for n_ in names for d_ in suns]
+    mask, tix, incident = scenario.index_mapping(heliostat_group=group, string_mapping=mapping, device=CPU)
+    n_samples = int(mask.sum())
+    if dtype != torch.float32:
+        sun = scenario.light_sources.light_source_list[0]
+
+        def f32_distortions(number_of_points, number_of_facets=4, number_of_active_heliostats=1, random_seed=7):
+            torch.manual_seed(random_seed)
+            mvn = torch.distributions.MultivariateNormal(torch.zeros(2, dtype=torch.float32),
+                                                         torch.tensor([[4.3681e-06, 0.0], [0.0, 4.3681e-06]], dtype=torch.float32))
+            du, de = mvn.sample((number_of_active_heliostats, sun.number_of_rays, number_of_points)).permute(3, 0, 1, 2)
+            return du.to(dtype), de.to(dtype)
+
+        sun.get_distortions = f32_distortions
+
+    # calibration data with the TRUE kinematics: motor positions it drives to, flux it produces
+    true_rotation = kin.rotation_deviation_parameters.detach().clone()
+    with torch.no_grad():
+        group.activate_heliostats(active_heliostats_mask=mask, device=CPU)
+        group.align_surfaces_with_incident_ray_directions(
+            aim_points=scenario.solar_tower.get_centers_of_target_areas(target_area_indices=tix, device=CPU),
+            incident_ray_directions=incident, active_heliostats_mask=mask, device=CPU)
+        motors = kin.active_motor_positions.detach().clone()
+        rt = HeliostatRayTracer(scenario=scenario, heliostat_group=group, blocking_active=False, batch_size=100, random_seed=3,
+                                bitmap_resolution=res)
+        flux_measured = rt.trace_rays(incident_ray_directions=incident, active_heliostats_mask=mask, target_area_indices=tix,
+                                      device=CPU)[0].clone()
+    g = torch.Generator().manual_seed(5)
+    start = true_rotation + (3e-3 * torch.randn(true_rotation.shape, generator=g, dtype=torch.float32)).to(dtype)
+    kin.rotation_deviation_parameters = start.clone()
+
+    optimizer_dict = {constants.initial_learning_rate_rotation_deviation: 2e-4, constants.tolerance: 0.0, constants.max_epoch: n_epochs - 1,
+                      constants.batch_size: 30, constants.log_step: 0, constants.early_stopping_delta: 1e-9,
+                      constants.early_stopping_patience: 100, constants.early_stopping_window: 10}
+    scheduler_dict = {constants.scheduler_type: constants.exponential, constants.gamma: 0.9}
+    config = {constants.optimization: optimizer_dict, constants.scheduler: scheduler_dict}
+    ddp = dict(device=CPU, is_distributed=False, is_nested=False, rank=0, world_size=1, process_subgroup=None,
+               groups_to_ranks_mapping={0: [0]}, heliostat_group_rank=0, heliostat_group_world_size=1, ranks_to_groups_mapping={0: [0]})
+    rec = KinematicsReconstructor(ddp_setup=ddp, scenario=scenario, data={constants.data_parser: None, constants.heliostat_data_mapping: []},
+                                  optimization_configuration=config, reconstruction_method=constants.kinematics_reconstruction_raytracing,
+                                  bitmap_resolution=res)
+    rec._parse_group_calibration_data = lambda heliostat_group, device: (
+        flux_measured, torch.zeros(n_samples, 4), incident, motors, mask, tix)
+
+    log = dict(start=[], loss_per_sample=[], grad=[], lr=[], after=[], train_idx=None, flux=[])
+    loss_fn = rec._compute_raytracing_loss
+
+    def loss_wrapped(**kw):
+        log["start"].append(npy(kw["heliostat_group"].kinematics.rotation_deviation_parameters).copy())
+        log["train_idx"] = npy(kw["data_split"].train_indices)
+        return loss_fn(**kw)
+
+    rec._compute_raytracing_loss = loss_wrapped
+    setup = rec._setup_optimizer_scheduler_early_stopping
+
+    def setup_wrapped(heliostat_group):
+        optimizer, scheduler, stopper = setup(heliostat_group=heliostat_group)
+        step = optimizer.step
+
+        def step_wrapped(*a, **k):
+            prm = optimizer.param_groups[0]["params"][0]
+            log["grad"].append(npy(prm.grad).copy())
+            log["lr"].append(float(optimizer.param_groups[0]["lr"]))
+            r = step(*a, **k)
+            log["after"].append(npy(prm).copy())
+            return r
+
+        optimizer.step = step_wrapped
+        return optimizer, scheduler, stopper
+
+    rec._setup_optimizer_scheduler_early_stopping = setup_wrapped
+
+    class RecordingLoss(FocalSpotLoss):
+        def __call__(self, *a, **k):
+            out = super().__call__(*a, **k)
+            if out.requires_grad:
+                log["loss_per_sample"].append(npy(out).copy())
+                log["flux"].append(npy(k["prediction"]).copy())
+            return out
+
+    _, history = rec.reconstruct_kinematics(loss_definition=RecordingLoss(scenario=scenario), device=CPU)
+    E = len(log["after"])
+    assert E == n_epochs and len(log["loss_per_sample"]) == E, (E, len(log["loss_per_sample"]))
+    tr = log["train_idx"]
+    out = dict(
+        heliostats=np.asarray([group.names.index(n_) for n_ in names]), suns=np.asarray(suns, dtype=np.float32), target=np.asarray("target_3"),
+        incident_train=npy(incident[tr]), target_idx_train=npy(tix[tr]), motor_positions_train=npy(motors[tr]), train_indices=tr,
+        flux_measured_train=npy(flux_measured[tr]), resolution=npy(res), n_rays=np.int64(10), seed=np.int64(0),
+        points_per_facet=np.asarray([12, 12]), true_rotation=npy(true_rotation),
+        rotation_start=np.stack(log["start"]), flux_predicted=np.stack(log["flux"][:E]), loss_per_sample=np.stack(log["loss_per_sample"][:E]),
+        total_loss=np.asarray(history[0][0]["total_loss"][:E], dtype=np.float64), grad=np.stack(log["grad"]), lr=np.asarray(log["lr"]),
+        rotation_after=np.stack(log["after"]))
+    print("  kinematics reconstructor, total loss per epoch:", out["total_loss"], " |grad|:", [float(np.linalg.norm(g_)) for g_ in out["grad"]])
+    return out
+
+
 def save(name, arrays):
     path = OUT_DIR / f"{name}.npz"
     np.savez_compressed(path, **arrays)
@@ -1289,6 +1411,13 @@ def main():
         save_interop_check()
     if only is None or "kinematics" in only:
         kinematics_fixture()
+    if only is None or "kinematics_reconstructor_epochs" in only:
+        k32 = kinematics_reconstructor_epochs(dtype=torch.float32)
+        k64 = kinematics_reconstructor_epochs(dtype=torch.float64)
+        for key in ("loss_per_sample", "grad", "rotation_after", "total_loss", "flux_predicted"):
+            k32[key + "_f64_epoch0"] = k64[key][0]
+        torch.set_default_dtype(torch.float32)
+        save("kinematics_reconstructor_epochs", k32)
     if only is None or "surface_reconstructor_epochs" in only:
         a32 = surface_reconstructor_epochs(dtype=torch.float32)
         a64 = surface_reconstructor_epochs(dtype=torch.float64)
