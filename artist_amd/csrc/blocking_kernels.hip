@@ -115,40 +115,51 @@ __global__ __launch_bounds__(256) void beam_kernel(TraceArgs a, float max_scatte
     }
 }
 
-// cand_count[h] = number of primitives inside heliostat h's cone (may exceed Cmax: the host checks), ids in cand.
+// cand_count[h] = number of primitives inside heliostat h's cone, ids in cand[h] in ASCENDING order (the order in which the
+// kernels add the rectangles' sigmas: the same in every run), as many as the row holds (Cmax; a longer list is reported).
 __global__ __launch_bounds__(256) void cull_kernel(const Beam* __restrict__ beams, const float* __restrict__ corners, int N,
                                                    int Cmax, int* __restrict__ cand, int* __restrict__ cand_count)
 {
-    __shared__ int s_n;
+    __shared__ int s_wave[4];
     const int h = blockIdx.x;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Beam b = beams[h];
     const float tan_t = b.theta < 1.5f ? tanf(b.theta) : 1e30f;
-    for (int k = threadIdx.x; k < N; k += blockDim.x) {
-        const float* c = corners + 16 * (int64_t)k;
-        float lo[3], hi[3], cen[3];
-        for (int ax = 0; ax < 3; ++ax) {
-            const float v0 = c[ax], v1 = c[4 + ax], v2 = c[8 + ax], v3 = c[12 + ax];
-            lo[ax] = fminf(fminf(v0, v1), fminf(v2, v3));
-            hi[ax] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-            cen[ax] = 0.5f * (lo[ax] + hi[ax]);
+    int base = 0;                                   // (workgroup-uniform) candidates among the rectangles before this round's
+    for (int k0 = 0; k0 < N; k0 += 256) {
+        const int k = k0 + (int)threadIdx.x;
+        bool in_cone = false;
+        if (k < N) {
+            const float* c = corners + 16 * (int64_t)k;
+            float lo[3], hi[3], cen[3];
+            for (int ax = 0; ax < 3; ++ax) {
+                const float v0 = c[ax], v1 = c[4 + ax], v2 = c[8 + ax], v3 = c[12 + ax];
+                lo[ax] = fminf(fminf(v0, v1), fminf(v2, v3));
+                hi[ax] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                cen[ax] = 0.5f * (lo[ax] + hi[ax]);
+            }
+            // radius: the whole box (the filter tests the box) widened by the soft edge of the mask (3 % of a span)
+            const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+            const float rho = 0.5f * sqrtf(ex * ex + ey * ey + ez * ez) * 1.04f + 2e-3f;
+            const float wx = cen[0] - b.cx, wy = cen[1] - b.cy, wz = cen[2] - b.cz;
+            const float ts = wx * b.dx + wy * b.dy + wz * b.dz;
+            const float perp = sqrtf(fmaxf(wx * wx + wy * wy + wz * wz - ts * ts, 0.0f));
+            const float reach = b.r + rho;
+            in_cone = ts >= -reach && perp <= reach + (ts + reach) * tan_t;
         }
-        // radius: the whole box (the filter tests the box) widened by the soft edge of the mask (3 % of a span)
-        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-        const float rho = 0.5f * sqrtf(ex * ex + ey * ey + ez * ez) * 1.04f + 2e-3f;
-        const float wx = cen[0] - b.cx, wy = cen[1] - b.cy, wz = cen[2] - b.cz;
-        const float ts = wx * b.dx + wy * b.dy + wz * b.dz;
-        const float perp = sqrtf(fmaxf(wx * wx + wy * wy + wz * wz - ts * ts, 0.0f));
-        const float reach = b.r + rho;
-        const bool in_cone = ts >= -reach && perp <= reach + (ts + reach) * tan_t;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(in_cone);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = base;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
         if (in_cone) {
-            const int slot = atomicAdd(&s_n, 1);
+            const int slot = before + __popcll(m & ((1ull << lane) - 1ull));
             if (slot < Cmax) cand[(int64_t)h * Cmax + slot] = k;
         }
+        base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) cand_count[h] = s_n;
+    if (threadIdx.x == 0) cand_count[h] = base;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -295,30 +306,22 @@ __global__ void fill_int_kernel(int* p, int n, int v)
 // filter: thread <-> point, loop over a chunk of samples; every ray tests the boxes of the candidates that are
 // still undecided.  grid.x = H * n_ptiles * n_rchunks.
 // ---------------------------------------------------------------------------------------------------
-template <bool INTERLEAVED>
-__global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs a, const float* __restrict__ corners,
-                                                                       const int* __restrict__ owner,
-                                                                       const int* __restrict__ cand,
-                                                                       const int* __restrict__ cand_count, int Cmax,
-                                                                       const int* __restrict__ live,
-                                                                       int* __restrict__ flags)
-{
-    __shared__ float s_box[kMaxCand][6];
-    __shared__ float s_sph[kMaxCand][4];      // centre + half diagonal of the box
-    __shared__ int s_id[kMaxCand];
-    __shared__ int s_done[kMaxCand];
-    __shared__ int s_n, s_left;
+struct FilterTables { float box[kMaxCand][6]; float sph[kMaxCand][4]; int id[kMaxCand]; int done[kMaxCand]; int n, left; };
 
-    const int bid = blockIdx.x;
-    const int ptile = bid % a.n_ptiles;
-    const int rchunk = (bid / a.n_ptiles) % a.n_rchunks;
-    const int h = bid / (a.n_ptiles * a.n_rchunks);
+// One batch of at most kMaxCand candidates of heliostat h (entries c0 ... c0 + nb - 1 of its list): the tables and the lanes'
+// masks hold that many.  The returns before the last barrier are workgroup-uniform.
+template <bool INTERLEAVED>
+__device__ __forceinline__ void blocking_filter_batch(const TraceArgs& a, const float* __restrict__ corners, const int* __restrict__ owner,
+                                                      const int* __restrict__ cand, int Cmax, const int* __restrict__ live,
+                                                      int* __restrict__ flags, FilterTables& tab, int h, int ptile, int rchunk, int c0, int nb)
+{
+    auto& s_box = tab.box; auto& s_sph = tab.sph; auto& s_id = tab.id; auto& s_done = tab.done;
+    int& s_n = tab.n; int& s_left = tab.left;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const int own = owner[h];
-    const int nc = min(cand_count[h], Cmax);
-    for (int c = threadIdx.x; c < nc; c += blockDim.x) {
-        const int k = cand[(int64_t)h * Cmax + c];
+    for (int c = threadIdx.x; c < nb; c += blockDim.x) {
+        const int k = cand[(int64_t)h * Cmax + c0 + c];
         // undecided = foreign (:944-947), reachable in the reference tree, not flagged by an earlier workgroup
         if (k != own && live[k] && !*(volatile const int*)(flags + k)) {
             const int slot = atomicAdd(&s_n, 1);
@@ -430,6 +433,34 @@ __global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs
     }
 }
 
+// The first kMaxCand candidates of every list (REST = false: for every field met so far, the whole list), and - a second
+// launch, made when the rows are wider than the tables - the rest of the longer lists in batches of kMaxCand (the samples are
+// traced once per batch; a workgroup whose list fits the tables leaves at once).  Two instantiations rather than one loop: as a
+// loop the kernel took 97 instead of 66 VGPRs and ran 2.4 times slower at the metric size.
+template <bool INTERLEAVED, bool REST>
+__global__ __launch_bounds__(kFilterBlock) void blocking_filter_kernel(TraceArgs a, const float* __restrict__ corners,
+                                                                       const int* __restrict__ owner,
+                                                                       const int* __restrict__ cand,
+                                                                       const int* __restrict__ cand_count, int Cmax,
+                                                                       const int* __restrict__ live,
+                                                                       int* __restrict__ flags)
+{
+    __shared__ FilterTables tab;
+    const int bid = blockIdx.x;
+    const int ptile = bid % a.n_ptiles;
+    const int rchunk = (bid / a.n_ptiles) % a.n_rchunks;
+    const int h = bid / (a.n_ptiles * a.n_rchunks);
+    const int nc = min(cand_count[h], Cmax);
+    if constexpr (!REST) {
+        blocking_filter_batch<INTERLEAVED>(a, corners, owner, cand, Cmax, live, flags, tab, h, ptile, rchunk, 0, min(nc, kMaxCand));
+    } else {
+        for (int c0 = kMaxCand; c0 < nc; c0 += kMaxCand) {
+            blocking_filter_batch<INTERLEAVED>(a, corners, owner, cand, Cmax, live, flags, tab, h, ptile, rchunk, c0, min(nc - c0, kMaxCand));
+            __syncthreads();                 // every wave is done with this batch's tables
+        }
+    }
+}
+
 // cand[h] <- its flagged entries (the heliostat's own rectangle included when foreign rays flagged it: the
 // reference's mask is evaluated against every filtered primitive for every ray).
 __global__ void compact_kernel(int* __restrict__ cand, int* __restrict__ cand_count, int H, int Cmax,
@@ -483,7 +514,7 @@ extern "C" int art_blocking_filter(const float* origins, const float* normals, c
     if (H == 0) return ART_OK;
     TraceArgs a;
     if (!prim_corners || !owner || !flags || !cand || !cand_count || !workspace || N <= 0 || N > (1 << 22) ||
-        Cmax < 1 || Cmax > kMaxCand ||
+        Cmax < 1 || Cmax > (1 << 22) ||
         !fill_args(a, origins, normals, incident, dist_u, dist_e, dist_sh, dist_sr, dist_sp, target_idx, plane_centers,
                    plane_normals, plane_dims, cyl_centers, cyl_normals, cyl_axes, cyl_radii, cyl_heights, cyl_opening,
                    ray_magnitude, 0.0, 1.0, H, R, P, T, Tc, W, Hh, 0))
@@ -533,11 +564,19 @@ extern "C" int art_blocking_filter(const float* origins, const float* normals, c
     const int64_t blocks = (int64_t)a.H * a.n_ptiles * a.n_rchunks;
     if (blocks > 2147483647LL) return ART_EINVAL;
     if (interleaved_layout(a))
-        hipLaunchKernelGGL(blocking_filter_kernel<true>, dim3((unsigned)blocks), dim3(kFilterBlock), 0, stream, a,
+        hipLaunchKernelGGL((blocking_filter_kernel<true, false>), dim3((unsigned)blocks), dim3(kFilterBlock), 0, stream, a,
                            prim_corners, owner, cand, cand_count, (int)Cmax, live, flags);
     else
-        hipLaunchKernelGGL(blocking_filter_kernel<false>, dim3((unsigned)blocks), dim3(kFilterBlock), 0, stream, a,
+        hipLaunchKernelGGL((blocking_filter_kernel<false, false>), dim3((unsigned)blocks), dim3(kFilterBlock), 0, stream, a,
                            prim_corners, owner, cand, cand_count, (int)Cmax, live, flags);
+    if (Cmax > kMaxCand) {             // the rest of the lists that are longer than the tables (usually none: the workgroups leave at once)
+        if (interleaved_layout(a))
+            hipLaunchKernelGGL((blocking_filter_kernel<true, true>), dim3((unsigned)blocks), dim3(kFilterBlock), 0, stream, a,
+                               prim_corners, owner, cand, cand_count, (int)Cmax, live, flags);
+        else
+            hipLaunchKernelGGL((blocking_filter_kernel<false, true>), dim3((unsigned)blocks), dim3(kFilterBlock), 0, stream, a,
+                               prim_corners, owner, cand, cand_count, (int)Cmax, live, flags);
+    }
     hipLaunchKernelGGL(compact_kernel, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, stream, cand, cand_count, (int)H,
                        (int)Cmax, flags, status_word().dev);
     ART_HIP(hipGetLastError());

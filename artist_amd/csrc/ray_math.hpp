@@ -645,7 +645,7 @@ __device__ __forceinline__ unsigned cone_mask(const Prim* __restrict__ prims, co
 template <bool PRE = false>
 __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ prims, unsigned wave_mask, unsigned mask,
                                                     float ox, float oy, float oz, float rx, float ry, float rz,
-                                                    unsigned& near, float num0 = 0.0f, float num1 = 0.0f)
+                                                    unsigned& near, float num0 = 0.0f, float num1 = 0.0f, float tail = 0.0f)
 {
     float sum = 0.0f;
     near = 0u;
@@ -670,7 +670,8 @@ __device__ __forceinline__ float soft_transmittance(const Prim* __restrict__ pri
         const bool flat = g.sigma_raw == 1.0f;
         near |= s.near && !flat ? 1u << k : 0u;
     }
-    return __expf(-(kBlockAlpha * sum));
+    // (tail: the sigmas of the candidates beyond the tables - trace_kernels.hip, "wide" heliostats; + 0.0f otherwise: the same bits)
+    return __expf(-(kBlockAlpha * (sum + tail)));
 }
 
 // wave-uniform OR of a per-lane mask over the ACTIVE lanes (n <= 32 ballots; once per point, not per ray)

@@ -12,7 +12,8 @@
 namespace art {
 
 constexpr int kBlock = 256;     // 4 waves; one wave per SIMD, several blocks per CU
-constexpr int kMaxCand = 32;    // upper bound of Cmax: candidate tables live in LDS (116 B per rectangle)
+constexpr int kMaxCand = 32;    // candidates of a heliostat held in LDS (116 B per rectangle) and in the lanes' 32-bit masks; the rest of a
+                                // longer list is read from the caller's tables (trace_kernels.hip: "wide" heliostats)
 
 struct TraceArgs {
     const float4* origins;    // [H,P]
@@ -36,7 +37,8 @@ struct TraceArgs {
     const float* prim_normals;  // [N,4]
     const int32_t* cand;        // [H,Cmax] rectangles each heliostat's rays are tested against (art_blocking_filter)
     const int32_t* cand_count;  // [H]
-    int Cmax;
+    int Cmax;                   // row width of `cand` (any size: the first kMaxCand entries of a row go to LDS, the others are "wide")
+    double* wide_grad;          // backward: [H, Cmax - (kMaxCand - 1), 12] gradient sums of the listed candidates of wide heliostats (or NULL)
     float cone_cos, cone_sin;   // of the largest angle between a ray and its point's chief ray (0, 0: unknown)
     int slab_cull;              // per-point rectangle culling also by the three slabs of cone_mask (ray_math.hpp)
     float mag, k_ext, k_refl;
@@ -149,7 +151,7 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
     a.target_idx = target_idx; a.centers = centers; a.pnormals = pnormals; a.dims = dims;
     a.cyl_centers = cyl_centers; a.cyl_normals = cyl_normals; a.cyl_axes = cyl_axes; a.cyl_radii = cyl_radii;
     a.cyl_heights = cyl_heights; a.cyl_opening = cyl_opening; a.Tc = (int)Tc;
-    a.prim_corners = a.prim_spans = a.prim_normals = nullptr; a.cand = a.cand_count = nullptr; a.Cmax = 0;
+    a.prim_corners = a.prim_spans = a.prim_normals = nullptr; a.cand = a.cand_count = nullptr; a.Cmax = 0; a.wide_grad = nullptr;
     a.cone_cos = a.cone_sin = 0.0f; a.slab_cull = 1;
     a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
     a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;

@@ -420,7 +420,12 @@ __device__ __forceinline__ void compute_window(const TraceArgs& a, const Plane& 
 // Blocking rectangles of one heliostat in LDS (empty when the kernel is instantiated without blocking).
 // (grad is DOUBLE: on gfx950 ds_add_f64 retires a wave instruction in ~25 cycles, ds_add_f32 in ~193 - tools/lds_atomic_bench.hip)
 // (GRAD = false: the forward items - no gradient sums, 3 KB less static LDS: room for 4 KB more window)
-template <bool BLOCKING, bool GRAD = true> struct PrimTable { Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; double grad[GRAD ? kMaxCand * 12 : 1]; };
+// (n_wide / xmask: a heliostat with more candidates than the tables hold - see "wide heliostats" below)
+constexpr int kWideFirst = kMaxCand - 1;     // rectangles of such a heliostat that live in the tables
+template <bool BLOCKING, bool GRAD = true> struct PrimTable {
+    Prim prim[kMaxCand]; PrimAux aux[kMaxCand]; int id[kMaxCand]; double grad[GRAD ? kMaxCand * 12 : 1];
+    int n_wide; unsigned long long xmask[16];
+};
 template <bool GRAD> struct PrimTable<false, GRAD> { Prim prim[1]; PrimAux aux[1]; int id[1]; double grad[1]; };
 
 // candidates of heliostat h -> LDS; returns their number (workgroup-uniform).  Ends with a barrier.
@@ -428,7 +433,11 @@ template <bool BLOCKING, bool GRAD = true>
 __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<BLOCKING, GRAD>& tab)
 {
     if constexpr (!BLOCKING) return 0;
-    const int n = min(a.cand_count[h], a.Cmax);
+    else {
+    const int listed = min(a.cand_count[h], a.Cmax);
+    // a list longer than the tables: kWideFirst rectangles in the tables, the others are read from the list ("wide heliostats")
+    const int n = listed > kMaxCand ? kWideFirst : listed;
+    if (threadIdx.x == 0) tab.n_wide = listed > kMaxCand ? listed : 0;
     for (int c = threadIdx.x; c < n; c += blockDim.x) {
         const int k = a.cand[(int64_t)h * a.Cmax + c];
         tab.id[c] = k;
@@ -438,7 +447,113 @@ __device__ __forceinline__ int load_prims(const TraceArgs& a, int h, PrimTable<B
     if constexpr (GRAD) for (int c = threadIdx.x; c < n * 12; c += blockDim.x) tab.grad[c] = 0.0;
     __syncthreads();
     return n;
+    }
 }
+
+// ---- "wide" heliostats: more than kMaxCand candidate rectangles ---------------------------------------------------------
+// The tables above and the lanes' 32-bit masks serve a heliostat's first kMaxCand candidates - every heliostat of every field
+// met so far.  A heliostat with a longer list (a dense row field under a low sun) is not refused: the soft mask is
+// exp(-alpha sum sigma), so the candidates beyond the tables add their sigmas to the same sum.  Such a heliostat keeps
+// kWideFirst = kMaxCand - 1 rectangles in the tables (load_prims; PrimTable::n_wide = the length of its list), and bit 31 of
+// its masks stands for all the others: set in a wave's mask when a ray of the wave's points can reach one of them (so the
+// kernels' one test "wmask != 0" still decides whether a ray looks at rectangles at all, and their hot loops carry nothing
+// new), set in a ray's `near` mask when the ray entered the soft edge of one of them.  The others are read from the caller's
+// tables (wave-uniform addresses), their constants rebuilt per use (make_prim), and every lane evaluates them with the same
+// functions as the tabled ones - soft_plane, soft_uv, soft_sigma: a ray outside a rectangle's soft edge fails their own tests,
+// which is all the lane masks ever anticipated.  Per point a wave keeps (in LDS, PrimTable::xmask) a 64-bit mask of the first 64
+// such candidates its rays can reach at all (bounding sphere against the cone of the scattered rays, as in cone_mask);
+// candidates beyond those 64 are evaluated for every ray.  Everything here runs behind "bit 31 is set": cold code.
+struct WideTabs {
+    const float* corners; const float* spans; const float* normals;
+    const int32_t* row;        // this heliostat's candidate list
+    double* grad_row;          // backward: its [n - kWideFirst, 12] gradient sums (NULL: forward)
+    float cone_cos, cone_sin;
+    int n;                     // length of the list (> kMaxCand)
+};
+// rows of an item's slab of rectangle gradients: the candidates of the tables (the others' sums: TraceArgs::wide_grad)
+__host__ __device__ __forceinline__ int slab_rows(const TraceArgs& a) { return a.Cmax < kMaxCand ? a.Cmax : kMaxCand; }
+__device__ __forceinline__ WideTabs wide_tabs(const TraceArgs& a, int h, int n)
+{
+    WideTabs w;
+    w.corners = a.prim_corners; w.spans = a.prim_spans; w.normals = a.prim_normals;
+    w.row = a.cand + (int64_t)h * a.Cmax;
+    w.grad_row = a.wide_grad != nullptr ? a.wide_grad + ((int64_t)h * (a.Cmax - kWideFirst)) * 12 : nullptr;
+    w.cone_cos = a.cone_cos; w.cone_sin = a.cone_sin;
+    w.n = n;
+    return w;
+}
+__device__ __forceinline__ Prim wide_prim(const WideTabs& w, int c)
+{
+    const int k = __builtin_amdgcn_readfirstlane(w.row[c]);
+    return make_prim(w.corners, w.spans, w.normals, k);
+}
+// One point per lane of a wide heliostat (o, chief direction d - not normalised): which of the candidates kWideFirst ...
+// kWideFirst + 63 can a ray of this wave's points touch -> the wave's word of tab.xmask; returns bit 31 if any can, or if the
+// list goes on beyond them.  0 for a heliostat whose list fits the tables.
+template <bool GRAD>
+__device__ __forceinline__ unsigned wide_point(const TraceArgs& a, int h, PrimTable<true, GRAD>& tab, float ox, float oy, float oz,
+                                               float dx, float dy, float dz)
+{
+    const int n_list = __builtin_amdgcn_readfirstlane(tab.n_wide);
+    if (__builtin_expect(n_list == 0, 1)) return 0u;
+    const WideTabs w = wide_tabs(a, h, n_list);
+    const float il = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-30f));
+    dx *= il; dy *= il; dz *= il;
+    unsigned long long bits = 0ull;
+    const int n = min(w.n, kWideFirst + 64);
+    for (int c = kWideFirst; c < n; ++c) {
+        const Prim q = wide_prim(w, c);
+        const float wx = q.cx - ox, wy = q.cy - oy, wz = q.cz - oz;
+        const float l2 = wx * wx + wy * wy + wz * wz;
+        const float t = wx * dx + wy * dy + wz * dz;
+        const float perp = sqrtf(fmaxf(l2 - t * t, 0.0f));
+        if (wave_any(perp * w.cone_cos - t * w.cone_sin <= q.rho || l2 <= q.rho * q.rho)) bits |= 1ull << (c - kWideFirst);
+    }
+    if ((threadIdx.x & 63) == 0) tab.xmask[threadIdx.x >> 6] = bits;       // (read back by this wave only: no barrier)
+    return bits != 0ull || w.n > kWideFirst + 64 ? 0x80000000u : 0u;
+}
+template <bool GRAD> __device__ __forceinline__ unsigned wide_point(const TraceArgs&, int, PrimTable<false, GRAD>&, float, float, float, float, float, float) { return 0u; }
+
+// One ray per lane, the wave's mask has bit 31: if the heliostat is wide (otherwise bit 31 is its 32nd tabled rectangle and
+// nothing happens), the bit is cleared in `wm` - the mask of TABLED rectangles for soft_transmittance and the adjoint - and
+// the sigmas of the listed candidates come back (sum; near: this lane's ray entered a soft edge among them with a gradient).
+struct WideSum { float sum; int near; };
+template <typename ONE> __device__ __forceinline__ void wide_for_each(const WideTabs& w, unsigned long long bits, ONE&& one)
+{
+    for (int c = kWideFirst; c < w.n; ++c) {
+        if (c < kWideFirst + 64 && ((bits >> (c - kWideFirst)) & 1ull) == 0ull) continue;       // (wave-uniform)
+        one(c);
+    }
+}
+template <bool GRAD>
+__device__ __forceinline__ WideSum wide_ray(const TraceArgs& a, int h, PrimTable<true, GRAD>& tab, unsigned& wm, float ox, float oy,
+                                            float oz, float rx, float ry, float rz)
+{
+    WideSum out = {0.0f, 0};
+    const int n_list = __builtin_amdgcn_readfirstlane(tab.n_wide);
+    if (n_list == 0) return out;
+    wm &= 0x7FFFFFFFu;
+    const WideTabs w = wide_tabs(a, h, n_list);
+    unsigned long long bits = tab.xmask[threadIdx.x >> 6];
+    bits = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
+    float sum = 0.0f;
+    bool near = false;
+    wide_for_each(w, bits, [&](int c) {
+        const Prim q = wide_prim(w, c);
+        SoftHit s;
+        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, s);
+        if (!wave_any(in_front)) return;
+        soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, s);
+        if (!wave_any(s.near)) return;
+        SoftSig g;
+        const float sg = soft_sigma(s, g);
+        sum += s.near ? sg : 0.0f;
+        near |= s.near && g.sigma_raw != 1.0f;
+    });
+    out.sum = sum; out.near = near ? 1 : 0;
+    return out;
+}
+template <bool GRAD> __device__ __forceinline__ WideSum wide_ray(const TraceArgs&, int, PrimTable<false, GRAD>&, unsigned&, float, float, float, float, float, float) { WideSum z = {0.0f, 0}; return z; }
 
 // Work items of the windowed kernels.  A CU holds one workgroup (the window fills its LDS), so the grid is one
 // PERSISTENT workgroup per CU that pulls (heliostat, point block, sample chunk) items from a counter in global memory:
@@ -662,6 +777,7 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
                 pmask = cone_mask(s_tab.prim, s_tab.aux, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin,
                                   a.slab_cull != 0);
                 wmask = wave_or_mask(pmask, n_prims);
+                wmask |= wide_point(a, h, s_tab, o.x, o.y, o.z, d.x, d.y, d.z);     // (bit 31: see there)
             }
         }
         // One ray: scatter -> hit -> weights -> 4 pipelined LDS adds.  Ray arithmetic is the reference's
@@ -712,8 +828,10 @@ __device__ __forceinline__ void trace_fwd_item(const TraceArgs& a, float* __rest
                 // (blocking.py:212-354; heliostat_ray_tracer.py:462-480)
                 float blocked = 0.0f;
                 if (wmask != 0u) {
-                    unsigned near;
-                    blocked = 1.0f - soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);   // :364-365
+                    unsigned near, wm = wmask;
+                    float tail = 0.0f;           // the sigmas of the candidates beyond the tables (a wide heliostat)
+                    if (__builtin_expect((wmask >> 31) != 0u, 0)) tail = wide_ray(a, h, s_tab, wm, o.x, o.y, o.z, rx, ry, rz).sum;
+                    blocked = 1.0f - soft_transmittance(s_tab.prim, wm, pmask, o.x, o.y, o.z, rx, ry, rz, near, 0.0f, 0.0f, tail);   // :364-365
                     keep = 1.0f - blocked;       // exactly 0 once the transmittance drops below 2^-25, as in the reference
                 }
                 n_free += __popcll(__builtin_amdgcn_ballot_w64(blocked < 1e-3f));
@@ -1067,6 +1185,9 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 if (rest != 0u) bnum1 = soft_plane_num(s_tab.prim[__builtin_ctz(rest)], o.x, o.y, o.z);
             }
         }
+        if constexpr (BLOCKING) {          // (after the two numerators: they belong to tabled rectangles)
+            if (n_prims > 0) wmask |= wide_point(a, h, s_tab, o.x, o.y, o.z, d.x, d.y, d.z);     // (bit 31: see there)
+        }
         auto carries = [&]() {                       // cold: a cell of the previous ray wrapped (see resolve_carries)
             PendingSplat ps = {po1, po2, po3, po4, pq1, pq2, pq3, pq4, (int)ptbe, (int)ptbu};
             resolve_carries(ps, acc, a.W, a.Hh, win.shift);
@@ -1119,8 +1240,10 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
                 // 2^-25, as in the reference
                 float blocked = 0.0f, keep = 1.0f;
                 if (wmask != 0u) {
-                    unsigned near;
-                    blocked = 1.0f - soft_transmittance<true>(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1);
+                    unsigned near, wm = wmask;
+                    float tail = 0.0f;           // the sigmas of the candidates beyond the tables (a wide heliostat)
+                    if (__builtin_expect((wmask >> 31) != 0u, 0)) tail = wide_ray(a, h, s_tab, wm, o.x, o.y, o.z, rx, ry, rz).sum;
+                    blocked = 1.0f - soft_transmittance<true>(s_tab.prim, wm, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1, tail);
                     keep = 1.0f - blocked;
                 }
                 n_free += __popcll(ballot64(blocked < 1e-3f) & live);
@@ -1762,6 +1885,55 @@ __device__ __attribute__((noinline)) AdjointOut block_adjoint(LdsPrims prims, Pr
     return block_adjoint_body<false>(prims, sums, unused, unused2, wave_mask, near, ox, oy, oz, rx, ry, rz, g_sigma);
 }
 
+// The same adjoint for the listed candidates of a wide heliostat (see wide_ray; all lanes of the wave are active here): `wm`
+// and `nr` - the wave's and this lane's masks - lose their bit 31, the ray side is returned, the rectangle side - twelve wave
+// sums per rectangle with a lane in its soft edge - goes to the heliostat's row of `wide_grad` by fp64 atomics (the items of a
+// heliostat share the row; the sums are rounded to fp32 once, by reduce_prim_grads_kernel: their order can move the result by
+// an fp64 rounding, not by an fp32 one except in a tie).
+template <bool GRAD>
+__device__ __forceinline__ RayGrad wide_ray_adjoint(const TraceArgs& a, int h, PrimTable<true, GRAD>& tab, unsigned& wm, unsigned& nr,
+                                                    float ox, float oy, float oz, float rx, float ry, float rz, float g_sigma)
+{
+    RayGrad out = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n_list = __builtin_amdgcn_readfirstlane(tab.n_wide);
+    if (n_list == 0) return out;
+    const bool adj = (nr >> 31) != 0u;
+    wm &= 0x7FFFFFFFu; nr &= 0x7FFFFFFFu;
+    if (!wave_any(adj)) return out;
+    const WideTabs w = wide_tabs(a, h, n_list);
+    unsigned long long bits = tab.xmask[threadIdx.x >> 6];
+    bits = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
+    const int lane = threadIdx.x & 63;
+    wide_for_each(w, bits, [&](int c) {
+        const Prim q = wide_prim(w, c);
+        SoftHit sh;
+        const bool in_front = soft_plane(q, ox, oy, oz, rx, ry, rz, sh);
+        soft_uv(q, ox, oy, oz, rx, ry, rz, in_front, sh);
+        if (!wave_any(adj && sh.near)) return;
+        SoftSig sg;
+        (void)soft_sigma(sh, sg);
+        const bool on = adj && sh.near && sg.sigma_raw != 1.0f;
+        if (!wave_any(on)) return;
+        SoftGrad g;
+        soft_sigma_bwd(q, ox, oy, oz, rx, ry, rz, sh, sg, on ? g_sigma : 0.0f, g);
+        if (on) {     // other lanes may hold non-finite intermediates: branch, do not multiply
+            out.ox += g.ox; out.oy += g.oy; out.oz += g.oz;
+            out.rx += g.rx; out.ry += g.ry; out.rz += g.rz;
+        }
+        const float part[12] = {on ? g.c0[0] : 0.f, on ? g.c0[1] : 0.f, on ? g.c0[2] : 0.f, on ? g.su[0] : 0.f, on ? g.su[1] : 0.f,
+                                on ? g.su[2] : 0.f, on ? g.sv[0] : 0.f, on ? g.sv[1] : 0.f, on ? g.sv[2] : 0.f, on ? g.n[0] : 0.f,
+                                on ? g.n[1] : 0.f, on ? g.n[2] : 0.f};
+        double* __restrict__ cell = w.grad_row + (int64_t)(c - kWideFirst) * 12;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const float total = wave_reduce<kSum>(part[j]);          // wave-uniform
+            if (lane == 0 && w.grad_row != nullptr) atomicAdd(cell + j, (double)total);
+        }
+    });
+    return out;
+}
+template <bool GRAD> __device__ __forceinline__ RayGrad wide_ray_adjoint(const TraceArgs&, int, PrimTable<false, GRAD>&, unsigned&, unsigned&, float, float, float, float, float, float, float) { RayGrad z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return z; }
+
 // A heliostat that is skipped because its target index is outside the tables (ART_ETARGET, target_in_range) gets ZERO
 // gradients for the item's points - `grad_origins` / `grad_normals` (or the item's chunk slab) are the caller's uninitialised
 // memory, and the status word may not have reached the host before the optimiser reads them.  (Both launches of a split call
@@ -1838,8 +2010,8 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
         if (bad_target) {
             zero_block_gradients(a, item, grad_origins, grad_normals);
             if constexpr (BLOCKING) {                // ... and no rectangle gradients from this item either
-                float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
-                for (int c = tid; c < a.Cmax * 12; c += blockDim.x) slab[c] = 0.0f;
+                float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * slab_rows(a) * 12;
+                for (int c = tid; c < slab_rows(a) * 12; c += blockDim.x) slab[c] = 0.0f;
             }
         }
         if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
@@ -1909,6 +2081,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
                 pmask = cone_mask(s_tab.prim, s_tab.aux, n_prims, o.x, o.y, o.z, d.x * il, d.y * il, d.z * il, a.cone_cos, a.cone_sin,
                                   a.slab_cull != 0);
                 wmask = wave_or_mask(pmask, n_prims);
+                wmask |= wide_point(a, h, s_tab, o.x, o.y, o.z, d.x, d.y, d.z);     // (bit 31: see there)
             }
         }
         // One ray.  The forward re-computation is the reference's arithmetic (it decides which cells the ray
@@ -1922,7 +2095,11 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
             unsigned near = 0u;                                    // rectangles whose soft mask this ray entered
             if constexpr (BLOCKING) {
                 if (wmask != 0u) {
-                    trans = soft_transmittance(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near);
+                    unsigned wm = wmask;
+                    WideSum ws = {0.0f, 0};                        // the sigmas of the candidates beyond the tables (a wide heliostat)
+                    if (__builtin_expect((wmask >> 31) != 0u, 0)) ws = wide_ray(a, h, s_tab, wm, o.x, o.y, o.z, rx, ry, rz);
+                    trans = soft_transmittance(s_tab.prim, wm, pmask, o.x, o.y, o.z, rx, ry, rz, near, 0.0f, 0.0f, ws.sum);
+                    near |= (unsigned)ws.near << 31;               // (bit 31 of a wide heliostat's masks stands for all of them)
                     keep = 1.0f - (1.0f - trans);                  // the reference's rounding (blocked = 1 - trans)
                 }
             }
@@ -1932,10 +2109,15 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
                     // only rays inside some rectangle's mask that still carry light have a gradient through it
                     const bool adj = lane_live && near != 0u && g_keep != 0.0f && trans > 1e-30f;
                     if (wave_any(adj)) {
-                        const AdjointOut ao = block_adjoint((LdsPrims)s_tab.prim, prim_sums, wmask, adj ? near : 0u, o.x, o.y,
+                        unsigned wm = wmask, nr = adj ? near : 0u;
+                        RayGrad x = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if (__builtin_expect((wmask >> 31) != 0u, 0))
+                            x = wide_ray_adjoint(a, h, s_tab, wm, nr, o.x, o.y, o.z, rx, ry, rz, -kBlockAlpha * trans * g_keep);
+                        const AdjointOut ao = block_adjoint((LdsPrims)s_tab.prim, prim_sums, wm, nr, o.x, o.y,
                                                             o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f);
                         prim_sums = ao.sums;
-                        const RayGrad b = ao.ray;
+                        RayGrad b = ao.ray;
+                        b.ox += x.ox; b.oy += x.oy; b.oz += x.oz; b.rx += x.rx; b.ry += x.ry; b.rz += x.rz;
                         bgx += b.ox; bgy += b.oy; bgz += b.oz;
                         gdx += m.cu * b.rx + m.m10 * b.ry + m.m20 * b.rz;
                         gdy += m.m11 * b.ry + m.m21 * b.rz - m.su * b.rx;
@@ -2100,7 +2282,7 @@ __device__ __forceinline__ void trace_bwd_item(const TraceArgs& a, const float* 
             }
             __syncthreads();
         }
-        float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
+        float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * slab_rows(a) * 12;
         for (int c = tid; c < n_prims * 12; c += blockDim.x) slab[c] = (float)s_tab.grad[c];
     }
 }
@@ -2148,8 +2330,8 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
         if (bad_target) {
             zero_block_gradients(a, item, grad_origins, grad_normals);
             if constexpr (BLOCKING) {                // ... and no rectangle gradients from this item either
-                float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
-                for (int c = tid; c < a.Cmax * 12; c += blockDim.x) slab[c] = 0.0f;
+                float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * slab_rows(a) * 12;
+                for (int c = tid; c < slab_rows(a) * 12; c += blockDim.x) slab[c] = 0.0f;
             }
         }
         if (tid == 0) *s_next = (int)(gridDim.x + fetch_work_item(work_counter, a));
@@ -2253,6 +2435,9 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 if (rest != 0u) bnum1 = soft_plane_num(s_tab.prim[__builtin_ctz(rest)], o.x, o.y, o.z);
             }
         }
+        if constexpr (BLOCKING) {          // (after the two numerators: they belong to tabled rectangles)
+            if (n_prims > 0) wmask |= wide_point(a, h, s_tab, o.x, o.y, o.z, d.x, d.y, d.z);     // (bit 31: see there)
+        }
         auto trace_one = [&](const float u, const float e, const unsigned long long live) {
             // sun-shape angles are milliradians: the Taylor kernels serve every lane almost always; only the rotation's
             // sines and cosines sit behind the (wave-uniform) branch - two copies of the whole ray body made the compiler
@@ -2335,7 +2520,11 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                 [[maybe_unused]] unsigned near = 0u;
                 if constexpr (BLOCKING) {
                     if (wmask != 0u) {
-                        trans = soft_transmittance<true>(s_tab.prim, wmask, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1);
+                        unsigned wm = wmask;
+                        WideSum ws = {0.0f, 0};                               // the sigmas of the candidates beyond the tables (a wide heliostat)
+                        if (__builtin_expect((wmask >> 31) != 0u, 0)) ws = wide_ray(a, h, s_tab, wm, o.x, o.y, o.z, rx, ry, rz);
+                        trans = soft_transmittance<true>(s_tab.prim, wm, pmask, o.x, o.y, o.z, rx, ry, rz, near, bnum0, bnum1, ws.sum);
+                        near |= (unsigned)ws.near << 31;                      // (bit 31 of a wide heliostat's masks stands for all of them)
                         g_keep_scale = kIm * (-ah);                           // dI / d(keep) = mag (-a) k_ext k_refl for a ray in use
                         kIm *= 1.0f - (1.0f - trans);                         // keep, with the reference's rounding (blocked = 1 - trans)
                     }
@@ -2364,10 +2553,15 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
                     const float g_keep = gI * g_keep_scale;
                     const bool adj = lane_live && near != 0u && g_keep != 0.0f && trans > 1e-30f;
                     if (wave_any(adj)) {
-                        const AdjointOut ao = block_adjoint_body<true>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wmask, adj ? near : 0u, o.x, o.y,
-                                                                       o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f, bnum0, bnum1);
+                        unsigned wm = wmask, nr = adj ? near : 0u;
+                        RayGrad x = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if (__builtin_expect((wmask >> 31) != 0u, 0))
+                            x = wide_ray_adjoint(a, h, s_tab, wm, nr, o.x, o.y, o.z, rx, ry, rz, -kBlockAlpha * trans * g_keep);
+                        AdjointOut ao = block_adjoint_body<true>((LdsPrims)s_tab.prim, prim_sums, point_sums, point_sums2, wm, nr, o.x, o.y,
+                                                                 o.z, rx, ry, rz, adj ? -kBlockAlpha * trans * g_keep : 0.0f, bnum0, bnum1);
                         point_touched = true;
                         prim_sums = ao.sums;
+                        ao.ray.ox += x.ox; ao.ray.oy += x.oy; ao.ray.oz += x.oz; ao.ray.rx += x.rx; ao.ray.ry += x.ry; ao.ray.rz += x.rz;
                         bgx += ao.ray.ox; bgy += ao.ray.oy; bgz += ao.ray.oz;
                         gdx += m.cu * ao.ray.rx + m.m10 * ao.ray.ry + m.m20 * ao.ray.rz;
                         gdy += m.m11 * ao.ray.ry + m.m21 * ao.ray.rz - m.su * ao.ray.rx;
@@ -2470,7 +2664,7 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
             }
             __syncthreads();
         }
-        float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * a.Cmax * 12;
+        float* __restrict__ slab = prim_slabs + ((int64_t)(item.h * a.n_pblocks + item.pblock) * a.n_rchunks + item.rchunk) * slab_rows(a) * 12;
         for (int c = tid; c < n_prims * 12; c += blockDim.x) slab[c] = (float)s_tab.grad[c];
     }
 }
@@ -2565,13 +2759,24 @@ __global__ __launch_bounds__(256) void reduce_chunks_kernel(const float4* __rest
 // and the 256 partial sums are added in thread order by a fixed tree: bit-reproducible.  A heliostat whose list is empty
 // (the lean launch of a split call traced it) or overflowed beyond Cmax (truncated; reported) contributes its first
 // min(count, Cmax) candidates like the kernels that filled the slabs.
-__global__ __launch_bounds__(256) void reduce_prim_grads_kernel(const float* __restrict__ slabs, const int32_t* __restrict__ cand,
+// (a wide heliostat - more than kMaxCand candidates -: the sums of its candidates c >= kWideFirst are its fp64 row of `wide`)
+__global__ __launch_bounds__(256) void wide_grad_zero_kernel(const int32_t* __restrict__ cand_count, int Cmax, double* __restrict__ wide)
+{
+    const int h = blockIdx.x;
+    const int listed = min(cand_count[h], Cmax);
+    if (listed <= kMaxCand) return;
+    double* __restrict__ row = wide + (int64_t)h * (Cmax - kWideFirst) * 12;
+    for (int i = threadIdx.x; i < (listed - kWideFirst) * 12; i += blockDim.x) row[i] = 0.0;
+}
+__global__ __launch_bounds__(256) void reduce_prim_grads_kernel(const float* __restrict__ slabs, const double* __restrict__ wide,
+                                                                const int32_t* __restrict__ cand,
                                                                 const int32_t* __restrict__ cand_count, int H, int Cmax,
                                                                 int items_per_heliostat, float* __restrict__ g_corners,
                                                                 float* __restrict__ g_spans, float* __restrict__ g_pnormals)
 {
     __shared__ float s_part[256][13];              // (+1: no bank conflicts in the tree)
     const int k = blockIdx.x, tid = threadIdx.x;
+    const int rows = min(Cmax, kMaxCand);          // of an item's slab
     float acc[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) acc[j] = 0.0f;
@@ -2579,8 +2784,14 @@ __global__ __launch_bounds__(256) void reduce_prim_grads_kernel(const float* __r
         const int nc = min(cand_count[h], Cmax);
         for (int c = 0; c < nc; ++c) {
             if (cand[(int64_t)h * Cmax + c] != k) continue;
+            if (nc > kMaxCand && c >= kWideFirst) {
+                const double* __restrict__ v = wide + ((int64_t)h * (Cmax - kWideFirst) + (c - kWideFirst)) * 12;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) acc[j] += (float)v[j];
+                continue;
+            }
             for (int it = 0; it < items_per_heliostat; ++it) {
-                const float* __restrict__ v = slabs + (((int64_t)h * items_per_heliostat + it) * Cmax + c) * 12;
+                const float* __restrict__ v = slabs + (((int64_t)h * items_per_heliostat + it) * rows + c) * 12;
 #pragma unroll
                 for (int j = 0; j < 12; ++j) acc[j] += v[j];
             }
@@ -3007,12 +3218,15 @@ static size_t bwd_main_geometry(TraceArgs& a, FwdConfig& cfg, bool lean, bool le
 
 // Scratch floats a backward launch of geometry `a` needs: [n_rchunks,H,P,8] slabs of partial point gradients when the samples
 // are cut into chunks, then one [Cmax,12] slab of rectangle gradients per item when blocking is on.
-struct BwdScratch { int64_t chunk_floats, slab_floats; };
+// (a candidate list longer than the tables - Cmax > kMaxCand -: the slabs hold the tables' rows, and the candidates beyond them
+//  have one fp64 row [Cmax - kWideFirst, 12] per heliostat behind the slabs, TraceArgs::wide_grad)
+struct BwdScratch { int64_t chunk_floats, slab_floats, wide_floats; };
 static BwdScratch bwd_scratch_need(const TraceArgs& a, bool blocking, int64_t Cmax)
 {
     BwdScratch n;
     n.chunk_floats = a.n_rchunks > 1 ? (int64_t)a.n_rchunks * a.H * a.P * 8 : 0;
-    n.slab_floats = blocking ? (int64_t)a.H * a.n_pblocks * a.n_rchunks * Cmax * 12 : 0;
+    n.slab_floats = blocking ? (int64_t)a.H * a.n_pblocks * a.n_rchunks * std::min<int64_t>(Cmax, kMaxCand) * 12 : 0;
+    n.wide_floats = blocking && Cmax > kMaxCand ? (int64_t)a.H * (Cmax - kWideFirst) * 12 * 2 : 0;
     return n;
 }
 
@@ -3059,7 +3273,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
     a.status = status.dev;
     const bool blocking = prim_corners != nullptr;
     if (blocking) {
-        if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > kMaxCand) return ART_EINVAL;
+        if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > (1 << 22)) return ART_EINVAL;
         a.prim_corners = prim_corners; a.prim_spans = prim_spans; a.prim_normals = prim_normals;
         a.cand = cand; a.cand_count = cand_count; a.Cmax = (int)Cmax;
         set_cone(a, max_scatter_angle);
@@ -3313,7 +3527,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
     }
     const bool blocking = prim_corners != nullptr;
     if (blocking) {
-        if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > kMaxCand || N <= 0 ||
+        if (!prim_spans || !prim_normals || !cand || !cand_count || Cmax < 1 || Cmax > (1 << 22) || N <= 0 ||
             !grad_prim_corners || !grad_prim_spans || !grad_prim_normals)
             return ART_EINVAL;
         a.prim_corners = prim_corners; a.prim_spans = prim_spans; a.prim_normals = prim_normals;
@@ -3339,7 +3553,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         // (no float atomics: bit-reproducible gradients).  Without (enough) scratch the samples stay in one item.
         const bool scratch_usable = grad_scratch != nullptr && (reinterpret_cast<uintptr_t>(grad_scratch) % 16) == 0;
         BwdScratch need = bwd_scratch_need(a, blocking, Cmax);
-        if (a.n_rchunks > 1 && (!scratch_usable || grad_scratch_floats < need.chunk_floats + need.slab_floats)) {
+        if (a.n_rchunks > 1 && (!scratch_usable || grad_scratch_floats < need.chunk_floats + need.slab_floats + need.wide_floats)) {
             cfg = cfg0;
             perm_bytes = bwd_main_geometry(a, cfg, lean, lean_block, facet_points, true);
             need = bwd_scratch_need(a, blocking, Cmax);
@@ -3352,9 +3566,13 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         // (behind the chunk slabs); reduce_prim_grads_kernel adds them in item order.
         float* prim_slabs = nullptr;
         if (blocking) {
-            if (!scratch_usable || grad_scratch_floats < need.chunk_floats + need.slab_floats)
+            if (!scratch_usable || grad_scratch_floats < need.chunk_floats + need.slab_floats + need.wide_floats)
                 return ART_EINVAL;                    // (art_trace_bwd_scratch_floats says how much)
             prim_slabs = grad_scratch + need.chunk_floats;
+            if (need.wide_floats > 0) {               // (both float counts before it are multiples of four: 8-byte aligned)
+                a.wide_grad = reinterpret_cast<double*>(prim_slabs + need.slab_floats);
+                hipLaunchKernelGGL(wide_grad_zero_kernel, dim3((unsigned)H), dim3(256), 0, stream, a.cand_count, a.Cmax, a.wide_grad);
+            }
         }
         SideJoin side = {nullptr};                    // (joins `stream` when this scope is left, errors included)
         std::function<int()> launch_lean;
@@ -3461,7 +3679,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
         if (launch_lean) { const int rc = launch_lean(); if (rc != ART_OK) return rc; }
         if (blocking) {
             if (side.s) { side.s->end(); side.s = nullptr; }        // (the lean launch wrote no slabs, but `stream` must own what follows)
-            hipLaunchKernelGGL(reduce_prim_grads_kernel, dim3((unsigned)N), dim3(256), 0, stream, prim_slabs, a.cand, a.cand_count, a.H,
+            hipLaunchKernelGGL(reduce_prim_grads_kernel, dim3((unsigned)N), dim3(256), 0, stream, prim_slabs, a.wide_grad, a.cand, a.cand_count, a.H,
                                a.Cmax, a.n_pblocks * a.n_rchunks, grad_prim_corners, grad_prim_spans, grad_prim_normals);
             ART_HIP(hipGetLastError());
         }
@@ -3487,7 +3705,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
 // blocking on), when it is given at least that much: the floats of the geometry it then takes.  Host arithmetic only.
 extern "C" int64_t art_trace_bwd_scratch_need(int64_t H, int64_t R, int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t Cmax)
 {
-    if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || Cmax < 0 || Cmax > kMaxCand || T < 0 || Tc < 0) return 0;
+    if (H <= 0 || R <= 0 || P <= 0 || H > (1 << 24) || R > (1 << 24) || P > (1 << 26) || Cmax < 0 || Cmax > (1 << 22) || T < 0 || Tc < 0) return 0;
     FwdConfig cfg = fwd_config();
     if (cfg.variant != 0) return 0;
     if (facet_points < 0 || (facet_points > 0 && P % facet_points != 0)) return 0;
@@ -3497,7 +3715,7 @@ extern "C" int64_t art_trace_bwd_scratch_need(int64_t H, int64_t R, int64_t P, i
     if (blocking && cfg.tile_cap > 148 * 256) cfg.tile_cap = 148 * 256;
     (void)bwd_main_geometry(a, cfg, bwd_uses_lean(blocking, T, Tc), bwd_uses_lean_block(blocking, T, Tc), facet_points, false);
     const BwdScratch n = bwd_scratch_need(a, blocking, Cmax);
-    return n.chunk_floats + n.slab_floats;
+    return n.chunk_floats + n.slab_floats + n.wide_floats;
 }
 
 // The caller's side of it: enough for every receiver configuration (the tables' types are not known when the buffer is

@@ -143,8 +143,12 @@ def _planar_ptrs(centers, plane_normals, dims):
     return (centers.data_ptr(), plane_normals.data_ptr(), dims.data_ptr())
 
 
-#: capacity of a heliostat's list of candidate blocking rectangles (``Cmax`` of art_blocking_filter, <= 32)
-BLOCKING_CANDIDATES = 32
+#: Row width of a heliostat's list of candidate blocking rectangles (``Cmax`` of art_blocking_filter) - workspace, not a limit of
+#: the kernels: they keep the first 32 rectangles of a list in LDS and read any others from the list itself (slower, never
+#: refused).  A list that does not fit its ROW is reported (ART_ECANDIDATES: workspace exhausted - raise this number; ``None`` =
+#: the number of rectangles, which no list can exceed; 4 B per heliostat and entry, 96 B more in the backward scratch).
+BLOCKING_CANDIDATES = 256
+_LAST_BLOCKING = None
 
 # Pixel accumulators of art_trace_fwd ([n_maps,Hh,W] uint64, zero on entry and zero again afterwards): one buffer per
 # (device, stream), grown on demand, so that calls on different streams never share one.
@@ -193,8 +197,9 @@ def check_async_errors(device=None, clear: bool = True) -> None:
         _ACCUM.clear()              # a skipped heliostat leaves nothing behind, but take no chances with the invariant
         raise IndexError("target_area_indices out of range (found by the kernels: art_async_status)")
     if rc == -5:
-        raise _lib.ArtistHipError(f"a heliostat has more than {BLOCKING_CANDIDATES} blocking rectangles inside its ray cone "
-                                  "(found by art_blocking_filter: art_async_status); its blocking would be incomplete")
+        raise _lib.ArtistHipError(f"a heliostat has more blocking rectangles inside its ray cone than its candidate row holds "
+                                  f"(artist_amd.ops.BLOCKING_CANDIDATES = {BLOCKING_CANDIDATES}: raise it, or None for no bound; "
+                                  "found by art_blocking_filter: art_async_status); its blocking would be incomplete")
     if rc == -6:
         _ACCUM.clear()              # (a launch that ended abnormally may have left pixel accumulators behind)
     _lib.check(rc, "art_async_status")
@@ -266,7 +271,7 @@ class TraceRays(torch.autograd.Function):
             owner = owner.to(torch.int32).contiguous()
             if owner.shape != (H,):
                 raise ValueError("owner must hold one primitive index per traced heliostat")
-            Cmax = BLOCKING_CANDIDATES
+            Cmax = N if BLOCKING_CANDIDATES is None else max(1, min(N, int(BLOCKING_CANDIDATES)))
             flags = torch.empty((N,), dtype=torch.int32, device=dev)
             cand = torch.empty((H, Cmax), dtype=torch.int32, device=dev)
             cand_count = torch.empty((H,), dtype=torch.int32, device=dev)
@@ -280,6 +285,8 @@ class TraceRays(torch.autograd.Function):
             # (more than Cmax rectangles inside a heliostat's ray cone: the device reports it - ART_ECANDIDATES from
             #  check_async_errors() or from the next trace call - instead of a host read of the counts in every call)
             block_tabs = (prim_corners, prim_spans, prim_normals, cand, cand_count)
+            global _LAST_BLOCKING
+            _LAST_BLOCKING = (cand, cand_count)            # (diagnostics and tests: the last call's candidate lists, still on the device)
             block_ptrs = tuple(t.data_ptr() for t in block_tabs)
 
         flux = torch.empty((n_maps, height, width), dtype=torch.float32, device=dev)
@@ -303,7 +310,8 @@ class TraceRays(torch.autograd.Function):
                              "artist_amd.ops.check_async_errors() clears the status)")
         if rc == -5:
             raise _lib.ArtistHipError(
-                f"a heliostat has more than {BLOCKING_CANDIDATES} blocking rectangles inside its ray cone (found by "
+                f"a heliostat has more blocking rectangles inside its ray cone than its candidate row holds "
+                f"(artist_amd.ops.BLOCKING_CANDIDATES = {BLOCKING_CANDIDATES}: raise it, or set it to None; found by "
                 "art_blocking_filter in an earlier call, whose bitmaps and factors for that heliostat are NaN; "
                 "artist_amd.ops.check_async_errors() clears the status)")
         _lib.check(rc, "art_trace_fwd")

@@ -41,7 +41,7 @@ extern "C" {
 #define ART_ELAUNCH -3     /* HIP launch or runtime error (see art_last_hip_error) */
 #define ART_EUNSUPPORTED -4
 #define ART_EQUEUE -6      /* a work counter of this stream was not zero at the start of a call: an earlier launch on it ended abnormally (art_async_status) */
-#define ART_ECANDIDATES -5 /* a heliostat has more blocking rectangles inside its ray cone than Cmax: found on the DEVICE (art_async_status) */
+#define ART_ECANDIDATES -5 /* workspace exhausted: a heliostat has more blocking rectangles inside its ray cone than its candidate ROW (Cmax entries, the caller's choice up to N) holds: found on the DEVICE (art_async_status) */
 
 /* Library / ABI version (bumped when a signature changes). */
 int art_abi_version(void);
@@ -78,7 +78,10 @@ int art_last_hip_error(void);
  *                     prim_corners == NULL <=> blocking_active=False
  *   cand [H,Cmax], cand_count [H]   per heliostat the rectangles its rays are tested against, as written by
  *                     art_blocking_filter (the filtered set of lbvh_filter_blocking_planes, :832-995); the soft
- *                     mask (soft_ray_blocking_mask, :212-354) is evaluated in the kernel for every ray
+ *                     mask (soft_ray_blocking_mask, :212-354) is evaluated in the kernel for every ray.  Cmax is the
+ *                     ROW WIDTH of `cand` - workspace, any size up to N, not a limit of the kernels: a heliostat's
+ *                     first 32 rectangles live in LDS, the rest of a longer list is read from the list itself (the
+ *                     reference has no such number: every ray meets every filtered rectangle)
  *   max_scatter_angle bound on |distortion angle| in radians (blocking only; < 0 = unknown): lets a surface point
  *                     skip the rectangles that none of its scattered rays can reach - speed only, never results
  *   ray_magnitude     Rays.ray_magnitudes fill value (heliostat_ray_tracer.py:185-203)
@@ -125,7 +128,8 @@ int art_trace_fwd(const float *origins, const float *normals, const float *incid
  * synchronises `stream` and returns ART_ETARGET if a kernel launched through this library met a target index
  * outside [0, T + Tc) since the status was last cleared (the heliostat was skipped - no table is indexed out of
  * bounds - its bitmap and factors are zero, and so are its gradients in art_trace_bwd), ART_ECANDIDATES if
- * art_blocking_filter found more than Cmax rectangles inside a heliostat's ray cone (the surplus is not evaluated:
+ * art_blocking_filter found more rectangles inside a heliostat's ray cone than its candidate row holds (Cmax < N was the
+ * caller's choice: with Cmax = N it cannot happen.  The surplus is not evaluated:
  * that heliostat's blocking is incomplete; cand_count[h] holds the number found, and art_trace_fwd writes NaN
  * into that heliostat's bitmap - its target's bitmap in mode 1 - and factors, so the call that overflowed cannot
  * be mistaken for a result), ART_OK otherwise.  `clear` != 0 resets the status.  Until it is cleared, every later
@@ -167,9 +171,11 @@ int art_trace_bwd(const float *origins, const float *normals, const float *incid
  * point's samples into chunks; with a 16-byte aligned buffer of at least this size the chunks' partial gradients are
  * written to slabs and added in chunk order - bit-reproducible gradients; with NULL (or less) the samples of a point stay
  * in one work item, which is reproducible too but leaves most of the chip idle on a field of a few heliostats.
- * With blocking (Cmax = the capacity passed to art_blocking_filter) the buffer is REQUIRED: every work item leaves its
- * rectangle gradients in a [Cmax,12] slab and a last kernel adds the slabs in item order - the rectangle gradients are
- * bit-reproducible as well (no float atomics anywhere in the trace kernels).
+ * With blocking (Cmax = the row width passed to art_blocking_filter) the buffer is REQUIRED: every work item leaves its
+ * rectangle gradients in a [min(Cmax, 32),12] slab and a last kernel adds the slabs in item order - the rectangle gradients
+ * are bit-reproducible as well (no float atomics).  Rows wider than 32: one fp64 row [Cmax - 31, 12] per heliostat more, for
+ * the listed candidates of a heliostat with more than 32 (fp64 atomics, rounded to fp32 once - the only float atomics of
+ * the library; reproducible to an fp64 rounding).
  * The size covers every receiver configuration art_trace_bwd can meet for these sizes (planar, cylindrical, mixed: the
  * launch geometries differ and the caller allocates before the tables' types matter); art_trace_bwd never rejects a
  * buffer of this size (tests/test_host_logic.py sweeps it). */
@@ -189,10 +195,12 @@ int64_t art_trace_bwd_scratch_need(int64_t H, int64_t R, int64_t P, int64_t face
  *   lbvh_compat != 0   reproduce the reference tree's reachability: its split search (:640-650) leaves most
  *                      leaves of a larger tree unreachable from the root, and an unreachable rectangle is never
  *                      returned; 0 = every rectangle whose box is hit (what the method documents);
- *   Cmax <= 32         capacity of a heliostat's candidate list;
+ *   Cmax               row width of `cand`: 1 ... N.  Lists of up to 32 rectangles cost what they always did; longer ones
+ *                      are filtered in batches of 32 and traced with the rest read from the list (slower, correct);
  *   flags [N]          out: 1 = in the filtered set;
- *   cand [H,Cmax], cand_count [H]   out: filtered rectangles inside heliostat h's ray cone; cand_count[h] > Cmax
- *                      reports an overflow (the list is then truncated: raise Cmax) - and so does the device status
+ *   cand [H,Cmax], cand_count [H]   out: filtered rectangles inside heliostat h's ray cone, in ascending order;
+ *                      cand_count[h] > Cmax reports a row that was too narrow (the list is then truncated: raise Cmax,
+ *                      at most to N) - and so does the device status
  *                      word: ART_ECANDIDATES from art_async_status and from the next art_trace_fwd / art_trace_bwd,
  *                      so a caller need not read the counts back;
  *   workspace          art_blocking_workspace_bytes(H, N) bytes of device memory, 256-byte aligned.

@@ -81,7 +81,7 @@ def test_no_float_atomics_in_any_trace_kernel(tmp_path):
     `global_atomic_add_f32` nor an LDS `ds_add_f32` / `ds_add_f64` (`ds_add_rtn_*` likewise) - in ANY trace kernel, planar
     or cylindrical, blocking on or off: flux goes through 64-bit integer accumulators, gradients through plain stores and
     chunk slabs, and the rectangle gradients of the blocking backward through wave reductions and item slabs (round 2
-    still flushed those with float atomics)."""
+    still flushed those with float atomics) - with one narrow exception since round 4, stated where it is checked below."""
     import shutil
     import subprocess
     llvm = pathlib.Path("/opt/rocm/lib/llvm/bin")
@@ -94,7 +94,13 @@ def test_no_float_atomics_in_any_trace_kernel(tmp_path):
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
     starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
     assert starts, "no offload bundles in the library"
-    per_kernel, seen_trace = {}, False
+    per_kernel, per_kernel_f64_only, seen_trace = {}, {}, False
+
+    def blocking_instantiation(mangled):
+        # trace_bwd_lds_kernel<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING, LEAN>: the fourth template argument
+        dem = subprocess.run(["c++filt", mangled], capture_output=True, text=True).stdout
+        m = re.search(r"trace_bwd_lds_kernel<(\w+), (\w+), (\w+), (\w+), (\w+)>", dem)
+        return bool(m) and m.group(4) == "true"
     for k, start in enumerate(starts):
         part = tmp_path / f"bundle{k}.bin"
         part.write_bytes(blob[start: starts[k + 1] if k + 1 < len(starts) else len(blob)])
@@ -112,6 +118,13 @@ def test_no_float_atomics_in_any_trace_kernel(tmp_path):
                 seen_trace |= "trace_fwd_lds_kernel" in current
             elif current and re.search(r"global_atomic_(add|pk_add)_f(32|64)|ds_(add|pk_add)(_rtn)?_f(32|64)", line):
                 per_kernel[current] = per_kernel.get(current, 0) + 1
+                only_f64 = re.search(r"global_atomic_add_f64", line) is not None
+                per_kernel_f64_only[current] = per_kernel_f64_only.get(current, True) and only_f64
     assert seen_trace, "trace kernels not found in the device code"
     offenders = {k: v for k, v in per_kernel.items() if "trace_" in k or "reduce_prim" in k or "reduce_chunks" in k}
-    assert not offenders, offenders
+    # The one exception (round 4): the blocking BACKWARD kernels add the rectangle gradients of a "wide" heliostat's listed
+    # candidates - the ones beyond the 32 of the LDS tables - to its fp64 row by global fp64 atomics.  No other float atomic
+    # anywhere: not in the forward kernels, not in the kernels without blocking, none on fp32, none in LDS.
+    allowed = {k for k in offenders if "trace_bwd_lds_kernel" in k and per_kernel_f64_only.get(k, False) and blocking_instantiation(k)}
+    assert not (set(offenders) - allowed), {k: offenders[k] for k in set(offenders) - allowed}
+    assert not any("trace_fwd" in k for k in offenders)

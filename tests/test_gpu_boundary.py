@@ -141,11 +141,13 @@ def test_skipped_heliostat_has_zero_gradients(golden):
 
 
 def test_candidate_overflow_poisons_the_overflowed_heliostat(golden, monkeypatch):
-    """More rectangles inside one heliostat's ray cone than the tables hold.  (1) Whatever the host learns and when, the
+    """More rectangles inside one heliostat's ray cone than its candidate ROW holds - the caller's workspace, 32 entries here (the
+    kernels themselves take lists of any length: test_more_candidates_than_the_tables_hold).  (1) Whatever the host learns and when, the
     RESULTS of the call that overflowed say so: NaN bitmap and factors for that heliostat, finite ones for the others -
     shown by clearing the status word between the filter and the trace call, which is the race a caller can lose.
     (2) Unpatched, the overflow is raised by the same call or the next one, with the hint how to clear the status."""
     from artist_amd import ArtistHipError, _lib, ops, trace_rays
+    monkeypatch.setattr(ops, "BLOCKING_CANDIDATES", 32)
     d = golden("small_blocking")
     inp = trace_inputs(d)
     blk = blocking_inputs(d)
@@ -166,6 +168,7 @@ def test_candidate_overflow_poisons_the_overflowed_heliostat(golden, monkeypatch
     monkeypatch.setattr(handle, "art_trace_fwd", trace_after_losing_the_race)
     flux, fac, _ = trace_rays(**inp, blocking=crowded)
     monkeypatch.undo()
+    monkeypatch.setattr(ops, "BLOCKING_CANDIDATES", 32)
     torch.cuda.synchronize()
     over = np.isnan(n(fac)).any(axis=0)                          # [H]
     assert over.any() and not over.all()

@@ -1004,6 +1004,74 @@ def test_blocking_backward(golden, name):
         assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)
 
 
+def crowd(blk, k, n_extra):
+    """The tables ``blk`` (torch or numpy) plus ``n_extra`` small rectangles above rectangle ``k`` (0.3 of its spans, stepped
+    along its first span down to its upper edge, each lifted a millimetre more along its normal): whoever had ``k`` in its ray
+    cone now has n_extra more candidates, their soft edges cross the beam at different heights, and they block rays that ``k``
+    let pass."""
+    is_t = torch.is_tensor(blk["corners"])
+    c0, su, sv, nn = blk["corners"][k][0], blk["spans"][k][0], blk["spans"][k][1], blk["normals"][k]
+    if is_t:
+        j = torch.arange(n_extra, dtype=torch.float32, device=c0.device)[:, None]
+        w = torch.tensor([1.0, 1.0, 1.0, 0.0], device=c0.device)
+        rep = lambda a: a[None].repeat(n_extra, 1)                               # noqa: E731
+        stack, cat = torch.stack, lambda a, b: torch.cat([a, b])                 # noqa: E731
+    else:
+        j = np.arange(n_extra, dtype=np.float32)[:, None]
+        w = np.array([1.0, 1.0, 1.0, 0.0], np.float32)
+        rep = lambda a: np.repeat(a[None], n_extra, 0)                           # noqa: E731
+        stack, cat = np.stack, lambda a, b: np.concatenate([a, b]).astype(np.float32)   # noqa: E731
+    c0s = c0[None] + (1.4 - (0.4 / n_extra) * j) * su[None] + 1e-3 * (j + 1) * nn[None] * w
+    sus, svs = rep(0.3 * su), rep(0.3 * sv)
+    corners = stack([c0s, c0s + sus, c0s + sus + svs, c0s + svs], 1)
+    return dict(blk, corners=cat(blk["corners"], corners), spans=cat(blk["spans"], stack([sus, svs], 1)),
+                normals=cat(blk["normals"], rep(nn)), lbvh_compat=False)
+
+
+@pytest.mark.parametrize("n_extra", [30, 40, 110])
+def test_more_candidates_than_the_tables_hold(golden, n_extra):
+    """A heliostat with more candidate rectangles than the kernels keep in LDS (32; artist/raytracing/blocking.py:212-354 has no
+    such number: every ray meets every filtered rectangle) is traced, not refused: the sigmas of the others are added from the
+    caller's tables (40 more: through the wave's 64-bit mask; 110 more: the ones beyond it for every ray; 30 more: a list of
+    exactly 32, the last case that is NOT wide - bit 31 of the masks is then a rectangle like any other).  Forward and
+    backward - rays and rectangles - against the oracle, which has no limit."""
+    from artist_amd import ops, trace_rays
+    d = golden("small_blocking")
+    H = d["aligned_points"].shape[0]
+    k = int(d["filter_indices"][0])
+    blk = crowd(blocking_inputs(d), k, n_extra)
+    o_blk = crowd(oracle.blocking_tables(d, H), k, n_extra)
+    inp = trace_inputs(d)
+    inp["origins"].requires_grad_(True); inp["normals"].requires_grad_(True)
+    tabs = {key: blk[key].clone().requires_grad_(True) for key in ("corners", "spans", "normals")}
+    flux, fac, flags = trace_rays(**inp, blocking=dict(blk, **tabs))
+    counts = n(ops._LAST_BLOCKING[1])
+    print("candidates per heliostat:", counts, " filtered:", int(n(flags).sum()), "of", flags.shape[0])
+    assert counts.max() == 32 if n_extra == 30 else counts.max() > 32 + (64 if n_extra > 100 else 0)     # the case is what it says
+    o_flux, o_fac = oracle_fwd(d, blocking=o_blk)
+    assert np.isfinite(n(flux)).all() and np.isfinite(n(fac)).all()
+    err = rel_l2(n(flux), o_flux)
+    print(f"flux {err:.2e}; unblocked fractions {n(fac[2])} (oracle {o_fac[2]})")
+    assert err < 2e-4, err
+    rays = d["blocked"][0].size
+    np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=1.5 / rays)
+    narrow, _, _ = trace_rays(**trace_inputs(d), blocking=blocking_inputs(d))
+    assert rel_l2(n(flux), n(narrow)) > 1e-3                                  # the extra rectangles do block
+    (flux * t(d["loss_weights"])).sum().backward()
+    go, gn, gpc, gps, gpn = oracle.trace_bwd(
+        d["aligned_points"], d["aligned_normals"], d["incident"], d["distortions_u"], d["distortions_e"],
+        d["target_idx"], d["target_centers"], d["target_normals"], d["target_dims"], d["resolution"], d["loss_weights"],
+        float(d["ray_magnitude"]), float(d["extinction"]), float(d["reflectivity"]), blocking=o_blk)
+    for got, orc, key in ((inp["origins"].grad, go, "origins"), (inp["normals"].grad, gn, "normals"), (tabs["corners"].grad, gpc, "corners"),
+                          (tabs["spans"].grad, gps, "spans"), (tabs["normals"].grad, gpn, "rectangle normals")):
+        e = rel_l2(n(got), orc)
+        print(f"  gradient w.r.t. {key}: {e:.2e}")
+        assert e < 2e-3, (key, e)
+    # rectangles beyond the tables (the lists are in ascending order: these sit behind at least 32 others) do receive gradients
+    far = H + (96 if n_extra > 100 else (32 if n_extra > 30 else 24))
+    assert np.abs(gpc[far:]).sum() > 0 and np.abs(n(tabs["corners"].grad)[far:]).sum() > 0
+
+
 def test_blocking_filter_matches_reference_tree(golden):
     """art_blocking_filter on the field-like layouts of known_answers.npz: with ``lbvh_compat`` only rectangles that
     the reference's tree can reach are ever flagged (26 of 391, 3 of 2000), without it every hit rectangle is."""
@@ -1240,11 +1308,13 @@ def test_trace_rays_does_not_wait_for_the_device(blocking):
         assert rt.filtered_blocking_primitive_indices is not None       # (made on demand: this read does synchronise)
 
 
-def test_too_many_candidate_rectangles_are_reported_by_the_device(golden):
-    """More rectangles inside one heliostat's ray cone than the kernels' tables hold (32): the filter says so through the
-    device status word - no host read of the candidate counts in every call - ``check_async_errors`` raises, later trace
+def test_too_many_candidate_rectangles_are_reported_by_the_device(golden, monkeypatch):
+    """More rectangles inside one heliostat's ray cone than its candidate ROW holds (the caller's workspace; 32 entries here -
+    the kernels themselves take lists of any length, test_more_candidates_than_the_tables_hold): the filter says so through
+    the device status word - no host read of the candidate counts in every call - ``check_async_errors`` raises, later trace
     calls refuse to start until the status is cleared, and the library works as before afterwards."""
     from artist_amd import ArtistHipError, _lib, ops, trace_rays
+    monkeypatch.setattr(ops, "BLOCKING_CANDIDATES", 32)
     d = golden("small_blocking")
     inp = trace_inputs(d)
     blk = blocking_inputs(d)

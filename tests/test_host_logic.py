@@ -364,14 +364,14 @@ def test_trace_bwd_never_rejects_a_buffer_of_the_reported_scratch_size():
     lib = _lib.lib()
     worst = 0
     for R, P, facet in ((100, 10000, 2500), (180, 3600, 900), (1, 10000, 2500), (4, 400, 100), (100, 10000, 0), (7, 1024, 256)):
-        for Cmax in (0, 1, 8, 16, 32):
+        for Cmax in (0, 1, 8, 16, 32, 33, 256):        # (beyond 32: rows wider than the kernels' tables - fp64 rows for the rest)
             for H in list(range(1, 600, 7)) + [1000, 4096]:
                 reported = lib.art_trace_bwd_scratch_floats(H, R, P, facet, Cmax)
                 for T, Tc in ((1, 0), (0, 1), (2, 1)):
                     need = lib.art_trace_bwd_scratch_need(H, R, P, facet, T, Tc, Cmax)
                     assert need <= reported, (H, R, P, facet, Cmax, T, Tc, need, reported)
                     worst = max(worst, need)
-                assert Cmax == 0 or reported >= H * Cmax * 12
+                assert Cmax == 0 or reported >= H * min(Cmax, 32) * 12 + (H * (Cmax - 31) * 24 if Cmax > 32 else 0)
     assert worst > 0
     assert lib.art_trace_bwd_scratch_floats(100, 100, 10000, 2500, 8) > 67200      # the advisor's case
 
@@ -399,7 +399,7 @@ def test_trace_bwd_accepts_the_reported_scratch_size_on_the_host():
 
     ART_EINVAL = -1
     for R, P, facet in ((100, 10000, 2500), (180, 3600, 900)):
-        for Cmax in (0, 8, 16):
+        for Cmax in (0, 8, 16, 100):
             for H in (1, 3, 60, 100, 101, 313, 599):
                 reported = lib.art_trace_bwd_scratch_floats(H, R, P, facet, Cmax)
                 for T, Tc in ((1, 0), (0, 1), (1, 1)):
@@ -407,5 +407,5 @@ def test_trace_bwd_accepts_the_reported_scratch_size_on_the_host():
                     assert rc != ART_EINVAL and rc != 0, (H, R, P, facet, Cmax, T, Tc, rc)
                     if Cmax:
                         need = lib.art_trace_bwd_scratch_need(H, R, P, facet, T, Tc, Cmax)
-                        whole = H * Cmax * 12          # the least any geometry needs
+                        whole = H * min(Cmax, 32) * 12 + (H * (Cmax - 31) * 24 if Cmax > 32 else 0)     # the least any geometry needs
                         assert call(H, R, P, facet, T, Tc, Cmax, min(need, whole) - 1) == ART_EINVAL

@@ -9,6 +9,10 @@ from artist_amd import HeliostatRayTracer
 from artist_amd.scene import build_synthetic_scenario
 
 dev = torch.device("cuda:0")
+import os
+if os.environ.get("ART_BLOCKING_CANDIDATES"):          # A/B runs: the candidate rows' width (artist_amd.ops.BLOCKING_CANDIDATES)
+    from artist_amd import ops
+    ops.BLOCKING_CANDIDATES = int(os.environ["ART_BLOCKING_CANDIDATES"])
 
 
 def timed(fn, steps):
