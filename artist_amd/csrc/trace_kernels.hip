@@ -525,17 +525,12 @@ template <typename ONE> __device__ __forceinline__ void wide_for_each(const Wide
         one(c);
     }
 }
-template <bool GRAD>
-__device__ __forceinline__ WideSum wide_ray(const TraceArgs& a, int h, PrimTable<true, GRAD>& tab, unsigned& wm, float ox, float oy,
-                                            float oz, float rx, float ry, float rz)
+// (out of line, plain arguments: one copy per kernel instead of one per inlined ray body - the lean backward item has nine, and
+//  with the listed candidates' code inlined its kernel grew from 57 to 76 KB, past the instruction cache: +4.6 % on a field
+//  without a single wide heliostat)
+__device__ __attribute__((noinline)) WideSum wide_sum_listed(const WideTabs w, unsigned long long bits, float ox, float oy, float oz,
+                                                             float rx, float ry, float rz)
 {
-    WideSum out = {0.0f, 0};
-    const int n_list = __builtin_amdgcn_readfirstlane(tab.n_wide);
-    if (n_list == 0) return out;
-    wm &= 0x7FFFFFFFu;
-    const WideTabs w = wide_tabs(a, h, n_list);
-    unsigned long long bits = tab.xmask[threadIdx.x >> 6];
-    bits = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
     float sum = 0.0f;
     bool near = false;
     wide_for_each(w, bits, [&](int c) {
@@ -550,8 +545,20 @@ __device__ __forceinline__ WideSum wide_ray(const TraceArgs& a, int h, PrimTable
         sum += s.near ? sg : 0.0f;
         near |= s.near && g.sigma_raw != 1.0f;
     });
-    out.sum = sum; out.near = near ? 1 : 0;
+    WideSum out = {sum, near ? 1 : 0};
     return out;
+}
+template <bool GRAD>
+__device__ __forceinline__ WideSum wide_ray(const TraceArgs& a, int h, PrimTable<true, GRAD>& tab, unsigned& wm, float ox, float oy,
+                                            float oz, float rx, float ry, float rz)
+{
+    WideSum out = {0.0f, 0};
+    const int n_list = __builtin_amdgcn_readfirstlane(tab.n_wide);
+    if (n_list == 0) return out;
+    wm &= 0x7FFFFFFFu;
+    unsigned long long bits = tab.xmask[threadIdx.x >> 6];
+    bits = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
+    return wide_sum_listed(wide_tabs(a, h, n_list), bits, ox, oy, oz, rx, ry, rz);
 }
 template <bool GRAD> __device__ __forceinline__ WideSum wide_ray(const TraceArgs&, int, PrimTable<false, GRAD>&, unsigned&, float, float, float, float, float, float) { WideSum z = {0.0f, 0}; return z; }
 
@@ -1890,19 +1897,10 @@ __device__ __attribute__((noinline)) AdjointOut block_adjoint(LdsPrims prims, Pr
 // sums per rectangle with a lane in its soft edge - goes to the heliostat's row of `wide_grad` by fp64 atomics (the items of a
 // heliostat share the row; the sums are rounded to fp32 once, by reduce_prim_grads_kernel: their order can move the result by
 // an fp64 rounding, not by an fp32 one except in a tie).
-template <bool GRAD>
-__device__ __forceinline__ RayGrad wide_ray_adjoint(const TraceArgs& a, int h, PrimTable<true, GRAD>& tab, unsigned& wm, unsigned& nr,
-                                                    float ox, float oy, float oz, float rx, float ry, float rz, float g_sigma)
+__device__ __attribute__((noinline)) RayGrad wide_adjoint_listed(const WideTabs w, unsigned long long bits, float ox, float oy, float oz,
+                                                                 float rx, float ry, float rz, float g_sigma, bool adj)
 {
     RayGrad out = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int n_list = __builtin_amdgcn_readfirstlane(tab.n_wide);
-    if (n_list == 0) return out;
-    const bool adj = (nr >> 31) != 0u;
-    wm &= 0x7FFFFFFFu; nr &= 0x7FFFFFFFu;
-    if (!wave_any(adj)) return out;
-    const WideTabs w = wide_tabs(a, h, n_list);
-    unsigned long long bits = tab.xmask[threadIdx.x >> 6];
-    bits = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
     const int lane = threadIdx.x & 63;
     wide_for_each(w, bits, [&](int c) {
         const Prim q = wide_prim(w, c);
@@ -1931,6 +1929,20 @@ __device__ __forceinline__ RayGrad wide_ray_adjoint(const TraceArgs& a, int h, P
         }
     });
     return out;
+}
+template <bool GRAD>
+__device__ __forceinline__ RayGrad wide_ray_adjoint(const TraceArgs& a, int h, PrimTable<true, GRAD>& tab, unsigned& wm, unsigned& nr,
+                                                    float ox, float oy, float oz, float rx, float ry, float rz, float g_sigma)
+{
+    RayGrad out = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n_list = __builtin_amdgcn_readfirstlane(tab.n_wide);
+    if (n_list == 0) return out;
+    const bool adj = (nr >> 31) != 0u;
+    wm &= 0x7FFFFFFFu; nr &= 0x7FFFFFFFu;
+    if (!wave_any(adj)) return out;
+    unsigned long long bits = tab.xmask[threadIdx.x >> 6];
+    bits = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(bits >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
+    return wide_adjoint_listed(wide_tabs(a, h, n_list), bits, ox, oy, oz, rx, ry, rz, g_sigma, adj);
 }
 template <bool GRAD> __device__ __forceinline__ RayGrad wide_ray_adjoint(const TraceArgs&, int, PrimTable<false, GRAD>&, unsigned&, unsigned&, float, float, float, float, float, float, float) { RayGrad z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return z; }
 
