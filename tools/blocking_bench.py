@@ -26,16 +26,20 @@ def timed(fn, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def main(H=1000, R=100, steps=5):
-    scenario, _ = build_synthetic_scenario(H, n_rays=R, device=dev)
+def main(H=1000, R=100, steps=5, dense=False):
+    # --dense: the same field with rows 2.6 m apart behind a tower target 12 m up and the sun 6 degrees above the horizon - the
+    # beams of the back rows pass through dozens of mirrors: candidate lists beyond the kernels' 32 tabled rectangles
+    scenario, _ = build_synthetic_scenario(H, n_rays=R, device=dev, **(dict(target_centers=((0.0, 0.0, 12.0, 1.0),)) if dense else {}))
     g = scenario.heliostat_field.heliostat_groups[0]
     i = torch.arange(H, device=dev)
-    g.positions = torch.stack([((i % 40) - 19.5) * 4.2, 60.0 + (i // 40) * 5.0, torch.zeros(H, device=dev),
+    pitch_x, pitch_y, y0 = (3.4, 2.6, 30.0) if dense else (4.2, 5.0, 60.0)
+    g.positions = torch.stack([((i % 40) - 19.5) * pitch_x, y0 + (i // 40) * pitch_y, torch.zeros(H, device=dev),
                                torch.ones(H, device=dev)], dim=1)
     mask = torch.ones(H, dtype=torch.int32, device=dev)
     g.activate_heliostats(mask)
     tix = torch.zeros(H, dtype=torch.long, device=dev)
-    inc = torch.nn.functional.normalize(torch.tensor([[0.0, 0.94, -0.34, 0.0]], device=dev), dim=1).repeat(H, 1)
+    sun = [0.0, 0.9945, -0.1045, 0.0] if dense else [0.0, 0.94, -0.34, 0.0]
+    inc = torch.nn.functional.normalize(torch.tensor([sun], device=dev), dim=1).repeat(H, 1)
     g.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask)
     pts = g.active_surface_points.detach().requires_grad_(True)
     g.active_surface_points = pts
@@ -57,8 +61,13 @@ def main(H=1000, R=100, steps=5):
         out[label] = {"fwd_ms": timed(fwd, steps), "fwd_bwd_ms": timed(fwd_bwd, steps),
                       "mean_unblocked_fraction": float(unblocked.mean()), "flux_sum": float(flux.sum()),
                       "filtered": 0 if not rt.blocking_active else int(rt.filtered_blocking_primitive_indices.numel())}
+        if rt.blocking_active:
+            from artist_amd import ops
+            counts = ops._LAST_BLOCKING[1]
+            out[label].update(candidates_max=int(counts.max()), heliostats_beyond_32=int((counts > 32).sum()),
+                              heliostats_with_candidates=int((counts > 0).sum()))
     print(json.dumps(out))
 
 
 if __name__ == "__main__":
-    main()
+    main(dense="--dense" in sys.argv)
