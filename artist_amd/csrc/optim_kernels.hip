@@ -27,44 +27,55 @@ struct AdamArgs {
     int nu, nv;          // > 0: lock the outer edge of every [nu,nv,3] net
 };
 
+// one element of the update (torch/optim/adam.py, _single_tensor_adam)
+__device__ __forceinline__ void adam_element(const AdamArgs& a, float& p, float g, float& m, float& v, bool locked)
+{
+    float gr = locked ? 0.0f : a.grad_sign * g;
+    if (a.weight_decay != 0.0f) gr = gr + a.weight_decay * p;
+    m = m + (gr - m) * a.one_minus_beta1;                       // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + (a.one_minus_beta2 * gr) * gr;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;      // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+    p = p - a.step_size * (m / denom);                          // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+// is element i a u or v component of an edge control point of its [nu,nv,3] net?  (surface_reconstructor.py:1212-1222: the edge
+// control points keep their u and v - components 0, 1 -; z stays free)
+__device__ __forceinline__ bool adam_locked(const AdamArgs& a, unsigned i)
+{
+    if (a.nu <= 0) return false;
+    const unsigned cell = i / 3u, comp = i - 3u * cell;
+    const unsigned line = cell / (unsigned)a.nv, col = cell - line * (unsigned)a.nv, row = line % (unsigned)a.nu;
+    return comp < 2u && (row == 0u || row == (unsigned)a.nu - 1u || col == 0u || col == (unsigned)a.nv - 1u);
+}
+
+// One thread per four elements, everything in registers: 16-byte loads and stores where the four tensors are 16-byte aligned
+// and the group is whole, element by element otherwise (the last thread of an odd size; unaligned views).
+// (Round 4's first version kept the four elements in arrays that the element-wise path indexed in a loop: the compiler moved
+//  them to LDS - 16 KB per workgroup - and the kernel took 21 us at any size.)
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamArgs a)
 {
     const int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i0 >= a.n) return;
     const bool vec = i0 + 4 <= a.n && (((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.exp_avg | (uintptr_t)a.exp_avg_sq) & 15) == 0;
-    float p[4], g[4], m[4], v[4];
-    const int cnt = (int)(a.n - i0 < 4 ? a.n - i0 : 4);
     if (vec) {
-        *reinterpret_cast<float4*>(p) = *reinterpret_cast<const float4*>(a.param + i0);
-        *reinterpret_cast<float4*>(g) = *reinterpret_cast<const float4*>(a.grad + i0);
-        *reinterpret_cast<float4*>(m) = *reinterpret_cast<const float4*>(a.exp_avg + i0);
-        *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(a.exp_avg_sq + i0);
-    } else {
-        for (int k = 0; k < cnt; ++k) { p[k] = a.param[i0 + k]; g[k] = a.grad[i0 + k]; m[k] = a.exp_avg[i0 + k]; v[k] = a.exp_avg_sq[i0 + k]; }
+        float4 p = *reinterpret_cast<const float4*>(a.param + i0);
+        const float4 g = *reinterpret_cast<const float4*>(a.grad + i0);
+        float4 m = *reinterpret_cast<const float4*>(a.exp_avg + i0);
+        float4 v = *reinterpret_cast<const float4*>(a.exp_avg_sq + i0);
+        const unsigned i = (unsigned)i0;              // (a lock implies n < 2^31: checked by the caller)
+        adam_element(a, p.x, g.x, m.x, v.x, adam_locked(a, i));
+        adam_element(a, p.y, g.y, m.y, v.y, adam_locked(a, i + 1u));
+        adam_element(a, p.z, g.z, m.z, v.z, adam_locked(a, i + 2u));
+        adam_element(a, p.w, g.w, m.w, v.w, adam_locked(a, i + 3u));
+        *reinterpret_cast<float4*>(a.param + i0) = p;
+        *reinterpret_cast<float4*>(a.exp_avg + i0) = m;
+        *reinterpret_cast<float4*>(a.exp_avg_sq + i0) = v;
+        return;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k >= cnt) break;
-        float gr = a.grad_sign * g[k];
-        if (a.nu > 0) {
-            const int64_t cell = (i0 + k) / 3;
-            const int comp = (int)((i0 + k) - 3 * cell);
-            const int c = (int)(cell % a.nv), r = (int)((cell / a.nv) % a.nu);
-            // surface_reconstructor.py:1212-1222: the edge control points keep their u and v (components 0, 1); z stays free
-            if (comp < 2 && (r == 0 || r == a.nu - 1 || c == 0 || c == a.nv - 1)) gr = 0.0f;
-        }
-        if (a.weight_decay != 0.0f) gr = gr + a.weight_decay * p[k];
-        m[k] = m[k] + (gr - m[k]) * a.one_minus_beta1;                    // exp_avg.lerp_(grad, 1 - beta1)
-        v[k] = v[k] * a.beta2 + (a.one_minus_beta2 * gr) * gr;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-        const float denom = sqrtf(v[k]) * a.inv_bc2_sqrt + a.eps;         // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
-        p[k] = p[k] - a.step_size * (m[k] / denom);                       // param.addcdiv_(exp_avg, denom, value=-step_size)
-    }
-    if (vec) {
-        *reinterpret_cast<float4*>(a.param + i0) = *reinterpret_cast<const float4*>(p);
-        *reinterpret_cast<float4*>(a.exp_avg + i0) = *reinterpret_cast<const float4*>(m);
-        *reinterpret_cast<float4*>(a.exp_avg_sq + i0) = *reinterpret_cast<const float4*>(v);
-    } else {
-        for (int k = 0; k < cnt; ++k) { a.param[i0 + k] = p[k]; a.exp_avg[i0 + k] = m[k]; a.exp_avg_sq[i0 + k] = v[k]; }
+    for (int64_t i = i0; i < a.n && i < i0 + 4; ++i) {
+        float p = a.param[i], m = a.exp_avg[i], v = a.exp_avg_sq[i];
+        adam_element(a, p, a.grad[i], m, v, adam_locked(a, (unsigned)i));
+        a.param[i] = p; a.exp_avg[i] = m; a.exp_avg_sq[i] = v;
     }
 }
 
@@ -80,7 +91,7 @@ extern "C" int art_adam_step(float* param, const float* grad, float* exp_avg, fl
     if (n == 0) return ART_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) ||
         !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || lock_nu < 0 || lock_nv < 0 || (lock_nu > 0) != (lock_nv > 0) ||
-        lock_nu > 4096 || lock_nv > 4096 || (lock_nu > 0 && n % (lock_nu * lock_nv * 3) != 0))
+        lock_nu > 4096 || lock_nv > 4096 || (lock_nu > 0 && (n % (lock_nu * lock_nv * 3) != 0 || n > 2147483647LL)))
         return ART_EINVAL;
     AdamArgs a;
     a.param = param; a.grad = grad; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.n = n;
