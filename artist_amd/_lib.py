@@ -15,7 +15,7 @@ _PKG = pathlib.Path(__file__).resolve().parent
 LIB_PATH = pathlib.Path(os.environ.get("ARTIST_HIP_LIB", _PKG / "libartist_hip.so"))   # override: diagnostic builds only
 CSRC = _PKG / "csrc"
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ArtistHipError(RuntimeError):
@@ -47,7 +47,7 @@ SIGNATURES = {
     "art_flux_crop_bwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr],
     "art_flux_loss": [_ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr, _ptr, _ptr, _ptr],
     "art_flux_crop_pixel_loss_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr],
-    "art_flux_crop_pixel_loss_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr],
+    "art_flux_crop_pixel_loss_bwd": [_ptr, _ptr, _ptr, _c_i64, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr],
     "art_flux_crop_kl_loss_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],
     "art_flux_crop_kl_loss_bwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_i64, _c_dbl, _c_dbl, _ptr, _ptr, _ptr],
     "art_flux_center_of_mass": [_ptr, _c_i64, _c_i64, _c_i64, _ptr, _ptr],

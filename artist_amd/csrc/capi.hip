@@ -5,7 +5,7 @@ namespace art {
 thread_local int g_last_hip_error = 0;
 }
 
-extern "C" int art_abi_version(void) { return 12; }
+extern "C" int art_abi_version(void) { return 13; }
 
 extern "C" int art_last_hip_error(void) { return art::g_last_hip_error; }
 

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
                                                                   const float* __restrict__ gcom,
                                                                   const float* __restrict__ grad_out, int Hh, int W,
                                                                   float crop_w, float crop_h, float* __restrict__ grad_flux,
-                                                                  const float* __restrict__ grad_loss)
+                                                                  const float* __restrict__ grad_loss, int grad_loss_stride = 1)
 {
     constexpr int CS = LOSS ? 4 : 3;                 // stride of the centre record
     __shared__ int s_j0[kTileX], s_i0[kTileY];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     m.sx = crop_w / fmaxf(dims[2 * b], 1e-8f); m.sy = crop_h / fmaxf(dims[2 * b + 1], 1e-8f);
     m.xc = com[CS * b]; m.yc = com[CS * b + 1]; m.W = W; m.Hh = Hh;
     const float S = com[CS * b + 2];
-    const float scale = LOSS ? (grad_loss[b] * 2.0f) / com[CS * b + 3] : 1.0f;
+    const float scale = LOSS ? (grad_loss[(int64_t)b * grad_loss_stride] * 2.0f) / com[CS * b + 3] : 1.0f;     // (stride 0: the gradient of a summed loss)
     if (threadIdx.x == 0) { s_wide = 0; s_ilo = 0x7fffffff; s_ihi = -1; }
     __syncthreads();
     if (threadIdx.x < kTileX + kTileY) {
@@ -967,16 +967,18 @@ extern "C" int art_flux_crop_pixel_loss_fwd(const float* flux, const float* targ
 }
 
 extern "C" int art_flux_crop_pixel_loss_bwd(const float* target_dims, const float* centers4, const float* grad_loss,
-                                            const float* residual, const float* center_grad_unit, int64_t B, int64_t Hh, int64_t W,
-                                            double crop_width, double crop_height, float* grad_flux, void* stream_)
+                                            int64_t grad_loss_stride, const float* residual, const float* center_grad_unit, int64_t B,
+                                            int64_t Hh, int64_t W, double crop_width, double crop_height, float* grad_flux, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!crop_args_ok(residual, target_dims, center_grad_unit, centers4, B, Hh, W) || !grad_loss || !grad_flux) return ART_EINVAL;
+    if (!crop_args_ok(residual, target_dims, center_grad_unit, centers4, B, Hh, W) || !grad_loss || !grad_flux ||
+        (grad_loss_stride != 0 && grad_loss_stride != 1))
+        return ART_EINVAL;
     if (B == 0) return ART_OK;
     hipLaunchKernelGGL(flux_crop_bwd_tiled_kernel<true>,
                        dim3((unsigned)((W + kTileX - 1) / kTileX), (unsigned)((Hh + kTileY - 1) / kTileY), (unsigned)B),
                        dim3(256), 0, stream, target_dims, centers4, center_grad_unit, residual, (int)Hh, (int)W, (float)crop_width,
-                       (float)crop_height, grad_flux, grad_loss);
+                       (float)crop_height, grad_flux, grad_loss, (int)grad_loss_stride);
     ART_HIP(hipGetLastError());
     return ART_OK;
 }

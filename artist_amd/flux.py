@@ -155,11 +155,17 @@ class FluxCropPixelLoss(torch.autograd.Function):
         dims, centers, residual, unit = ctx.saved_tensors
         dev = residual.device
         B, Hh, W = residual.shape
-        grad_loss = _f32c(grad_loss)
+        # the gradient of `loss.sum()` arrives as an expanded scalar (stride 0): the kernel reads the one value - no copy to [B]
+        stride = 1
+        if grad_loss.dtype == torch.float32 and grad_loss.dim() == 1 and grad_loss.stride(0) == 0 and grad_loss.is_cuda:
+            stride = 0
+        else:
+            grad_loss = _f32c(grad_loss)
         grad_flux = torch.empty_like(residual)
         with torch.cuda.device(dev):
-            rc = _lib.lib().art_flux_crop_pixel_loss_bwd(dims.data_ptr(), centers.data_ptr(), grad_loss.data_ptr(), residual.data_ptr(),
-                                                         unit.data_ptr(), B, Hh, W, *ctx.crop, grad_flux.data_ptr(), _stream(dev))
+            rc = _lib.lib().art_flux_crop_pixel_loss_bwd(dims.data_ptr(), centers.data_ptr(), grad_loss.data_ptr(), stride,
+                                                         residual.data_ptr(), unit.data_ptr(), B, Hh, W, *ctx.crop, grad_flux.data_ptr(),
+                                                         _stream(dev))
         _lib.check(rc, "art_flux_crop_pixel_loss_bwd")
         return grad_flux, None, None, None, None
 

@@ -347,8 +347,10 @@ int art_flux_crop_pixel_loss_fwd(const float *flux, const float *target_dims, co
                                  float *centers4, float *residual, float *center_grad_unit, const double *moments,
                                  void *stream);
 int art_flux_crop_pixel_loss_bwd(const float *target_dims, const float *centers4, const float *grad_loss,
-                                 const float *residual, const float *center_grad_unit, int64_t B, int64_t Hh, int64_t W,
-                                 double crop_width, double crop_height, float *grad_flux, void *stream);
+                                 int64_t grad_loss_stride, const float *residual, const float *center_grad_unit, int64_t B,
+                                 int64_t Hh, int64_t W, double crop_width, double crop_height, float *grad_flux, void *stream);
+/* (grad_loss_stride: 1 = grad_loss [B]; 0 = one value for every bitmap - the gradient of `loss.sum()` as autograd hands it
+ *  over, an expanded scalar: no copy to [B] first) */
 
 /* ---------------------------------------------------------------------------------------------
  * art_flux_crop_kl_loss_fwd / _bwd - crop_flux_distributions_around_center (artist/flux/bitmap.py:121-246) followed by

@@ -39,6 +39,34 @@ def test_two_streams_trace_concurrently(golden):
             np.testing.assert_array_equal(n(gn), n(ref_gn))
 
 
+def test_gradient_of_a_summed_loss_needs_no_copy():
+    """``FluxCropPixelLoss(...).sum().backward()``: autograd hands the op an expanded scalar (stride 0), which the kernel reads
+    as it is (``grad_loss_stride = 0`` of art_flux_crop_pixel_loss_bwd) - the same gradient, bit for bit, as with a materialised
+    ``[B]`` vector of that value, also when the value is not 1."""
+    from artist_amd.flux import FluxCropPixelLoss
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    B, Hh, W = 12, 64, 64
+    ys, xs = torch.meshgrid(torch.arange(Hh, device=DEV, dtype=torch.float32), torch.arange(W, device=DEV, dtype=torch.float32), indexing="ij")
+    cx, cy = 24 + 16 * torch.rand(B, generator=gen, device=DEV), 24 + 16 * torch.rand(B, generator=gen, device=DEV)
+    flux = torch.exp(-((xs[None] - cx[:, None, None]) ** 2 + (ys[None] - cy[:, None, None]) ** 2) / (2 * 5.0 ** 2)).contiguous()
+    truth = torch.rand((B, Hh, W), generator=gen, device=DEV) + 0.1
+    dims = torch.full((B, 2), 8.0, device=DEV)
+    grads = []
+    for weight in (None, 0.37):
+        for materialised in (False, True):
+            f = flux.clone().requires_grad_(True)
+            loss = FluxCropPixelLoss.apply(f, dims, truth, 6.0, 6.0)
+            if materialised:
+                g, = torch.autograd.grad(loss, f, torch.full_like(loss, 1.0 if weight is None else weight))
+            else:
+                (loss.sum() if weight is None else loss.sum() * weight).backward()
+                g = f.grad
+            grads.append(n(g))
+    np.testing.assert_array_equal(grads[0], grads[1])
+    np.testing.assert_array_equal(grads[2], grads[3])
+    assert np.abs(grads[0]).max() > 0 and not np.array_equal(grads[0], grads[2])
+
+
 def test_two_streams_share_no_part_sums():
     """Small batches of the fused crop + pixel-loss pair give a bitmap several workgroups and pass their part sums through
     library-owned scratch - one per (GPU, stream).  Two streams with DIFFERENT bitmaps, submitted interleaved: every loss and
