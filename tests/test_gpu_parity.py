@@ -738,7 +738,12 @@ def test_trace_forward_cylinders(golden, name, interleaved):
     flux, fac = trace_rays(**trace_inputs(d, interleaved), cyl=cyl_inputs(d))
     o_flux, o_fac = oracle_fwd(d, cyl=oracle.cyl_tables(d))
     yard = rel_l2(d["flux"], d64["flux"])                 # what fp32 does to the reference itself
-    assert rel_l2(n(flux), o_flux) < max(yard, 2e-3), (rel_l2(n(flux), o_flux), yard)
+    # Two legs (round-3 review: a 1e-3 defect would have passed the yardstick alone).  (1) HIP against the fp32 restatement, which
+    # does the same operations in the same order: tight - measured 1.5e-6 / 7.1e-6 (tools/parity_margins.py) - and the
+    # restatement in fp64 is pinned on the reference's fp64 fixtures in the CPU suite (tests/test_oracle_golden.py).  (2) HIP
+    # against the reference's fp32 fixture, where torch's other operation order is amplified ~400 times by the cancellation
+    # in b^2 - 4ac: within the reference's own fp32-vs-fp64 distance.
+    assert rel_l2(n(flux), o_flux) < 3e-5, rel_l2(n(flux), o_flux)
     assert rel_l2(n(flux), d["flux"]) < max(yard, 2e-3), (rel_l2(n(flux), d["flux"]), yard)
     assert rel_l2(n(flux), d64["flux"]) < 2 * max(yard, 2e-3)
     # planar heliostats of the mixed case are untouched by the cylinder launch: same bar as test_trace_forward
@@ -766,7 +771,7 @@ def test_trace_backward_cylinders(golden, name):
                               float(d["extinction"]), float(d["reflectivity"]), cyl=oracle.cyl_tables(d))
     for got, orc, key in ((inp["origins"].grad, go, "grad_aligned_points"), (inp["normals"].grad, gn, "grad_aligned_normals")):
         yard = rel_l2(d[key], d64[key])
-        assert rel_l2(n(got), orc) < max(yard, 1e-3), (key, rel_l2(n(got), orc), yard)
+        assert rel_l2(n(got), orc) < 3e-5, (key, rel_l2(n(got), orc))              # (measured <= 3.9e-6: the same two legs as in the forward test)
         assert rel_l2(n(got), d[key]) < max(2 * yard, 1e-3), (key, rel_l2(n(got), d[key]), yard)
         assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)
 
@@ -956,7 +961,7 @@ def test_blocking_forward(golden, name, interleaved):
     np.testing.assert_array_equal(np.nonzero(n(flags))[0], d["filter_indices"])          # the reference's filtered set
     o_flux, o_fac = oracle_fwd(d, blocking=oracle.blocking_tables(d, H))
     yard = rel_l2(d["flux"], d64["flux"])               # sigmoid(1000 x) amplifies fp32 rounding in the edge band
-    assert rel_l2(n(flux), o_flux) < max(yard, 2e-4), (rel_l2(n(flux), o_flux), yard)
+    assert rel_l2(n(flux), o_flux) < 2e-6, rel_l2(n(flux), o_flux)      # HIP against the fp32 restatement: tight (measured 2.5e-7)
     assert rel_l2(n(flux), d["flux"]) < max(yard, 2e-4), (rel_l2(n(flux), d["flux"]), yard)
     rays = d["blocked"][0].size
     np.testing.assert_allclose(n(fac), o_fac, rtol=0, atol=1.5 / rays)                    # <= 1 ray per counter
@@ -999,7 +1004,7 @@ def test_blocking_backward(golden, name):
                           (spans.grad, None, "grad_prim_spans")):
         yard = rel_l2(d[key], d64[key])                 # the reference's own fp32-vs-fp64 distance
         if orc is not None:
-            assert rel_l2(n(got), orc) < max(yard, 1e-3), (key, rel_l2(n(got), orc), yard)
+            assert rel_l2(n(got), orc) < 2e-5, (key, rel_l2(n(got), orc))             # HIP against the fp32 restatement: tight
         assert rel_l2(n(got), d[key]) < max(2 * yard, 1e-3), (key, rel_l2(n(got), d[key]), yard)
         assert rel_l2(n(got), d64[key]) < max(3 * yard, 1e-3), (key, rel_l2(n(got), d64[key]), yard)
 
