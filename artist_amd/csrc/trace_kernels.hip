@@ -2877,7 +2877,7 @@ __global__ __launch_bounds__(kMomentsBlock) void accum_to_flux_moments_kernel(un
 }
 
 // out[t] = sum_h [target_idx[h] == t] bitmaps[h]   (heliostat_ray_tracer.py:593-608)
-// One thread per (t, VEC pixels); heliostats are added in index order (deterministic) with 8-16 loads in flight.
+// One thread per (t, VEC pixels); heliostats are added in index order (deterministic) with 8-64 loads in flight.
 // A 256 x 256 bitmap has too few pixels to fill the chip with 4-pixel threads: VEC = 4 only for large bitmaps.
 template <int VEC>
 __global__ __launch_bounds__(256) void per_target_sum_kernel(const float* __restrict__ bitmaps,
@@ -2890,7 +2890,7 @@ __global__ __launch_bounds__(256) void per_target_sum_kernel(const float* __rest
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
-    constexpr int kInFlight = VEC == 1 ? 16 : 8;
+    constexpr int kInFlight = VEC == 1 ? 64 : 8;      // (a thread of a 256 x 256 bitmap has 64 loads in flight: 80 -> 69 us per 1000 bitmaps against 16)
     for (int h0 = 0; h0 < H; h0 += kInFlight) {
         float val[kInFlight][VEC];
 #pragma unroll

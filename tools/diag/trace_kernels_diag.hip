@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include "../../artist_amd/csrc/flux_moments.hpp"
 
 #include "trace_common.hpp"
 
@@ -2894,6 +2895,13 @@ __global__ __launch_bounds__(256) void reduce_prim_grads_kernel(const float* __r
 
 // pixel accumulators -> fp32 bitmap (one rounding per pixel), and the accumulators are left zero for the next call.
 // sign_unit = sign(mag k_ext k_refl) 2^(ex_g - 28).  Two pixels per thread: 16-byte loads, 8-byte stores.
+__global__ __launch_bounds__(kMomentsBlock) void diag_moments_kernel(const float* __restrict__ flux, int Hh, int W, double* __restrict__ moments)
+{
+    __shared__ double s_red[16 * 3];
+    double s, xs, ys;
+    com_part_sums(flux + (int64_t)blockIdx.y * Hh * W, Hh, W, blockIdx.x, s_red, s, xs, ys);
+    if (threadIdx.x == 0) { double* m = moments + ((int64_t)blockIdx.y * kLossParts + blockIdx.x) * 3; m[0] = s; m[1] = xs; m[2] = ys; }
+}
 __global__ __launch_bounds__(256) void accum_to_flux_kernel(unsigned long long* __restrict__ accum, float* __restrict__ flux,
                                                             int64_t npix, float sign_unit)
 {
@@ -3292,7 +3300,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
                              const int32_t* cand_count, int64_t Cmax, double max_scatter_angle,
                              double ray_magnitude, double extinction, double reflectivity, int64_t H, int64_t R,
                              int64_t P, int64_t facet_points, int64_t T, int64_t Tc, int64_t W, int64_t Hh, int mode, float* flux,
-                             float* factors, uint64_t* accum, void* stream_)
+                             float* factors, uint64_t* accum, double* moments, void* stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     TraceArgs a;
@@ -3515,6 +3523,10 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
         const float sign_unit = (kI < 0.0f ? -1.0f : 1.0f) * ldexpf(1.0f, a.ex_g - 28);
         hipLaunchKernelGGL(accum_to_flux_kernel, dim3((unsigned)((npix / 2 + 1 + 255) / 256)), dim3(256), 0, stream, a.accum, flux, npix,
                            sign_unit);
+        // (diagnostic copy: the centre-of-mass sums the product's conversion pass leaves behind are formed from the finished bitmap)
+        if (moments != nullptr && n_maps <= 65535 && Hh >= kLossParts && (((int64_t)Hh * W) & 1) == 0)
+            hipLaunchKernelGGL(diag_moments_kernel, dim3((unsigned)kLossParts, (unsigned)n_maps), dim3(kMomentsBlock), 0, stream, flux, (int)Hh, (int)W, moments);
+        else if (moments != nullptr) ART_HIP(hipMemsetAsync(moments, 0xFF, sizeof(double) * n_maps * kLossParts * 3, stream));
     }
     if (blocking)
         hipLaunchKernelGGL(poison_overflow_kernel, dim3((unsigned)H), dim3(256), 0, stream, a.cand_count, a.Cmax, a.target_idx,

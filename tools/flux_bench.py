@@ -48,7 +48,7 @@ cases["crop_pixel_loss_fwd"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux)
                                 2 * nbytes)
 cases["crop_pixel_loss_fwd_keep"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4),
                                                                               p(resid), p(unit), None, s), 3 * nbytes)
-cases["crop_pixel_loss_bwd"] = (lambda: lib.art_flux_crop_pixel_loss_bwd(p(dims), p(c4), p(gl), p(resid), p(unit), B, Hh, W, 6.0, 6.0,
+cases["crop_pixel_loss_bwd"] = (lambda: lib.art_flux_crop_pixel_loss_bwd(p(dims), p(c4), p(gl), 1, p(resid), p(unit), B, Hh, W, 6.0, 6.0,
                                                                          p(gflux), s), 2 * nbytes)
 res = {}
 for name, (fn, alg) in cases.items():
