@@ -68,6 +68,9 @@ struct TraceArgs {
     // accum_to_flux_kernel turns it into the fp32 bitmap (one rounding per pixel) and leaves it zero again.
     // One unit = sign(k) 2^(ex_g - 28) with 2^ex_g > |mag k_ext k_refl|: the largest single contribution is < 2^28 |d||m| units.
     unsigned long long* accum;
+    // The windows of this launch's work items, by queue position, made by a kernel of their own before the trace kernel starts
+    // (trace_kernels.hip: window_table_kernel) - or NULL: every item works its window out itself, as its first phase.
+    const void* win_table;
     int ex_g;
     float scale_g;            // 2^(28 - ex_g)
     unsigned int* status;     // device status word (mapped host memory): bit 0 = a target index was out of range
@@ -151,7 +154,7 @@ static inline bool fill_args(TraceArgs& a, const float* origins, const float* no
     a.target_idx = target_idx; a.centers = centers; a.pnormals = pnormals; a.dims = dims;
     a.cyl_centers = cyl_centers; a.cyl_normals = cyl_normals; a.cyl_axes = cyl_axes; a.cyl_radii = cyl_radii;
     a.cyl_heights = cyl_heights; a.cyl_opening = cyl_opening; a.Tc = (int)Tc;
-    a.prim_corners = a.prim_spans = a.prim_normals = nullptr; a.cand = a.cand_count = nullptr; a.Cmax = 0; a.wide_grad = nullptr;
+    a.prim_corners = a.prim_spans = a.prim_normals = nullptr; a.cand = a.cand_count = nullptr; a.Cmax = 0; a.wide_grad = nullptr; a.win_table = nullptr;
     a.cone_cos = a.cone_sin = 0.0f; a.slab_cull = 1;
     a.mag = (float)mag; a.k_ext = (float)(1.0 - ext); a.k_refl = (float)refl;
     a.H = (int)H; a.R = (int)R; a.P = (int)P; a.T = (int)T; a.W = (int)W; a.Hh = (int)Hh; a.mode = mode;

@@ -642,6 +642,36 @@ __device__ __forceinline__ WorkItem decode_work_item(const TraceArgs& a, int ite
     return w;
 }
 
+// ---- the windows of a launch's items, made ahead of the launch ------------------------------------------------------------
+// A CU holds ONE trace workgroup, so the window phase of an item - a load round trip, thirteen block reductions, two barriers:
+// ~5 us - is 5 us of an idle CU, sixteen times per CU at the metric size (and what keeps small items from paying).
+// The lean planar launches therefore get their windows from a table, filled by this kernel before they start: one small
+// workgroup per item, thousands of them at once, the same routine (compute_window) on a sample of 256 of the item's points.
+// The window is a guess that only decides which rays go through LDS: results do not depend on who made it.
+// `order`: 0 / 1 the queue runs first-to-last / last-to-first, -1 decided here as the forward kernel decides it.
+template <bool INTERLEAVED>
+__global__ __launch_bounds__(256) void window_table_kernel(TraceArgs a, Window* __restrict__ table, int order)
+{
+    __shared__ float s_red[13][16];
+    __shared__ Window s_win;
+    const int item = blockIdx.x;
+    const bool reverse = order < 0 ? farther_end_is_last(a) : order != 0;
+    const WorkItem w = decode_work_item(a, item, reverse);
+    const int t = a.target_idx[w.h];
+    Window empty = {0, 0, 0, 0, 0, 1, a.scale_g * (1.0f / (float)(1 << kCellShift)), kCellShift, 0, 0};
+    if ((unsigned)t >= (unsigned)a.T || w.r1 <= w.r0) {        // (skipped by the trace kernel as well; cylinders: not served)
+        if (threadIdx.x == 0) table[item] = empty;
+        return;
+    }
+    const Plane pl = load_plane(a.centers, a.pnormals, a.dims, t, a.W, a.Hh, a.mag, a.k_ext, a.k_refl);
+    const Cyl cy = {};
+    int p0, p1;
+    block_range(a, w.pblock, p0, p1, w.tail);
+    compute_window<INTERLEAVED, false>(a, pl, cy, a.incident[w.h], a.origins + (int64_t)w.h * a.P, a.normals + (int64_t)w.h * a.P, p0, p1,
+                                       (int64_t)w.h * a.sh + (int64_t)w.r0 * a.sr, s_red, &s_win);
+    if (threadIdx.x == 0) table[item] = s_win;
+}
+
 // The k-th heliostat (k = 0, 1, ...) with a non-empty candidate list, or -1.  Workgroup-wide (ballots + a scan of the wave
 // totals in LDS); s_scan holds 18 ints.  The blocking launch of a split call has one workgroup per item: mapping the
 // workgroups to the BLOCKED heliostats in order puts the (with the reference's tree: few dozen) workgroups that have work
@@ -1085,21 +1115,25 @@ __device__ __forceinline__ void trace_fwd_item_lean(const TraceArgs& a, float* _
     const float4* __restrict__ nrm = a.normals + (int64_t)h * a.P;
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
-    // ---- phase 1: window (as in the generic item) ------------------------------------------------
+    // ---- phase 1: window (as in the generic item) - or, when the launch came with its windows (window_table_kernel), only the
+    //      clearing of the tile -----------------------------------------------------------------------------------------------
     if (tid < 3) s_cnt[tid] = 0;
+    const Window* const win_table = static_cast<const Window*>(a.win_table);
     const int pf = (a.win_sample != 0 && p1 - p0 > (int)blockDim.x) ? window_sample_point(p0, p1) : p0 + tid;
     FirstPoint fp = {{0.0f, 0.0f, 0.0f, 1.0f}, {0.0f, 0.0f, 1.0f, 0.0f}, 0.0f, 0.0f};
-    if (pf < p1) {
+    if (win_table == nullptr && pf < p1) {
         fp.o = org[pf]; fp.n = nrm[pf];
         load_dist_row<INTERLEAVED>(a.dist_u + dbase, a.dist_e + dbase, pf * (int)a.sp, fp.u, fp.e);
     }
+    if (win_table != nullptr && tid == 0) s_win = win_table[bid];
     {
         uint4* t4 = reinterpret_cast<uint4*>(tile);
         for (int i = tid; i < a.tile_cap / 4; i += blockDim.x) t4[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid < 2) tile[a.tile_cap + tid] = 0u;
     }
     const int n_prims = load_prims<BLOCKING, false>(a, h, s_tab);
-    compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
+    if (win_table != nullptr) __syncthreads();
+    else compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win, &fp);
     const Window win = s_win;
     const float Wf = (float)a.W, Hf = (float)a.Hh;
     // (Packing the edge points into the block's last waves, which takes 8 % off the backward kernel, was measured here too:
@@ -2320,7 +2354,7 @@ template <bool INTERLEAVED, bool ATOMIC_OUT, bool BLOCKING = false, bool CYL = f
 __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const float* __restrict__ grad_flux,
                                                     float4* __restrict__ grad_origins, float4* __restrict__ grad_normals,
                                                     const WorkItem item, unsigned int* __restrict__ work_counter, int* s_next,
-                                                    float* __restrict__ prim_slabs = nullptr)
+                                                    float* __restrict__ prim_slabs = nullptr, const int queue_item = -1)
 {
     extern __shared__ __attribute__((aligned(16))) float gtile[];
     __shared__ float s_red[13][16];
@@ -2364,6 +2398,10 @@ __device__ __forceinline__ void trace_bwd_item_lean(const TraceArgs& a, const fl
     const int64_t dbase = (int64_t)h * a.sh + (int64_t)r0 * a.sr;
 
     const int n_prims = load_prims<BLOCKING>(a, h, s_tab);
+    if (a.win_table != nullptr && queue_item >= 0) {       // the launch came with its items' windows (window_table_kernel)
+        if (tid == 0) s_win = static_cast<const Window*>(a.win_table)[queue_item];
+        __syncthreads();
+    } else
     compute_window<INTERLEAVED, CYL>(a, pl, cy, inc, org, nrm, p0, p1, dbase, s_red, &s_win);
     const Window win = s_win;
     unsigned next_item = 0u;
@@ -2739,7 +2777,7 @@ __global__ __launch_bounds__(CYL ? kCylBwdThreads : (BLOCKING ? (LEAN ? kLeanBlo
     while (item < n_items) {
         if constexpr (LEAN)
             trace_bwd_item_lean<INTERLEAVED, ATOMIC_OUT, BLOCKING, CYL>(a, grad_flux, grad_origins, grad_normals,
-                                                                   decode_work_item(a, item, reverse), work_counter, &s_next, prim_slabs);
+                                                                   decode_work_item(a, item, reverse), work_counter, &s_next, prim_slabs, item);
         else
             trace_bwd_item<INTERLEAVED, ATOMIC_OUT, CYL, BLOCKING>(a, grad_flux, grad_origins, grad_normals, prim_slabs,
                                                                    decode_work_item(a, item, reverse), work_counter, &s_next);
@@ -3125,6 +3163,46 @@ static int64_t host_item_count(const TraceArgs& a)
     return (int64_t)(a.h_group > 1 ? a.n_groups : a.H) * a.n_pblocks * a.n_rchunks;
 }
 
+// The window tables of a stream's launches (window_table_kernel): kWindowTableItems entries per role - forward / backward, main /
+// lean launch of a split call -, allocated once per (device, stream) like the counters below.  A launch with more items than
+// that works its windows out in its items, as every launch did before round 4.
+constexpr int kWindowTableItems = 32768;
+static Window* stream_window_tables(hipStream_t stream)
+{
+    struct Entry { int dev; hipStream_t stream; Window* base; };
+    static std::vector<Entry> table;
+    static std::mutex lock;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> guard(lock);
+    for (const Entry& e : table)
+        if (e.dev == dev && e.stream == stream) return e.base;
+    Window* base = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&base), sizeof(Window) * 4 * kWindowTableItems) != hipSuccess) return nullptr;
+    table.push_back({dev, stream, base});
+    return base;
+}
+// Fills the table of launch `a` (role 0 ... 3) and points the launch at it; leaves a.win_table NULL when there is no table to be had.
+static void launch_window_table(TraceArgs& a, int role, int order, hipStream_t stream)
+{
+    a.win_table = nullptr;
+    const int64_t items = host_item_count(a);
+    // Small fields only.  Measured same-box, step of the bench with / without the table: 125 heliostats (1.25e6 points) 1.198 /
+    // 1.224 ms, 250: 1.945 / 1.925, 500: 3.83 / 3.82, 1000: 7.89 / 7.87 - the trace kernels get 64 + 72 us shorter at the metric
+    // size, and the two table kernels take 77 us each: their sampled points are 400 MB of cache lines that the items' own window
+    // phase reads too, but as a prefetch of what the item traces next.  A field whose points fit the last-level cache (and whose
+    // CUs see four items each, so that every prologue shows) is where the table pays.  (ARTIST_HIP_WINDOW_TABLE = 2 forces it: tests)
+    const int mode = debug_env_int("ARTIST_HIP_WINDOW_TABLE", 1);
+    if (mode == 0 || items < 1 || items > kWindowTableItems || a.h_group > 1) return;
+    if (mode != 2 && (int64_t)a.H * a.P > 1500000) return;
+    Window* base = stream_window_tables(stream);
+    if (base == nullptr) return;
+    Window* tab = base + (int64_t)role * kWindowTableItems;
+    if (interleaved_layout(a)) hipLaunchKernelGGL(window_table_kernel<true>, dim3((unsigned)items), dim3(256), 0, stream, a, tab, order);
+    else hipLaunchKernelGGL(window_table_kernel<false>, dim3((unsigned)items), dim3(256), 0, stream, a, tab, order);
+    a.win_table = tab;
+}
+
 // The queue's finer-grained end (lean kernels, whole samples per item): the heliostats of the LAST round of resident
 // workgroups are cut into twice as many point blocks.  With ~2 items per CU (one of eight ranks' share of the metric field:
 // 500 items of ~200 us on 256 CUs) the queue otherwise ends with half an item of idle time per CU on average; splitting by
@@ -3344,6 +3422,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             if (items_l > 2147483647LL - 65536) return ART_EINVAL;
             const int64_t blocks_l = (debug_env_int("ARTIST_HIP_PERSISTENT", 3) & 1) ? std::min<int64_t>(items_l, resident_workgroups()) : items_l;
             const size_t lds_l = ((size_t)al.tile_cap + 2) * sizeof(unsigned);
+            if (T > 0) launch_window_table(al, 1, -1, stream);          // (on `stream`, ahead of the side stream's start)
             const FwdLaunch launch = {al, flux, counts, work_counters[2]};
             const bool il_l = interleaved_layout(al);
             const int threads_l = cl.block;
@@ -3424,6 +3503,7 @@ extern "C" int art_trace_fwd(const float* origins, const float* normals, const f
             if (K > 1) { a.h_group = std::min(K, a.H); a.n_groups = (a.H + a.h_group - 1) / a.h_group; field_groups = true; }
         }
         if (lean && T > 0 && Tc == 0) set_queue_tail(a, 512);
+        if (lean && T > 0 && Tc == 0 && !field_groups) launch_window_table(a, 0, -1, stream);
         if (debug_env_int("ARTIST_HIP_PRINT_GEOMETRY", 0))
             fprintf(stderr, "art_trace_fwd: H %d P %d unit %d blocks/unit %d p_block %d n_pblocks %d r_chunk %d n_rchunks %d threads %d lean %d group %d tail %d x %d\n",
                     a.H, a.P, a.facet_points, a.blocks_per_facet, a.p_block, a.n_pblocks, a.r_chunk, a.n_rchunks, cfg.block, (int)lean,
@@ -3620,6 +3700,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
                 if (wc == nullptr) { g_last_hip_error = (int)hipErrorOutOfMemory; return ART_ELAUNCH; }
                 wc += 4;                                 // backward, lean launch of a split call
                 const int threads_l = lean_bwd_threads(al.p_block);
+                launch_window_table(al, 3, al.reverse_bwd != 0 ? 1 : 0, stream);
                 // submitted AFTER the blocking launch (see art_trace_fwd)
                 SideStream* ss = side_stream();
                 if (ss != nullptr && !ss->begin(stream)) ss = nullptr;
@@ -3643,6 +3724,7 @@ extern "C" int art_trace_bwd(const float* origins, const float* normals, const f
             }
         }
         if (lean && a.n_rchunks == 1) set_queue_tail(a, 384);
+        if (lean && T > 0 && Tc == 0) launch_window_table(a, 2, a.reverse_bwd != 0 ? 1 : 0, stream);
         if (lean) cfg.block = lean_bwd_threads(a.p_block);       // (the geometry is fixed by now)
         const int64_t items = host_item_count(a);
         if (items > 2147483647LL - 65536) return ART_EINVAL;

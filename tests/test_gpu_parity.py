@@ -2024,13 +2024,16 @@ def test_scenario_file_to_flux(golden, name):
                                    dict(ARTIST_HIP_WINDOW_SAMPLE="0"), dict(ARTIST_HIP_BWD_THREADS="1024"), dict(ARTIST_HIP_BWD_THREADS="768"),
                                    dict(ARTIST_HIP_BWD_THREADS="1024", ARTIST_HIP_BWD_PBLOCK="640"),
                                    dict(ARTIST_HIP_BWD_THREADS="1024", ARTIST_HIP_BWD_PACK="200"),
-                                   dict(ARTIST_HIP_BWD_THREADS="1024", ARTIST_HIP_TAIL="2", ARTIST_HIP_BWD_PBLOCK="320")])
+                                   dict(ARTIST_HIP_BWD_THREADS="1024", ARTIST_HIP_TAIL="2", ARTIST_HIP_BWD_PBLOCK="320"),
+                                   dict(ARTIST_HIP_WINDOW_TABLE="0"), dict(ARTIST_HIP_WINDOW_TABLE="2", ARTIST_HIP_TAIL="2"),
+                                   dict(ARTIST_HIP_WINDOW_TABLE="0", ARTIST_HIP_BWD_REVERSE="1")])
 def test_work_queue_variants_give_the_same_results(golden, monkeypatch, knobs):
     """The windowed kernels hand out (heliostat, point block, sample chunk) items through a work queue: persistent
     workgroups (default) or one workgroup per item, the lean or the generic ray body, other point-block sizes, samples cut
     into more chunks, the backward kernel's edge points packed or not (and with a margin that makes every point an edge point,
     and with a small window), the lean backward kernel launched with 768 or 1024 threads per workgroup, the queue's end cut into finer point blocks (ARTIST_HIP_TAIL=2: in both kernels, any field
-    size), the window phase on every point instead of a sample.  However the items are dealt, the bitmaps are the same BITS
+    size), the window phase on every point instead of a sample, the items' windows from a table made ahead of the launch (the default
+    for a field this small) or by the items themselves.  However the items are dealt, the bitmaps are the same BITS
     (integer pixel accumulators); the gradients are the same bits as long as a point's samples are summed in the same order
     (everything but the chunking)."""
     from artist_amd import trace_rays
