@@ -13,6 +13,8 @@ names = {"final_bench.json": "bench_line.json", "final_bench_h125.json": "bench_
          "final_nurbs_bench.json": "nurbs_bench.json", "final_nurbs_mfma_bench.json": "nurbs_mfma_bench.json",
          "final_pipeline_probe.txt": "pipeline_probe.txt", "final_kstats.txt": "kernel_stats_top.txt",
          "final_kstats_h125.txt": "kernel_stats_top_h125.txt", "final_gap_h125.txt": "gap_report_h125.txt", "final_gap.txt": "gap_report.txt",
+         "final_blocking_bench_dense.json": "blocking_bench_dense.json", "final_adam_bench.json": "adam_bench.json",
+         "final_per_target_bench.json": "per_target_bench.json", "final_parity_margins.txt": "parity_margins.txt",
          "final_pmc_summary.txt": "pmc_summary.txt", "pmc_finallds_summary.txt": "pmc_lds_conflicts.txt"}
 for a, b in names.items():
     if (src / a).exists() and (src / a).stat().st_size > 0:

@@ -32,4 +32,4 @@ print("r03 fwd", timed(lambda: old.art_flux_crop_pixel_loss_fwd(p(flux), p(dims)
 print("r03 bwd", timed(lambda: old.art_flux_crop_pixel_loss_bwd(p(flux), p(dims), p(truth), p(c4), p(gl), B, Hh, W, 6.0, 6.0, p(gflux), p(ws2), s)))
 print("new fwd", timed(lambda: new.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4), None, None, None, s)))
 print("new fwd keep", timed(lambda: new.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4), p(resid), p(unit), None, s)))
-print("new bwd", timed(lambda: new.art_flux_crop_pixel_loss_bwd(p(dims), p(c4), p(gl), p(resid), p(unit), B, Hh, W, 6.0, 6.0, p(gflux), s)))
+print("new bwd", timed(lambda: new.art_flux_crop_pixel_loss_bwd(p(dims), p(c4), p(gl), 1, p(resid), p(unit), B, Hh, W, 6.0, 6.0, p(gflux), s)))
