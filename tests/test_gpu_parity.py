@@ -1033,14 +1033,21 @@ def crowd(blk, k, n_extra):
                 normals=cat(blk["normals"], rep(nn)), lbvh_compat=False)
 
 
+@pytest.mark.parametrize("body", ["lean", "generic", "unbounded rows"])
 @pytest.mark.parametrize("n_extra", [30, 40, 110])
-def test_more_candidates_than_the_tables_hold(golden, n_extra):
+def test_more_candidates_than_the_tables_hold(golden, monkeypatch, n_extra, body):
     """A heliostat with more candidate rectangles than the kernels keep in LDS (32; artist/raytracing/blocking.py:212-354 has no
     such number: every ray meets every filtered rectangle) is traced, not refused: the sigmas of the others are added from the
     caller's tables (40 more: through the wave's 64-bit mask; 110 more: the ones beyond it for every ray; 30 more: a list of
     exactly 32, the last case that is NOT wide - bit 31 of the masks is then a rectangle like any other).  Forward and
-    backward - rays and rectangles - against the oracle, which has no limit."""
+    backward - rays and rectangles - against the oracle, which has no limit; through the lean ray bodies (what a planar tower
+    takes), the generic ones (``ARTIST_HIP_BLOCK_LEAN=0``: what a tower with cylinders takes), and with candidate rows as wide as
+    the table of rectangles (``BLOCKING_CANDIDATES = None``)."""
     from artist_amd import ops, trace_rays
+    if body == "generic":
+        monkeypatch.setenv("ARTIST_HIP_BLOCK_LEAN", "0")
+    if body == "unbounded rows":
+        monkeypatch.setattr(ops, "BLOCKING_CANDIDATES", None)
     d = golden("small_blocking")
     H = d["aligned_points"].shape[0]
     k = int(d["filter_indices"][0])

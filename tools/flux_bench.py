@@ -50,6 +50,14 @@ cases["crop_pixel_loss_fwd_keep"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(
                                                                               p(resid), p(unit), None, s), 3 * nbytes)
 cases["crop_pixel_loss_bwd"] = (lambda: lib.art_flux_crop_pixel_loss_bwd(p(dims), p(c4), p(gl), 1, p(resid), p(unit), B, Hh, W, 6.0, 6.0,
                                                                          p(gflux), s), 2 * nbytes)
+# the same pass with the centre-of-mass sums handed over (as the trace's conversion pass leaves them: include/artist_hip.h `moments`)
+lin = lambda k: torch.linspace(-1, 1, k, device=dev, dtype=torch.float64)
+f64 = flux.double()
+parts = [f64[:, (Hh * v) // 4:(Hh * (v + 1)) // 4] for v in range(4)]
+ysl = [lin(Hh)[(Hh * v) // 4:(Hh * (v + 1)) // 4] for v in range(4)]
+mom = torch.stack([torch.stack([q.sum((1, 2)), (q * lin(W)[None, None, :]).sum((1, 2)), (q * y[None, :, None]).sum((1, 2))], 1) for q, y in zip(parts, ysl)], 1).contiguous()
+cases["crop_pixel_loss_fwd_keep_moments"] = (lambda: lib.art_flux_crop_pixel_loss_fwd(p(flux), p(dims), p(truth), B, Hh, W, 6.0, 6.0, p(loss), p(c4),
+                                                                                      p(resid), p(unit), p(mom), s), 3 * nbytes)
 res = {}
 for name, (fn, alg) in cases.items():
     ms = timed(fn)
