@@ -335,6 +335,29 @@ __global__ __launch_bounds__(256) void flux_crop_bwd_tiled_kernel(const float* _
     //  that the loads of several rows are in flight together: with a branch per tap every load was waited for in turn
     //  and a workgroup took 26 us for 6 000 loads)
     const int xr = in_x ? 1 : 0;
+    if (W >= 4) {
+        // the four taps of a row are four consecutive floats: ONE 16-byte load at 4-byte alignment (from column min(j0, W - 4);
+        // the weights move with it - absent taps carry weight 0 - so the non-zero products are added in the same order: same bits)
+        struct __attribute__((packed, aligned(4))) Taps { float t0, t1, t2, t3; };
+        const int cb = in_x ? min(j0, W - 4) : 0, sh = in_x ? j0 - cb : 0;
+        const float w0 = sh == 0 ? wx0 : 0.0f, w1 = sh == 0 ? wx1 : (sh == 1 ? wx0 : 0.0f);
+        const float w2 = sh == 0 ? wx2 : (sh == 1 ? wx1 : (sh == 2 ? wx0 : 0.0f));
+        const float w3 = sh == 0 ? wx3 : (sh == 1 ? wx2 : (sh == 2 ? wx1 : wx0));
+        for (int r = threadIdx.x / kTileX; r <= ihi - ilo; r += kRowUnroll * (256 / kTileX)) {
+            float v[kRowUnroll];
+#pragma unroll
+            for (int q = 0; q < kRowUnroll; ++q) {
+                const int rr = min(r + q * (256 / kTileX), ihi - ilo);
+                const Taps t = *reinterpret_cast<const Taps*>(g + (int64_t)(ilo + rr) * W + cb);
+                v[q] = ((t.t0 * w0 + t.t1 * w1) + t.t2 * w2) + t.t3 * w3;
+            }
+#pragma unroll
+            for (int q = 0; q < kRowUnroll; ++q) {
+                const int rr = r + q * (256 / kTileX);
+                if (rr <= ihi - ilo) s_t[rr][tx] = in_x ? v[q] : 0.0f;
+            }
+        }
+    } else
     for (int r = threadIdx.x / kTileX; r <= ihi - ilo; r += kRowUnroll * (256 / kTileX)) {
         float v[kRowUnroll];
 #pragma unroll
