@@ -3166,7 +3166,7 @@ static int64_t host_item_count(const TraceArgs& a)
 // The window tables of a stream's launches (window_table_kernel): kWindowTableItems entries per role - forward / backward, main /
 // lean launch of a split call -, allocated once per (device, stream) like the counters below.  A launch with more items than
 // that works its windows out in its items, as every launch did before round 4.
-constexpr int kWindowTableItems = 32768;
+constexpr int kWindowTableItems = 4096;      // (the table serves small fields only: 640 KB per stream that ever launched one)
 static Window* stream_window_tables(hipStream_t stream)
 {
     struct Entry { int dev; hipStream_t stream; Window* base; };
