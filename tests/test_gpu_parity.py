@@ -1173,6 +1173,57 @@ def test_blocking_through_ray_tracer_mirror():
     assert rel_l2(n(points.grad), go + g_sfc) < 5e-3, rel_l2(n(points.grad), go + g_sfc)
 
 
+def test_dense_rows_under_a_low_sun_through_the_ray_tracer():
+    """The drop-in class on a field that NEEDS long candidate lists: 30 rows of four heliostats 2.6 m apart behind a target
+    12 m up, the sun 6 degrees above the horizon - the beams of the back rows pass through dozens of mirrors.  Until round 4 such a
+    heliostat came back as a NaN bitmap (more than 32 candidate rectangles); now: bitmaps, the three factors and the gradient
+    of the aligned points (ray origins + rectangle corners) against the CPU restatement, which has no limit
+    (artist/raytracing/blocking.py:212-354, 832-995)."""
+    from artist_amd import HeliostatRayTracer, ops
+    from artist_amd.scene import build_synthetic_scenario
+    H = 120
+    scenario, _ = build_synthetic_scenario(H, 8, n_eval=12, device=DEV, target_centers=((0.0, 0.0, 12.0, 1.0),))
+    group = scenario.heliostat_field.heliostat_groups[0]
+    i = torch.arange(H, device=DEV)
+    group.positions = torch.stack([((i % 4) - 1.5) * 3.4, 30.0 + (i // 4) * 2.6, torch.zeros(H, device=DEV), torch.ones(H, device=DEV)], dim=1)
+    mask = torch.ones(H, dtype=torch.int32, device=DEV)
+    tix = torch.zeros(H, dtype=torch.long, device=DEV)
+    inc = torch.nn.functional.normalize(torch.tensor([0.0, 0.9945, -0.1045, 0.0], device=DEV), dim=0).expand(H, 4).contiguous()
+    group.activate_heliostats(mask, DEV)
+    group.align_surfaces_with_incident_ray_directions(scenario.solar_tower.get_centers_of_target_areas(tix), inc, mask, DEV)
+    points = group.active_surface_points.detach().requires_grad_(True)
+    group.active_surface_points = points
+    rt = HeliostatRayTracer(scenario, group, bitmap_resolution=torch.tensor([64, 64]))           # blocking by default
+    rt.lbvh_compat = False
+    flux, intercept, on_target, unblocked = rt.trace_rays(inc, mask, tix)
+    counts = n(ops._LAST_BLOCKING[1])
+    print(f"candidates per heliostat: max {counts.max()}, {int((counts > 32).sum())} of {H} beyond 32; unblocked fraction "
+          f"{float(unblocked.min()):.3f} ... {float(unblocked.max()):.3f}")
+    assert counts.max() > 40 and (counts > 32).sum() >= 10
+    assert np.isfinite(n(flux)).all() and np.isfinite(n(unblocked)).all()
+    planar = scenario.solar_tower.target_areas[0]
+    prims = oracle.blocking_primitives(n(points))
+    blk = dict(corners=prims[0], spans=prims[1], normals=prims[2], owner=np.arange(H, dtype=np.int32), lbvh_compat=False)
+    common = (n(points), n(group.active_surface_normals), n(inc), n(rt.distortions_dataset.distortions_u),
+              n(rt.distortions_dataset.distortions_e), n(tix), n(planar.centers), n(planar.normals), n(planar.dimensions), (64, 64))
+    o_flux, o_fac, dbg = oracle.trace_fwd(*common, debug=True, blocking=blk)
+    assert sorted(rt.filtered_blocking_primitive_indices.tolist()) == np.nonzero(dbg["filter_flags"])[0].tolist()
+    err = rel_l2(n(flux), o_flux)
+    print(f"flux {err:.2e}")
+    assert err < 5e-6, err                                  # (measured 3.7e-7; 66 of the 120 heliostats list more than 32, the longest list 96)
+    rays = dbg["blocked"][0].size
+    np.testing.assert_allclose(n(unblocked), o_fac[2], rtol=0, atol=2.0 / rays)
+    np.testing.assert_allclose(n(intercept), o_fac[0], rtol=0, atol=2.0 / rays)
+    w = torch.rand(flux.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    (flux * w).sum().backward()
+    go, gn, gpc, gps, gpn = oracle.trace_bwd(*common, n(w), blocking=blk)
+    import test_oracle_golden as tog
+    _, _, _, g_sfc = tog._chain_primitive_grads(n(points), gpc, gps, gpn)
+    gerr = rel_l2(n(points.grad), go + g_sfc)
+    print(f"gradient of the aligned points {gerr:.2e}")
+    assert gerr < 1e-4, gerr                                # (measured 3.6e-6)
+
+
 def test_per_point_rectangle_culling_changes_speed_only(monkeypatch):
     """The trace kernels drop, per surface point, the rectangles none of the point's rays can enter (cone against bounding
     sphere, then the three slabs of ``cone_mask``, ray_math.hpp) and the filter does the same with the grown boxes: both

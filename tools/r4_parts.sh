@@ -1,6 +1,6 @@
 #!/bin/bash
 export ARTIST_HIP_DEBUG=1
-for B in 500 250; do for parts in 1 2 4; do
+for B in 125 64; do for parts in 1 2 4; do
   echo "B $B parts $parts: $(ARTIST_HIP_LOSS_PARTS=$parts timeout -k 10 200 python tools/flux_bench.py $B 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
